@@ -1,0 +1,533 @@
+"""Generate the golden fixtures in this directory by RUNNING THE REFERENCE.
+
+Run once, in the build container (the only place /root/reference exists):
+
+    python tests/golden/make_golden.py
+
+The reference's own .py files are imported unmodified from /root/reference with the two
+absent third-party modules stood in (see _pyg_standin.py for exactly what is stood in and
+what that means for these vectors).  Every case records INPUTS (graph, agent attributes,
+state before the step, step scalars, the Exponential(1) noise the sampler drew) and
+OUTPUTS per stage of the path.  At generation time the CPU
+oracle (oracle/gj_oracle.py) is asserted equal to the reference on every case.
+
+Files written (data only - no reference source text):
+    kat6.npz          6-agent / 2-school graph of test/unit/infection_networks/test_base.py:22-44
+    c100.npz          100-agent graph of test/conftest.py:36-89 (seed 999), several policy variants
+    june769.npz       test/data/data.pkl + configs/default.yaml: 15-step trajectory, 11 networks
+    june769_hot.npz   the same with every log_beta raised by 0.9 (a real epidemic wave)
+    synth10k.npz      10k-agent synthetic with degree-0/1 venues, a 5k-agent venue, duplicates
+    world769.npz      test/data/data.pkl as neutral arrays (graph + agent attributes)
+    default_params.json   yaml.safe_load(configs/default.yaml) (dates stringified)
+"""
+from __future__ import annotations
+
+import copy
+import datetime
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import _pyg_standin  # noqa: E402
+
+grad_june = _pyg_standin.import_reference()
+
+import torch  # noqa: E402
+import yaml  # noqa: E402
+from torch_geometric.data import HeteroData  # noqa: E402  (stand-in container)
+import torch_geometric.transforms as T  # noqa: E402
+
+import gj_oracle as O  # noqa: E402
+
+from grad_june import GradJune, Timer, Runner  # noqa: E402
+from grad_june.infection import infect_people_at_indices  # noqa: E402
+from grad_june.infection_networks import InfectionNetworks  # noqa: E402
+from grad_june.infection_networks.base import (  # noqa: E402
+    CompanyNetwork,
+    HouseholdNetwork,
+    SchoolNetwork,
+)
+from grad_june.paths import default_config_path  # noqa: E402
+from grad_june.policies import Policies, Quarantine, SocialDistancing, CloseVenue  # noqa: E402
+from grad_june.transmission import TransmissionSampler  # noqa: E402
+
+EDGE_SETS = ["household", "company", "school", "university", "care_home", "leisure"]
+
+
+def seed_all(seed):
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+
+
+# ------------------------------------------------------------------------------------------
+# neutral views of a reference HeteroData
+# ------------------------------------------------------------------------------------------
+def world_of(data):
+    A = len(data["agent"].id)
+    w = {"n_agents": A, "edge_sets": {}}
+    if "age" in data["agent"]:
+        w["age"] = data["agent"].age.clone()
+        w["sex"] = data["agent"].sex.clone()
+    else:
+        w["age"] = torch.zeros(A, dtype=torch.long)
+        w["sex"] = torch.zeros(A, dtype=torch.long)
+    for s in EDGE_SETS:
+        key = ("agent", "attends_" + s, s)
+        if key not in data:
+            continue
+        ei = data[key].edge_index
+        people = data[s]["people"]
+        if not isinstance(people, torch.Tensor):
+            people = torch.as_tensor(np.asarray(people))
+        w["edge_sets"][s] = {"agent": ei[0].clone(), "venue": ei[1].clone(), "people": people.clone()}
+    return w
+
+
+def state_of(data):
+    ag = data["agent"]
+    st = {k: ag["infection_parameters"][k].detach().clone() for k in ("max_infectiousness", "shape", "rate", "shift")}
+    for k in ("infection_time", "is_infected", "susceptibility"):
+        st[k] = ag[k].detach().clone()
+    st["current_stage"] = ag["symptoms"]["current_stage"].detach().clone()
+    return st
+
+
+def flat_world(w, out, prefix="world/"):
+    out[prefix + "n_agents"] = np.int64(w["n_agents"])
+    out[prefix + "age"] = w["age"].numpy()
+    out[prefix + "sex"] = w["sex"].numpy()
+    for s, es in w["edge_sets"].items():
+        out[f"{prefix}es/{s}/agent"] = es["agent"].numpy()
+        out[f"{prefix}es/{s}/venue"] = es["venue"].numpy()
+        out[f"{prefix}es/{s}/people"] = es["people"].numpy()
+
+
+def tables_of(model):
+    tabs = {}
+    for name, net in model.infection_networks.networks.items():
+        if hasattr(net, "leisure_probabilities"):
+            tabs[name] = net.leisure_probabilities.detach().clone()
+    return tabs
+
+
+# ------------------------------------------------------------------------------------------
+# one instrumented step: same call sequence as GradJune.forward (model.py:112-144)
+# ------------------------------------------------------------------------------------------
+def capture_step(model, data, timer, *, run_symptoms=True):
+    rec = {}
+    pre = state_of(data)
+    for k, v in pre.items():
+        rec["pre/" + k] = v.numpy().copy()
+    policies = model.policies
+    nets = model.infection_networks
+    rec["now"] = np.float64(timer.now)
+    rec["dt"] = np.float64(timer.duration)
+    rec["day_type"] = np.int64(0 if timer.day_type == "weekday" else 1)
+
+    with torch.no_grad():
+        data["agent"].transmission = model.transmission_updater(data=data, timer=timer)
+        rec["transmission"] = data["agent"].transmission.numpy().copy()
+        not_inf = nets(data=data, timer=timer, policies=policies)
+        rec["not_infected_probs"] = not_inf.numpy().copy()
+
+        # what the container call used: order, betas, quarantine thresholds / mask
+        order = timer.get_activity_order()
+        if policies.close_venue_policies:
+            order = policies.close_venue_policies.apply(edge_types=order, timer=timer)
+        rec["active"] = np.array(",".join(order))
+        if policies.quarantine_policies:
+            qm = policies.quarantine_policies.quarantine_mask
+            rec["qmask"] = qm.numpy().copy()
+            thr = [
+                (float(p.stage_threshold) if p.is_active(timer.date) else np.nan)
+                for p in policies.quarantine_policies.policies
+            ]
+            rec["q_thresholds"] = np.array(thr, dtype=np.float64)
+            rec["has_quarantine"] = np.int64(1)
+        else:
+            rec["has_quarantine"] = np.int64(0)
+            rec["q_thresholds"] = np.zeros(0)
+        for name in order:
+            net = nets[name]
+            beta_v = net._get_beta(policies=policies, timer=timer, data=data)
+            rec["beta/" + name] = np.float32(beta_v[0].item()) if len(beta_v) else np.float32(
+                (10.0 ** net.log_beta).item()
+            )
+            people = net._get_people_per_group(data)
+            pc = torch.maximum(torch.minimum(1.0 / (people - 1), torch.tensor(1.0)), torch.tensor(0.0))
+            trans = net._get_transmissions(data=data, policies=policies, timer=timer)
+            cum = net.propagate(net._get_edge_index(data), x=trans, y=beta_v * pc)
+            rec["cum/" + name] = cum.numpy().copy()
+            rec["ts/" + name] = net(data=data, timer=timer, policies=policies).numpy().copy()
+
+        rng = torch.get_rng_state()
+        new_inf = model.is_infected_sampler(not_inf)
+        after = torch.get_rng_state()
+        torch.set_rng_state(rng)
+        noise = torch.empty(2, not_inf.shape[0]).exponential_()
+        assert torch.equal(torch.get_rng_state(), after), "sampler drew something else"
+        rec["exp_noise"] = noise.numpy().copy()
+        rec["new_infected"] = new_inf.numpy().copy()
+        assert torch.equal(O.sample_infected(not_inf, noise), new_inf)
+
+        model.infect_people(data, timer, new_inf)
+        for k in ("susceptibility", "is_infected", "infection_time"):
+            rec["post/" + k] = data["agent"][k].numpy().copy()
+        if run_symptoms:
+            model.symptoms_updater(data=data, timer=timer, new_infected=new_inf)
+    return rec, pre
+
+
+def check_oracle(rec, pre, world, tables, atol=0.0):
+    """Assert that oracle/gj_oracle.py reproduces what the reference just computed."""
+    active = str(rec["active"]).split(",") if str(rec["active"]) else []
+    betas = {n: float(rec["beta/" + n]) for n in active}
+    thr = None
+    if int(rec["has_quarantine"]):
+        thr = [None if np.isnan(t) else float(t) for t in rec["q_thresholds"]]
+    out = O.hot_path_step(
+        world, pre, now=float(rec["now"]), delta_time=float(rec["dt"]), day_type=int(rec["day_type"]),
+        active=active, betas=betas, leisure_tables=tables, quarantine_thresholds=thr,
+        exp_noise=torch.from_numpy(rec["exp_noise"]), return_intermediates=True,
+    )
+
+    def same(a, b, what):
+        a = a.numpy() if isinstance(a, torch.Tensor) else a
+        if atol == 0.0:
+            ok = np.array_equal(a, b, equal_nan=True)
+        else:
+            ok = np.allclose(a, b, rtol=0, atol=atol, equal_nan=True)
+        assert ok, f"oracle != reference at {what}: max|d|={np.nanmax(np.abs(a - b))}"
+
+    same(out["transmission"], rec["transmission"], "transmission")
+    for n in active:
+        same(out["cum_" + n], rec["cum/" + n], "cum/" + n)
+        same(out["ts_" + n], rec["ts/" + n], "ts/" + n)
+    same(out["not_infected_probs"], rec["not_infected_probs"], "not_infected_probs")
+    same(out["new_infected"], rec["new_infected"], "new_infected")
+    for k in ("susceptibility", "is_infected", "infection_time"):
+        same(out[k], rec["post/" + k], "post/" + k)
+
+
+def add_steps(out, recs, prefix="step"):
+    out["n_steps"] = np.int64(len(recs))
+    for i, rec in enumerate(recs):
+        for k, v in rec.items():
+            out[f"{prefix}{i}/{k}"] = v
+
+
+def save(name, out):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **out)
+    print(f"wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB, {len(out)} arrays")
+
+
+# ------------------------------------------------------------------------------------------
+# case: kat6  (test_base.py:22-44)
+# ------------------------------------------------------------------------------------------
+def make_kat6():
+    data = HeteroData()
+    data["agent"].id = torch.arange(6)
+    data["agent"].transmission = torch.tensor([0.1, 0.2, 0.3, 0.4, 0.5, 0.6])
+    data["agent"].susceptibility = torch.tensor([1, 2, 3, 0.5, 0.7, 1.0])
+    data["school"].id = torch.arange(2)
+    data["school"].people = torch.tensor([2, 2])
+    data["agent", "attends_school", "school"].edge_index = torch.vstack(
+        (torch.arange(6), torch.tensor([0, 0, 0, 1, 1, 1]))
+    )
+    data = T.ToUndirected()(data)
+    nets = InfectionNetworks(school=SchoolNetwork(log_beta=np.log10(2.0)))
+    timer = Timer(initial_day="2022-02-01", total_days=10, weekday_step_duration=(24,),
+                  weekend_step_duration=(24,), weekday_activities=(("school",),),
+                  weekend_activities=(("school",),))
+    p = nets(data=data, timer=timer, policies=Policies())
+    expected = np.exp(-np.array([1.2, 2.4, 3.6, 1.5, 2.1, 3]))
+    assert np.allclose(p.detach().numpy(), expected)
+    out = {}
+    flat_world(world_of(data), out)
+    out["transmission"] = data["agent"].transmission.numpy()
+    out["susceptibility"] = data["agent"].susceptibility.numpy()
+    out["beta/school"] = np.float32((10.0 ** nets["school"].log_beta).item())
+    out["dt"] = np.float64(timer.duration)
+    out["not_infected_probs"] = p.detach().numpy()
+    out["expected_exponent"] = np.array([1.2, 2.4, 3.6, 1.5, 2.1, 3.0])
+    save("kat6.npz", out)
+
+
+# ------------------------------------------------------------------------------------------
+# case: c100  (conftest.py:36-89 under seed 999)
+# ------------------------------------------------------------------------------------------
+def conftest_data():
+    seed_all(999)
+    sampler = TransmissionSampler.from_file()
+    n = 100
+    data = HeteroData()
+    data["agent"].id = torch.arange(0, n)
+    data["agent"].age = torch.randint(0, 100, (n,))
+    data["agent"].sex = torch.randint(0, 2, (n,))
+    v = sampler(n)
+    data["agent"].infection_parameters = {
+        "max_infectiousness": v[0], "shape": v[1], "rate": v[2], "shift": v[3]}
+    data["agent"].transmission = torch.zeros(n)
+    data["agent"].susceptibility = torch.ones(n)
+    data["agent"].is_infected = torch.zeros(n)
+    data["agent"].infection_time = torch.zeros(n)
+    data["agent"].symptoms = {
+        "current_stage": torch.ones(n, dtype=torch.long),
+        "next_stage": torch.ones(n, dtype=torch.long),
+        "time_to_next_stage": torch.zeros(n)}
+    data["school"].id = torch.arange(0, 4)
+    data["school"].people = 25 * torch.ones(4)
+    data["company"].id = torch.arange(0, 4)
+    data["company"].people = 25 * torch.ones(4)
+    data["household"].id = torch.arange(0, 25)
+    data["household"].people = 4 * torch.ones(25)
+    data["agent", "attends_school", "school"].edge_index = torch.vstack(
+        (data["agent"].id, torch.tensor(np.repeat(np.arange(0, 4), 25))))
+    data["agent", "attends_company", "company"].edge_index = torch.vstack(
+        (data["agent"].id, torch.tensor(np.repeat(np.arange(0, 4), 25))))
+    data["agent", "attends_household", "household"].edge_index = torch.vstack(
+        (data["agent"].id, torch.tensor(np.repeat(np.arange(0, 25), 4))))
+    data = T.ToUndirected()(data)
+    return infect_people_at_indices(data, list(range(0, 100, 10)))
+
+
+def make_c100():
+    out = {}
+    base = conftest_data()
+    world = world_of(base)
+    flat_world(world, out)
+    variants = {}
+
+    def three_nets(lb=0.5):
+        return InfectionNetworks(
+            household=HouseholdNetwork(log_beta=lb), company=CompanyNetwork(log_beta=lb),
+            school=SchoolNetwork(log_beta=lb))
+
+    def tm(acts, day="2022-02-01"):
+        return Timer(initial_day=day, total_days=10, weekday_step_duration=(24,),
+                     weekend_step_duration=(24,), weekday_activities=(tuple(acts),),
+                     weekend_activities=(tuple(acts),))
+
+    # v0: plain model step at t=3 days (test_model.py:25-33 shape)
+    variants["plain_t3"] = (three_nets(), Policies.from_policy_list([]), tm(["company", "school", "household"]), 3, 0.0)
+    # v1: no policy collections at all (Policies(): quarantine mask is the scalar 1.0)
+    variants["nopolicy_t5"] = (three_nets(0.3), Policies(), tm(["company", "household"]), 5, 0.0)
+    # v2: quarantine active, everyone at stage 5 >= 3 (test_quarantine_policies.py:40-72)
+    q = Quarantine(stage_threshold=3, start_date="2022-02-01", end_date="2022-03-15", device="cpu")
+    variants["quarantine"] = (three_nets(3.0), Policies.from_policy_list([q]), tm(["company", "household"]), 2, 1.0)
+    # v3: social distancing (test_interaction_policies.py:92-123)
+    sd = SocialDistancing(start_date="2022-02-01", end_date="2022-02-25",
+                          beta_factors={"school": 0.3, "company": 0.5}, device="cpu")
+    variants["distancing"] = (three_nets(0.2), Policies.from_policy_list([sd]), tm(["company", "school"]), 4, 1.0)
+    # v4: close venue (test_close_venue_policies.py:46-69)
+    cv = CloseVenue(names=("company",), start_date="2022-02-01", end_date="2022-02-25", device="cpu")
+    variants["closed"] = (three_nets(1.0), Policies.from_policy_list([cv]), tm(["company", "household"]), 1, 1.0)
+    # v5: two quarantine policies, one inactive, mixed stages
+    q1 = Quarantine(stage_threshold=4, start_date="2022-02-01", end_date="2022-03-15", device="cpu")
+    q2 = Quarantine(stage_threshold=2, start_date="2023-02-01", end_date="2023-03-15", device="cpu")
+    variants["quarantine_mixed"] = (three_nets(0.8), Policies.from_policy_list([q1, q2]), tm(["company", "school", "household"]), 6, 0.5)
+
+    names = []
+    for vname, (nets, policies, timer, n_next, add_trans) in variants.items():
+        seed_all(1000 + len(names))
+        data = copy.deepcopy(base)
+        if vname == "quarantine":
+            data["agent"]["symptoms"]["current_stage"] = 5 * torch.ones(100)
+        if vname == "quarantine_mixed":
+            data["agent"]["symptoms"]["current_stage"] = torch.randint(0, 8, (100,)).float()
+        for _ in range(n_next):
+            next(timer)
+        model = GradJune(infection_networks=nets, policies=policies)
+        if add_trans:
+            # the policy integration tests add a constant to transmission; emulate by shifting
+            # max_infectiousness so the recorded path stays a1 -> a9 end to end
+            data["agent"]["infection_parameters"]["max_infectiousness"] = (
+                data["agent"]["infection_parameters"]["max_infectiousness"] * (1.0 + add_trans))
+        rec, pre = capture_step(model, data, timer, run_symptoms=False)
+        check_oracle(rec, pre, world, tables_of(model))
+        for k, v in rec.items():
+            out[f"{vname}/{k}"] = v
+        names.append(vname)
+    out["variants"] = np.array(",".join(names))
+    save("c100.npz", out)
+
+
+# ------------------------------------------------------------------------------------------
+# case: june769  (data.pkl + default.yaml; Runner.forward sequence, runner.py:151-183)
+# ------------------------------------------------------------------------------------------
+def default_params():
+    with open(default_config_path) as f:
+        return yaml.safe_load(f)
+
+
+def jsonable(o):
+    if isinstance(o, dict):
+        return {str(k): jsonable(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [jsonable(v) for v in o]
+    if isinstance(o, (datetime.date, datetime.datetime)):
+        return o.strftime("%Y-%m-%d")
+    return o
+
+
+def make_june769(tag="june769", beta_shift=0.0, write_world=True):
+    params = default_params()
+    for n in params["networks"]:
+        params["networks"][n]["log_beta"] = params["networks"][n]["log_beta"] + beta_shift
+    # policies that actually bite inside the 15 simulated days
+    params["policies"]["quarantine"] = {
+        "quarantine": {1: {"start_date": "2022-02-05", "end_date": "2022-02-12", "stage_threshold": 4}}}
+    params["policies"]["close_venue"] = {
+        "close_venue": {1: {"start_date": "2022-02-10", "end_date": "2022-02-13", "names": ["school", "pub"]}}}
+    params["policies"]["interaction"]["social_distancing"][1]["start_date"] = "2022-02-08"
+    seed_all(769)
+    runner = Runner.from_parameters(params)
+    world = world_of(runner.data)
+    out = {}
+    flat_world(world, out)
+    with open(os.path.join(HERE, "default_params.json"), "w") as f:
+        json.dump(jsonable(default_params()), f, indent=1, sort_keys=True)
+    out["params_json"] = np.array(json.dumps(jsonable(params), sort_keys=True))
+    tabs = tables_of(runner.model)
+    for n, t in tabs.items():
+        out["table/" + n] = t.numpy()
+    for n, net in runner.model.infection_networks.networks.items():
+        out["log_beta/" + n] = np.float32(net.log_beta.item())
+
+    # Runner.forward, instrumented
+    timer, model, data = runner.timer, runner.model, runner.data
+    with torch.no_grad():
+        timer.reset()
+        runner.restore_initial_data()
+        runner.set_initial_cases()
+    out["seed/is_infected"] = data["agent"].is_infected.numpy().copy()
+    cases = [float(data["agent"].is_infected.sum())]
+    recs = []
+    while timer.date < timer.final_date:
+        next(timer)
+        rec, pre = capture_step(model, data, timer, run_symptoms=True)
+        check_oracle(rec, pre, world, tabs)
+        recs.append(rec)
+        cases.append(float(data["agent"].is_infected.sum()))
+    add_steps(out, recs)
+    out["cases_per_timestep"] = np.array(cases, dtype=np.float32)
+    print(tag, "cases:", cases)
+    save(tag + ".npz", out)
+    if not write_world:
+        return
+
+    # the world itself as neutral arrays (+ string attributes), for Runner-level plumbing tests
+    w = {}
+    flat_world(world, w, prefix="")
+    w["agent/id"] = np.asarray(data["agent"].id)
+    w["agent/ethnicity"] = np.asarray(data["agent"].ethnicity)
+    w["agent/area"] = np.asarray(data["agent"].area)
+    for s in EDGE_SETS:
+        w[f"venue_id/{s}"] = np.asarray(data[s]["id"])
+    save("world769.npz", w)
+
+
+# ------------------------------------------------------------------------------------------
+# case: synth10k  (edge cases: deg-0/1 venues, people != degree, 5k venue, duplicates, no-edge agents)
+# ------------------------------------------------------------------------------------------
+def make_synth10k():
+    rng = np.random.default_rng(1234)
+    A = 10_000
+    params = default_params()
+    params["policies"]["quarantine"] = {
+        "quarantine": {1: {"start_date": "2022-01-01", "end_date": "2023-01-01", "stage_threshold": 4}}}
+    params["policies"]["interaction"]["social_distancing"][1]["start_date"] = "2022-01-01"
+    seed_all(4321)
+    data = HeteroData()
+    data["agent"].id = torch.arange(A)
+    data["agent"].age = torch.from_numpy(rng.integers(0, 100, A))
+    data["agent"].sex = torch.from_numpy(rng.integers(0, 2, A))
+
+    def add_set(name, agents, venues, n_venues, people=None):
+        agents = np.asarray(agents, dtype=np.int64)
+        venues = np.asarray(venues, dtype=np.int64)
+        perm = rng.permutation(len(agents))          # reference COO is unsorted
+        ei = torch.from_numpy(np.vstack((agents[perm], venues[perm])))
+        data["agent", "attends_" + name, name].edge_index = ei
+        data[name].id = torch.arange(n_venues)
+        if people is None:
+            people = np.bincount(venues, minlength=n_venues)
+        data[name].people = torch.from_numpy(np.asarray(people, dtype=np.int64))
+
+    # household: sizes 1..6, plus 50 empty households at the end; some `people` overridden
+    sizes = rng.integers(1, 7, 4000)
+    cut = np.searchsorted(np.cumsum(sizes), A)
+    sizes = sizes[: cut + 1]
+    hv = np.repeat(np.arange(len(sizes)), sizes)[:A]
+    nh = len(sizes) + 50
+    people = np.bincount(hv, minlength=nh)
+    people[:5] = [0, 1, 2, 3, 7]                      # people is an independent input
+    add_set("household", rng.permutation(A), hv, nh, people)
+    # company: lognormal sizes, 30% of agents unemployed
+    workers = rng.permutation(A)[: int(0.7 * A)]
+    csz = np.maximum(1, rng.lognormal(np.log(20), 1.0, 400).astype(int))
+    cv = np.repeat(np.arange(len(csz)), csz)
+    cv = cv[rng.permutation(len(cv))][: len(workers)]
+    add_set("company", workers[: len(cv)], cv, len(csz))
+    # school: ONE 5k-agent venue + 20 smaller ones + a duplicate edge + an empty school
+    pupils = rng.permutation(A)[:7000]
+    sv = np.concatenate([np.zeros(5000, dtype=np.int64), rng.integers(1, 21, 2000)])
+    add_set("school", np.concatenate([pupils, pupils[:3]]), np.concatenate([sv, sv[:3]]), 22)
+    # university: 3 venues, 600 agents ; care_home: 10 venues of ~30, a singleton
+    add_set("university", rng.permutation(A)[:600], rng.integers(0, 3, 600), 3)
+    ch_a = rng.permutation(A)[:301]
+    add_set("care_home", ch_a, np.concatenate([rng.integers(0, 10, 300), [10]]), 11)
+    # leisure: every agent attends k=3 distinct of 8 super-area nodes (multi-membership)
+    la = np.repeat(np.arange(A), 3)
+    lv = np.concatenate([rng.permutation(8)[:3] for _ in range(A)])
+    add_set("leisure", la, lv, 8)
+    data = T.ToUndirected()(data)
+
+    sampler = TransmissionSampler.from_parameters(params)
+    v = sampler(A)
+    data["agent"].infection_parameters = {
+        "max_infectiousness": v[0], "shape": v[1], "rate": v[2], "shift": v[3]}
+    inf = torch.from_numpy((rng.random(A) < 0.05).astype(np.float32))
+    data["agent"].transmission = torch.zeros(A)
+    data["agent"].is_infected = inf.clone()
+    data["agent"].susceptibility = 1.0 - inf
+    data["agent"].infection_time = torch.from_numpy((-10 * rng.random(A)).astype(np.float32)) * inf
+    data["agent"].symptoms = {
+        "current_stage": torch.from_numpy(np.where(inf.numpy() > 0, rng.integers(2, 7, A), 1)).long(),
+        "next_stage": torch.ones(A, dtype=torch.long),
+        "time_to_next_stage": torch.zeros(A)}
+
+    model = GradJune.from_parameters(params)
+    timer = Timer.from_parameters(params)
+    world = world_of(data)
+    out = {}
+    flat_world(world, out)
+    tabs = tables_of(model)
+    for n, t in tabs.items():
+        out["table/" + n] = t.numpy()
+    recs = []
+    for i in range(7):            # 2022-02-02 .. 02-08: five weekdays + a weekend
+        next(timer)
+        rec, pre = capture_step(model, data, timer, run_symptoms=True)
+        check_oracle(rec, pre, world, tabs)
+        recs.append(rec)
+    add_steps(out, recs)
+    save("synth10k.npz", out)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(1)
+    make_kat6()
+    make_c100()
+    make_june769()
+    make_june769("june769_hot", beta_shift=0.9, write_world=False)
+    make_synth10k()
+    print("all golden cases generated; oracle == reference on every recorded stage")
