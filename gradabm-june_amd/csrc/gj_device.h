@@ -1,0 +1,92 @@
+// Device-side helpers shared by the gfx950 kernels: wave64 reductions, Philox4x32-10, the
+// per-agent Gumbel-softmax decision (a8) and the infection state update (a9).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gj {
+
+constexpr int kWave = 64;          // CDNA wavefront
+constexpr int kThreads = 256;      // 4 waves per workgroup: one per SIMD of a CU
+constexpr int kEdgesPerThread = 8; // STREAM block = 2048 edges = GJ_STREAM_EDGES
+
+// Sum over the lanes of an aligned group of G lanes (G = 4, 16, 64); every lane gets the total
+// of ITS group.  Butterfly order: run-to-run deterministic.
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+  return v;
+}
+
+// ---- Philox4x32-10 (Salmon et al., SC'11), counter = (agent lo, agent hi, step lo, step hi),
+// key = seed.  One call yields the two Exponential(1) draws an agent needs.
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]);
+  const uint32_t lo0 = 0xD2511F53u * c[0];
+  const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]);
+  const uint32_t lo1 = 0xCD9E8D57u * c[2];
+  const uint32_t n0 = hi1 ^ c[1] ^ k0;
+  const uint32_t n2 = hi0 ^ c[3] ^ k1;
+  c[0] = n0;
+  c[1] = lo1;
+  c[2] = n2;
+  c[3] = lo0;
+}
+
+__device__ __forceinline__ void philox4x32_10(uint64_t ctr_lo, uint64_t ctr_hi, uint64_t key,
+                                              uint32_t (&out)[4]) {
+  uint32_t c[4] = {(uint32_t)ctr_lo, (uint32_t)(ctr_lo >> 32), (uint32_t)ctr_hi,
+                   (uint32_t)(ctr_hi >> 32)};
+  uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c[0];
+  out[1] = c[1];
+  out[2] = c[2];
+  out[3] = c[3];
+}
+
+// 24 random bits -> uniform in (0,1), every value exactly representable, never 0 or 1.
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * 5.9604644775390625e-8f; }
+
+__device__ __forceinline__ void exp_pair(uint64_t seed, uint64_t step, int64_t agent, float& e0, float& e1) {
+  uint32_t r[4];
+  philox4x32_10((uint64_t)agent, step, seed, r);
+  e0 = -logf(u01(r[0]));
+  e1 = -logf(u01(r[1]));
+}
+
+// a8: IsInfectedSampler.forward = F.gumbel_softmax(vstack(p, 1-p).log(), tau=0.1, hard=True, dim=0)
+// (reference grad_june/infection.py:13-18).  e0/e1 are the Exponential(1) draws of rows 0/1.
+// Returns the forward value 1 - (y_hard - y_soft + y_soft)[0], computed op for op.
+__device__ __forceinline__ float gumbel_new_infected(float p, float e0, float e1) {
+  const float l0 = logf(p);
+  const float l1 = logf(1.0f - p);
+  const float z0 = (l0 + (-logf(e0))) / 0.1f;
+  const float z1 = (l1 + (-logf(e1))) / 0.1f;
+  const float m = fmaxf(z0, z1);
+  const float x0 = expf(z0 - m);
+  const float x1 = expf(z1 - m);
+  const float s = x0 + x1;
+  const float y0 = x0 / s;
+  const float y1 = x1 / s;
+  const float h0 = (y1 > y0) ? 0.0f : 1.0f;  // argmax, ties -> row 0 (not infected)
+  const float ret0 = (h0 - y0) + y0;
+  return 1.0f - ret0;
+}
+
+// a9: GradJune.infect_people (reference grad_june/model.py:103-110)
+__device__ __forceinline__ void infect(float nw, float now, float& susc, float& inf, float& t_inf) {
+  susc = fmaxf(0.0f, susc - nw);
+  inf = inf + nw;
+  t_inf = t_inf + nw * (now - t_inf);
+}
+
+__device__ __forceinline__ float sgnf(float x) { return (float)((0.0f < x) - (x < 0.0f)); }
+
+}  // namespace gj

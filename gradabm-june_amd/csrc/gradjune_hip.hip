@@ -1,0 +1,721 @@
+// gfx950 (MI355X / CDNA4) kernels + C ABI for the per-timestep infection message-passing path
+// of GradABM-JUNE.  ABI: include/gradjune_hip.h.  Reference semantics: SURVEY.md section 8a.
+//
+// Per step (gj_step): three dependent launches on the caller's stream
+//   k_transmission    a1+a2   elementwise over agents           (HBM-bound, streaming)
+//   k_venue_reduce    a3-a5   segmented sum per venue (pass 1)   (HBM/MALL-bound, index stream + gather)
+//   [k_combine_long]          ordered combine of >2048-edge venues' partial sums
+//   k_agent_gather    a4,a6-a9 per-agent gather over its venues + epilogue + Gumbel decision
+//                              + state update (pass 2, fused)
+// The path is a sparse segmented reduction: no MFMA.  The rules that matter are coalesced index
+// streams, many independent gathers in flight, LDS staging of per-venue partial sums and wave64
+// shuffles for the segmented combine.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/gradjune_hip.h"
+#include "gj_device.h"
+
+namespace gj {
+
+// ------------------------------------------------------------------------------------------
+// kernel-argument blocks (passed by value; < 4 KiB)
+// ------------------------------------------------------------------------------------------
+struct SetP1 {
+  const int32_t* v_rowptr;
+  const int32_t* v_agent;
+  const float* v_pc;
+  float* cum;
+  int32_t stride;
+  int32_t nk;                              // networks active on this set in this step
+  float beta[GJ_MAX_NETS_PER_SET];
+  int32_t table[GJ_MAX_NETS_PER_SET];      // -1: no leisure table
+  int32_t raw;                             // 1: household (raw transmission), 0: q*transmission
+  int32_t leisure;                         // 1: any network of the set uses a table
+};
+
+struct P1Args {
+  SetP1 sets[GJ_MAX_SETS];
+  const gj_block* blocks;
+  const float* trans;
+  const float* qtrans;
+  const uint8_t* cls;
+  const float* tables;
+  float* partial;
+  int32_t day_type;
+};
+
+struct SetP2 {
+  const int32_t* a_rowptr;
+  const int32_t* a_venue;
+  const float* cum;
+  int32_t stride;
+  int32_t nk;
+  int32_t mask[GJ_MAX_NETS_PER_SET];
+  int32_t table[GJ_MAX_NETS_PER_SET];
+};
+
+struct P2Args {
+  SetP2 groups[GJ_MAX_SETS];   // active edge sets in accumulation order
+  int32_t n_groups;
+  int32_t any_leisure;
+  int64_t n_agents;
+  const uint8_t* cls;
+  const float* tables;
+  const float* stage;
+  float* susceptibility;
+  float* is_infected;
+  float* infection_time;
+  float* not_infected_probs;
+  float* new_infected;
+  float* trans_susc;
+  const float* exp_noise;
+  float now, dt, q_thr;
+  int32_t day_type, has_q, sample;
+  uint64_t seed, step;
+  int64_t agent_offset;
+};
+
+// ------------------------------------------------------------------------------------------
+// a1 + a2   transmission profile and quarantine-masked copy
+//   reference: grad_june/transmission.py:39-51, grad_june/policies/quarantine_policies.py:13-33
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float transmission_value(float mx, float shp, float rt, float sh, float t_inf,
+                                                    float inf, float now) {
+  const float t = now - t_inf;
+  const float d = t - sh;
+  const float sign = (sgnf(d + 1e-10f) + 1.0f) / 2.0f;
+  const float aux = expf(-lgammaf(shp)) * powf(d * rt, shp - 1.0f);
+  const float aux2 = expf((sh - t) * rt) * rt;
+  return mx * sign * aux * aux2 * inf;
+}
+
+__global__ __launch_bounds__(kThreads) void k_transmission(
+    int64_t n, const float* __restrict__ mx, const float* __restrict__ shp, const float* __restrict__ rt,
+    const float* __restrict__ sh, const float* __restrict__ t_inf, const float* __restrict__ inf,
+    const float* __restrict__ stage, float* __restrict__ trans, float* __restrict__ qtrans, float now,
+    int has_q, float q_thr) {
+  const int64_t n4 = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 a = reinterpret_cast<const float4*>(mx)[i];
+    const float4 b = reinterpret_cast<const float4*>(shp)[i];
+    const float4 c = reinterpret_cast<const float4*>(rt)[i];
+    const float4 d = reinterpret_cast<const float4*>(sh)[i];
+    const float4 e = reinterpret_cast<const float4*>(t_inf)[i];
+    const float4 f = reinterpret_cast<const float4*>(inf)[i];
+    float4 r;
+    r.x = transmission_value(a.x, b.x, c.x, d.x, e.x, f.x, now);
+    r.y = transmission_value(a.y, b.y, c.y, d.y, e.y, f.y, now);
+    r.z = transmission_value(a.z, b.z, c.z, d.z, e.z, f.z, now);
+    r.w = transmission_value(a.w, b.w, c.w, d.w, e.w, f.w, now);
+    reinterpret_cast<float4*>(trans)[i] = r;
+    if (has_q) {
+      const float4 s = reinterpret_cast<const float4*>(stage)[i];
+      float4 q;
+      q.x = (s.x < q_thr ? 1.0f : 0.0f) * r.x;
+      q.y = (s.y < q_thr ? 1.0f : 0.0f) * r.y;
+      q.z = (s.z < q_thr ? 1.0f : 0.0f) * r.z;
+      q.w = (s.w < q_thr ? 1.0f : 0.0f) * r.w;
+      reinterpret_cast<float4*>(qtrans)[i] = q;
+    }
+  }
+  // tail (n % 4 agents): first threads of block 0
+  if (blockIdx.x == 0) {
+    const int64_t i = (n4 << 2) + threadIdx.x;
+    if (threadIdx.x < (n & 3)) {
+      const float r = transmission_value(mx[i], shp[i], rt[i], sh[i], t_inf[i], inf[i], now);
+      trans[i] = r;
+      if (has_q) qtrans[i] = (stage[i] < q_thr ? 1.0f : 0.0f) * r;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// a3 + a4 + a5   pass 1: cum_n[v] = sum_{e in venue v} trans_n[agent(e)] * (beta_n * p_contact[v])
+//   reference: grad_june/infection_networks/base.py:61-79,86-87 (+ leisure_network.py:61-72)
+//
+// One workgroup per schedule entry (gj_block).
+//  STREAM: the block owns whole venues [v0,v1) with <= 2048 edges in total.  All 256 threads
+//          stream the block's contiguous edge range with coalesced index loads, 8 independent
+//          gathers in flight per thread, and stage the gathered values in LDS; then `lanes`
+//          lanes per venue sum each venue's LDS segment (lanes == 1: in edge order, i.e. the
+//          reference's scatter_add_ order) and combine with wave64 shuffles.
+//  LONG:   the block owns edges [e0,e1) of ONE venue; register accumulation, wave shuffles,
+//          cross-wave combine through LDS, partial sum to plan.partial[slot].
+// ------------------------------------------------------------------------------------------
+template <bool LEISURE>
+__device__ __forceinline__ float gather_x(const P1Args& A, const float* __restrict__ src, int32_t a,
+                                          const float* __restrict__ tab) {
+  float x = src[a];
+  if (LEISURE) x = tab[A.cls[a]] * x;   // (q*L)*t == L*(q*t) exactly for q in {0,1}
+  return x;
+}
+
+template <int G>
+__device__ __forceinline__ void stream_reduce(const SetP1& S, const gj_block& b, int k, const float* lds,
+                                              int tid) {
+  const int R = b.v1 - b.v0;
+  const int grp = tid / G, lane = tid % G;
+  constexpr int kGroups = kThreads / G;
+  const float beta = S.beta[k];
+  for (int r = grp; r < R; r += kGroups) {
+    const int v = b.v0 + r;
+    const int s = S.v_rowptr[v] - b.e0;
+    const int t = S.v_rowptr[v + 1] - b.e0;
+    const float y = beta * S.v_pc[v];
+    float sum = 0.0f;
+    for (int i = s + lane; i < t; i += G) sum += lds[i] * y;
+    if (G > 1) sum = group_sum<G>(sum);
+    if (lane == 0) S.cum[(int64_t)v * S.stride + k] = sum;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_venue_reduce(const P1Args A) {
+  __shared__ float lds[GJ_STREAM_EDGES];
+  __shared__ float wsum[kThreads / kWave][GJ_MAX_NETS_PER_SET];
+  const gj_block b = A.blocks[blockIdx.x];
+  const SetP1& S = A.sets[b.set];
+  const int nk = S.nk;
+  if (nk == 0) return;  // set not active in this step (block-uniform)
+  const int tid = threadIdx.x;
+  const float* __restrict__ src = S.raw ? A.trans : A.qtrans;
+
+  if (b.kind == 0) {
+    const int ne = b.e1 - b.e0;
+    for (int k = 0; k < nk; ++k) {
+      const float* tab = S.leisure ? A.tables + (int64_t)S.table[k] * GJ_TABLE_SIZE + A.day_type * 200 : nullptr;
+      // stage: coalesced index stream, kEdgesPerThread independent gathers per thread
+      int32_t ag[kEdgesPerThread];
+#pragma unroll
+      for (int j = 0; j < kEdgesPerThread; ++j) {
+        const int i = j * kThreads + tid;
+        ag[j] = (i < ne) ? S.v_agent[b.e0 + i] : -1;
+      }
+#pragma unroll
+      for (int j = 0; j < kEdgesPerThread; ++j) {
+        const int i = j * kThreads + tid;
+        if (ag[j] >= 0) lds[i] = S.leisure ? gather_x<true>(A, src, ag[j], tab) : gather_x<false>(A, src, ag[j], tab);
+      }
+      __syncthreads();
+      switch (b.lanes) {
+        case 1: stream_reduce<1>(S, b, k, lds, tid); break;
+        case 4: stream_reduce<4>(S, b, k, lds, tid); break;
+        case 16: stream_reduce<16>(S, b, k, lds, tid); break;
+        default: stream_reduce<64>(S, b, k, lds, tid); break;
+      }
+      if (k + 1 < nk) __syncthreads();
+    }
+    return;
+  }
+
+  // LONG: one venue, edges [e0,e1)
+  float acc[GJ_MAX_NETS_PER_SET];
+  float y[GJ_MAX_NETS_PER_SET];
+  const float pc = S.v_pc[b.v0];
+#pragma unroll
+  for (int k = 0; k < GJ_MAX_NETS_PER_SET; ++k) {
+    acc[k] = 0.0f;
+    y[k] = (k < nk) ? S.beta[k] * pc : 0.0f;
+  }
+  if (!S.leisure) {
+    float a0 = 0.0f;
+    int e = b.e0 + tid;
+    for (; e + 3 * kThreads < b.e1; e += 4 * kThreads) {
+      const int32_t i0 = S.v_agent[e], i1 = S.v_agent[e + kThreads], i2 = S.v_agent[e + 2 * kThreads],
+                    i3 = S.v_agent[e + 3 * kThreads];
+      const float x0 = src[i0], x1 = src[i1], x2 = src[i2], x3 = src[i3];
+      a0 += x0 * y[0];
+      a0 += x1 * y[0];
+      a0 += x2 * y[0];
+      a0 += x3 * y[0];
+    }
+    for (; e < b.e1; e += kThreads) a0 += src[S.v_agent[e]] * y[0];
+    acc[0] = a0;
+  } else {
+    const float* tabs = A.tables + A.day_type * 200;
+    for (int e = b.e0 + tid; e < b.e1; e += kThreads) {
+      const int32_t a = S.v_agent[e];
+      const float x = src[a];
+      const int c = A.cls[a];
+#pragma unroll
+      for (int k = 0; k < GJ_MAX_NETS_PER_SET; ++k)
+        if (k < nk) acc[k] += (tabs[(int64_t)S.table[k] * GJ_TABLE_SIZE + c] * x) * y[k];
+    }
+  }
+  const int wave = tid / kWave, lane = tid % kWave;
+#pragma unroll
+  for (int k = 0; k < GJ_MAX_NETS_PER_SET; ++k) {
+    if (k < nk) {
+      const float w = group_sum<kWave>(acc[k]);
+      if (lane == 0) wsum[wave][k] = w;
+    }
+  }
+  __syncthreads();
+  if (tid < nk) {
+    float s = 0.0f;
+#pragma unroll
+    for (int w = 0; w < kThreads / kWave; ++w) s += wsum[w][tid];
+    A.partial[(int64_t)b.slot * GJ_MAX_NETS_PER_SET + tid] = s;
+  }
+}
+
+// ordered combine of the partial sums of one long venue (deterministic: chunk order)
+struct CombineArgs {
+  struct { float* cum; int32_t stride; int32_t nk; } sets[GJ_MAX_SETS];
+  const gj_long_row* rows;
+  const float* partial;
+  int32_t n_rows;
+};
+
+__global__ __launch_bounds__(kThreads) void k_combine_long(const CombineArgs C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int row = i / GJ_MAX_NETS_PER_SET, k = i % GJ_MAX_NETS_PER_SET;
+  if (row >= C.n_rows) return;
+  const gj_long_row r = C.rows[row];
+  const auto& S = C.sets[r.set];
+  if (k >= S.nk) return;
+  float s = 0.0f;
+  for (int slot = r.slot0; slot < r.slot1; ++slot) s += C.partial[(int64_t)slot * GJ_MAX_NETS_PER_SET + k];
+  S.cum[(int64_t)r.v * S.stride + k] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// a4 + a6 + a7 (+ a8 + a9)   pass 2, one thread per agent:
+//   ts[a] = sum_n  sum_{e in row a of set(n)} cum_n[venue(e)] * susc_n[a]      (network order = params order)
+//   p = clamp(exp(-clamp(ts,1e-6,100) * dt), 0, 1);  Gumbel decision;  state update
+//   reference: base.py:80-83,118-141; leisure_network.py:74-85,107-120; infection.py:13-18; model.py:103-110
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_agent_gather(const P2Args P) {
+  const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= P.n_agents) return;
+  float susc = P.susceptibility[a];
+  float q = 1.0f;
+  if (P.has_q) q = (P.stage[a] < P.q_thr) ? 1.0f : 0.0f;
+  int c = 0;
+  if (P.any_leisure) c = P.cls[a];
+  const float* tabs = P.tables + P.day_type * 200;
+
+  float ts = 0.0f;
+  for (int g = 0; g < P.n_groups; ++g) {
+    const SetP2& S = P.groups[g];
+    const int r0 = S.a_rowptr[a], r1 = S.a_rowptr[a + 1];
+    if (S.nk == 1 && S.mask[0] <= GJ_MASK_Q) {
+      const float w = (S.mask[0] == GJ_MASK_RAW) ? susc : q * susc;
+      float acc = 0.0f;
+      for (int e = r0; e < r1; ++e) acc += S.cum[(int64_t)S.a_venue[e] * S.stride] * w;
+      ts += acc;
+    } else {
+      float w[GJ_MAX_NETS_PER_SET], acc[GJ_MAX_NETS_PER_SET];
+#pragma unroll
+      for (int k = 0; k < GJ_MAX_NETS_PER_SET; ++k) {
+        acc[k] = 0.0f;
+        w[k] = 0.0f;
+        if (k < S.nk) {
+          const int m = S.mask[k];
+          float wk = (m == GJ_MASK_RAW) ? susc : q;
+          if (m >= GJ_MASK_QL) wk = wk * tabs[(int64_t)S.table[k] * GJ_TABLE_SIZE + c];
+          if (m != GJ_MASK_RAW) wk = wk * susc;
+          if (m == GJ_MASK_QL_AGE75) wk = wk * (((c % 100) > 75) ? 1.0f : 0.0f);
+          w[k] = wk;
+        }
+      }
+      for (int e = r0; e < r1; ++e) {
+        const float* cv = S.cum + (int64_t)S.a_venue[e] * S.stride;
+#pragma unroll
+        for (int k = 0; k < GJ_MAX_NETS_PER_SET; ++k)
+          if (k < S.nk) acc[k] += cv[k] * w[k];
+      }
+#pragma unroll
+      for (int k = 0; k < GJ_MAX_NETS_PER_SET; ++k)
+        if (k < S.nk) ts += acc[k];
+    }
+  }
+  if (P.trans_susc) P.trans_susc[a] = ts;
+  ts = fminf(fmaxf(ts, 1e-6f), 100.0f);
+  float p = expf(-ts * P.dt);
+  p = fminf(fmaxf(p, 0.0f), 1.0f);
+  if (P.not_infected_probs) P.not_infected_probs[a] = p;
+  if (!P.sample) return;
+
+  float e0, e1;
+  if (P.exp_noise) {
+    e0 = P.exp_noise[a];
+    e1 = P.exp_noise[P.n_agents + a];
+  } else {
+    exp_pair(P.seed, P.step, P.agent_offset + a, e0, e1);
+  }
+  const float nw = gumbel_new_infected(p, e0, e1);
+  if (P.new_infected) P.new_infected[a] = nw;
+  if (nw != 0.0f) {   // unchanged values are not rewritten
+    float inf = P.is_infected[a], t_inf = P.infection_time[a];
+    infect(nw, P.now, susc, inf, t_inf);
+    P.susceptibility[a] = susc;
+    P.is_infected[a] = inf;
+    P.infection_time[a] = t_inf;
+  }
+}
+
+// a8 + a9 on a caller-supplied probability vector
+__global__ __launch_bounds__(kThreads) void k_sample_infect(int64_t n, const float* __restrict__ p_not,
+                                                            const float* __restrict__ noise, uint64_t seed,
+                                                            uint64_t step, int64_t agent_offset, float now,
+                                                            float* __restrict__ new_inf, float* __restrict__ susc,
+                                                            float* __restrict__ inf, float* __restrict__ t_inf) {
+  const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= n) return;
+  float e0, e1;
+  if (noise) {
+    e0 = noise[a];
+    e1 = noise[n + a];
+  } else {
+    exp_pair(seed, step, agent_offset + a, e0, e1);
+  }
+  const float nw = gumbel_new_infected(p_not[a], e0, e1);
+  if (new_inf) new_inf[a] = nw;
+  if (nw != 0.0f) {
+    float s = susc[a], i = inf[a], t = t_inf[a];
+    infect(nw, now, s, i, t);
+    susc[a] = s;
+    inf[a] = i;
+    t_inf[a] = t;
+  }
+}
+
+// halo pack / unpack
+__global__ __launch_bounds__(kThreads) void k_pack(int64_t n, const int32_t* __restrict__ idx,
+                                                   const float* __restrict__ src, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = src[idx[i]];
+}
+__global__ __launch_bounds__(kThreads) void k_unpack(int64_t n, const int32_t* __restrict__ idx,
+                                                     const float* __restrict__ in, float* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[idx[i]] = in[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// host side: argument checking and launch
+// ------------------------------------------------------------------------------------------
+static inline int launch_status() {
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? GJ_OK : (int)e;
+}
+
+static int check_plan(const gj_plan* plan) {
+  if (!plan) return GJ_E_NULL;
+  if (plan->n_agents < 0 || plan->n_ext_agents < plan->n_agents) return GJ_E_RANGE;
+  if (plan->n_ext_agents > INT32_MAX) return GJ_E_RANGE;
+  if (plan->n_sets < 0 || plan->n_sets > GJ_MAX_SETS) return GJ_E_RANGE;
+  for (int s = 0; s < plan->n_sets; ++s) {
+    const gj_edge_set& S = plan->sets[s];
+    if (S.n_edges < 0 || S.n_edges > INT32_MAX || S.n_venues < 0 || S.n_venues > INT32_MAX) return GJ_E_RANGE;
+    if (S.cum_stride < 1 || S.cum_stride > GJ_MAX_NETS_PER_SET) return GJ_E_PLAN;
+    if (!S.v_rowptr || !S.a_rowptr || !S.v_pcontact) return GJ_E_NULL;
+    if (S.n_edges > 0 && (!S.v_agent || !S.a_venue)) return GJ_E_NULL;
+    if (S.n_venues > 0 && !S.cum) return GJ_E_NULL;
+  }
+  if (plan->n_blocks < 0 || (plan->n_blocks > 0 && !plan->blocks)) return GJ_E_PLAN;
+  if (plan->n_long_rows < 0 || (plan->n_long_rows > 0 && (!plan->long_rows || !plan->partial))) return GJ_E_PLAN;
+  return GJ_OK;
+}
+
+// group the step's networks by edge set, keeping order; networks of one set must be adjacent
+struct Groups {
+  int n;
+  int set[GJ_MAX_SETS];
+  int first[GJ_MAX_SETS];
+  int nk[GJ_MAX_SETS];
+};
+
+static int group_networks(const gj_plan* plan, const gj_step_params* p, Groups* G) {
+  if (!p) return GJ_E_NULL;
+  if (p->n_nets < 0 || p->n_nets > GJ_MAX_NETS) return GJ_E_RANGE;
+  if (p->day_type < 0 || p->day_type > 1) return GJ_E_RANGE;
+  G->n = 0;
+  bool seen[GJ_MAX_SETS] = {false};
+  for (int i = 0; i < p->n_nets; ++i) {
+    const gj_network& N = p->nets[i];
+    if (N.set < 0 || N.set >= plan->n_sets) return GJ_E_RANGE;
+    if (N.mask_kind < GJ_MASK_RAW || N.mask_kind > GJ_MASK_QL_AGE75) return GJ_E_RANGE;
+    if (N.mask_kind >= GJ_MASK_QL) {
+      if (N.table < 0 || N.table >= plan->n_tables || !plan->tables || !plan->agent_class) return GJ_E_PLAN;
+    }
+    if (G->n > 0 && G->set[G->n - 1] == N.set) {
+      if (G->nk[G->n - 1] >= plan->sets[N.set].cum_stride) return GJ_E_PLAN;
+      // transmissions of one set come from one source array: RAW and masked kinds cannot mix
+      const int m0 = p->nets[G->first[G->n - 1]].mask_kind;
+      if ((m0 == GJ_MASK_RAW) != (N.mask_kind == GJ_MASK_RAW)) return GJ_E_PLAN;
+      G->nk[G->n - 1]++;
+    } else {
+      if (seen[N.set]) return GJ_E_PLAN;  // not adjacent
+      seen[N.set] = true;
+      G->set[G->n] = N.set;
+      G->first[G->n] = i;
+      G->nk[G->n] = 1;
+      G->n++;
+    }
+  }
+  return GJ_OK;
+}
+
+static int check_state(const gj_plan* plan, const gj_agent_state* st, const gj_step_params* p) {
+  if (!st) return GJ_E_NULL;
+  if (plan->n_agents == 0) return GJ_OK;
+  if (!st->transmission || !st->susceptibility || !st->is_infected || !st->infection_time) return GJ_E_NULL;
+  if (p->has_quarantine && (!st->current_stage || !st->q_transmission)) return GJ_E_NULL;
+  return GJ_OK;
+}
+
+static int do_transmission(const gj_plan* plan, const gj_agent_state* st, const gj_step_params* p,
+                           hipStream_t stream) {
+  if (!st->max_infectiousness || !st->shape || !st->rate || !st->shift) return GJ_E_NULL;
+  const int64_t n = plan->n_agents;
+  if (n == 0) return GJ_OK;
+  const int64_t n4 = (n + 3) / 4;
+  int64_t blocks = (n4 + kThreads - 1) / kThreads;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_transmission, dim3((unsigned)blocks), dim3(kThreads), 0, stream, n, st->max_infectiousness,
+                     st->shape, st->rate, st->shift, st->infection_time, st->is_infected, st->current_stage,
+                     st->transmission, st->q_transmission, p->now, p->has_quarantine, p->q_threshold);
+  return launch_status();
+}
+
+static int do_venue_reduce(const gj_plan* plan, const gj_agent_state* st, const gj_step_params* p, const Groups& G,
+                           hipStream_t stream) {
+  if (plan->n_blocks == 0 || G.n == 0) return GJ_OK;
+  P1Args A;
+  for (int s = 0; s < GJ_MAX_SETS; ++s) {
+    A.sets[s] = SetP1{};
+    A.sets[s].nk = 0;
+  }
+  for (int g = 0; g < G.n; ++g) {
+    const gj_edge_set& E = plan->sets[G.set[g]];
+    SetP1& S = A.sets[G.set[g]];
+    S.v_rowptr = E.v_rowptr;
+    S.v_agent = E.v_agent;
+    S.v_pc = E.v_pcontact;
+    S.cum = E.cum;
+    S.stride = E.cum_stride;
+    S.nk = G.nk[g];
+    S.raw = p->nets[G.first[g]].mask_kind == GJ_MASK_RAW;
+    S.leisure = 0;
+    for (int k = 0; k < G.nk[g]; ++k) {
+      const gj_network& N = p->nets[G.first[g] + k];
+      S.beta[k] = N.beta;
+      S.table[k] = N.mask_kind >= GJ_MASK_QL ? N.table : -1;
+      if (N.mask_kind >= GJ_MASK_QL) S.leisure = 1;
+    }
+    if (S.leisure) {
+      // a set either is a leisure set (every network has a table) or is not
+      for (int k = 0; k < G.nk[g]; ++k)
+        if (S.table[k] < 0) return GJ_E_PLAN;
+    }
+  }
+  A.blocks = plan->blocks;
+  A.trans = st->transmission;
+  A.qtrans = p->has_quarantine ? st->q_transmission : st->transmission;
+  A.cls = plan->agent_class;
+  A.tables = plan->tables;
+  A.partial = plan->partial;
+  A.day_type = p->day_type;
+  hipLaunchKernelGGL(k_venue_reduce, dim3((unsigned)plan->n_blocks), dim3(kThreads), 0, stream, A);
+  int rc = launch_status();
+  if (rc != GJ_OK) return rc;
+  if (plan->n_long_rows > 0) {
+    CombineArgs C;
+    for (int s = 0; s < GJ_MAX_SETS; ++s) {
+      C.sets[s].cum = A.sets[s].cum;
+      C.sets[s].stride = A.sets[s].stride;
+      C.sets[s].nk = A.sets[s].nk;
+    }
+    C.rows = plan->long_rows;
+    C.partial = plan->partial;
+    C.n_rows = plan->n_long_rows;
+    const int64_t threads = (int64_t)plan->n_long_rows * GJ_MAX_NETS_PER_SET;
+    hipLaunchKernelGGL(k_combine_long, dim3((unsigned)((threads + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                       stream, C);
+    rc = launch_status();
+  }
+  return rc;
+}
+
+static int do_agent_gather(const gj_plan* plan, const gj_agent_state* st, const gj_step_params* p, const Groups& G,
+                           const gj_step_io* io, int sample, hipStream_t stream) {
+  const int64_t n = plan->n_agents;
+  if (n == 0) return GJ_OK;
+  P2Args P;
+  P.n_groups = G.n;
+  P.any_leisure = 0;
+  for (int g = 0; g < G.n; ++g) {
+    const gj_edge_set& E = plan->sets[G.set[g]];
+    SetP2& S = P.groups[g];
+    S.a_rowptr = E.a_rowptr;
+    S.a_venue = E.a_venue;
+    S.cum = E.cum;
+    S.stride = E.cum_stride;
+    S.nk = G.nk[g];
+    for (int k = 0; k < GJ_MAX_NETS_PER_SET; ++k) {
+      S.mask[k] = 0;
+      S.table[k] = 0;
+    }
+    for (int k = 0; k < G.nk[g]; ++k) {
+      const gj_network& N = p->nets[G.first[g] + k];
+      S.mask[k] = N.mask_kind;
+      S.table[k] = N.mask_kind >= GJ_MASK_QL ? N.table : 0;
+      if (N.mask_kind >= GJ_MASK_QL) P.any_leisure = 1;
+    }
+  }
+  P.n_agents = n;
+  P.cls = plan->agent_class;
+  P.tables = plan->tables;
+  P.stage = st->current_stage;
+  P.susceptibility = st->susceptibility;
+  P.is_infected = st->is_infected;
+  P.infection_time = st->infection_time;
+  P.not_infected_probs = io ? io->not_infected_probs : nullptr;
+  P.new_infected = io ? io->new_infected : nullptr;
+  P.trans_susc = io ? io->trans_susc : nullptr;
+  P.exp_noise = io ? io->exp_noise : nullptr;
+  P.now = p->now;
+  P.dt = p->delta_time;
+  P.q_thr = p->q_threshold;
+  P.day_type = p->day_type;
+  P.has_q = p->has_quarantine;
+  P.sample = sample;
+  P.seed = p->seed;
+  P.step = p->step;
+  P.agent_offset = p->agent_offset;
+  const int64_t blocks = (n + kThreads - 1) / kThreads;
+  hipLaunchKernelGGL(k_agent_gather, dim3((unsigned)blocks), dim3(kThreads), 0, stream, P);
+  return launch_status();
+}
+
+}  // namespace gj
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+int gj_version(void) { return GJ_ABI_VERSION; }
+
+const char* gj_error_string(int code) {
+  switch (code) {
+    case GJ_OK: return "ok";
+    case GJ_E_NULL: return "required pointer is NULL";
+    case GJ_E_RANGE: return "count or index out of range";
+    case GJ_E_PLAN: return "inconsistent plan or network list";
+    case GJ_E_NODEVICE: return "no HIP device";
+    default: break;
+  }
+  if (code > 0) return hipGetErrorString((hipError_t)code);
+  return "unknown error";
+}
+
+int gj_transmission_update(const gj_plan* plan, const gj_agent_state* state, const gj_step_params* params,
+                           void* stream) {
+  int rc = gj::check_plan(plan);
+  if (rc) return rc;
+  if (!params) return GJ_E_NULL;
+  rc = gj::check_state(plan, state, params);
+  if (rc) return rc;
+  return gj::do_transmission(plan, state, params, (hipStream_t)stream);
+}
+
+int gj_venue_reduce(const gj_plan* plan, const gj_agent_state* state, const gj_step_params* params, void* stream) {
+  int rc = gj::check_plan(plan);
+  if (rc) return rc;
+  gj::Groups G;
+  rc = gj::group_networks(plan, params, &G);
+  if (rc) return rc;
+  rc = gj::check_state(plan, state, params);
+  if (rc) return rc;
+  return gj::do_venue_reduce(plan, state, params, G, (hipStream_t)stream);
+}
+
+int gj_agent_gather(const gj_plan* plan, const gj_agent_state* state, const gj_step_params* params,
+                    const gj_step_io* io, int sample, void* stream) {
+  int rc = gj::check_plan(plan);
+  if (rc) return rc;
+  gj::Groups G;
+  rc = gj::group_networks(plan, params, &G);
+  if (rc) return rc;
+  rc = gj::check_state(plan, state, params);
+  if (rc) return rc;
+  return gj::do_agent_gather(plan, state, params, G, io, sample, (hipStream_t)stream);
+}
+
+int gj_sample_infect(int64_t n_agents, const float* not_infected_probs, const float* exp_noise, uint64_t seed,
+                     uint64_t step, int64_t agent_offset, float now, float* new_infected, float* susceptibility,
+                     float* is_infected, float* infection_time, void* stream) {
+  if (n_agents < 0) return GJ_E_RANGE;
+  if (n_agents == 0) return GJ_OK;
+  if (!not_infected_probs || !susceptibility || !is_infected || !infection_time) return GJ_E_NULL;
+  const int64_t blocks = (n_agents + gj::kThreads - 1) / gj::kThreads;
+  hipLaunchKernelGGL(gj::k_sample_infect, dim3((unsigned)blocks), dim3(gj::kThreads), 0, (hipStream_t)stream, n_agents,
+                     not_infected_probs, exp_noise, seed, step, agent_offset, now, new_infected, susceptibility,
+                     is_infected, infection_time);
+  return gj::launch_status();
+}
+
+int gj_step(const gj_plan* plan, const gj_agent_state* state, const gj_step_params* params, const gj_step_io* io,
+            void* stream) {
+  int rc = gj::check_plan(plan);
+  if (rc) return rc;
+  gj::Groups G;
+  rc = gj::group_networks(plan, params, &G);
+  if (rc) return rc;
+  rc = gj::check_state(plan, state, params);
+  if (rc) return rc;
+  rc = gj::do_transmission(plan, state, params, (hipStream_t)stream);
+  if (rc) return rc;
+  rc = gj::do_venue_reduce(plan, state, params, G, (hipStream_t)stream);
+  if (rc) return rc;
+  return gj::do_agent_gather(plan, state, params, G, io, 1, (hipStream_t)stream);
+}
+
+int gj_pack_f32(int64_t n, const int32_t* index, const float* src, float* out, void* stream) {
+  if (n < 0) return GJ_E_RANGE;
+  if (n == 0) return GJ_OK;
+  if (!index || !src || !out) return GJ_E_NULL;
+  hipLaunchKernelGGL(gj::k_pack, dim3((unsigned)((n + gj::kThreads - 1) / gj::kThreads)), dim3(gj::kThreads), 0,
+                     (hipStream_t)stream, n, index, src, out);
+  return gj::launch_status();
+}
+
+int gj_unpack_f32(int64_t n, const int32_t* index, const float* in, float* dst, void* stream) {
+  if (n < 0) return GJ_E_RANGE;
+  if (n == 0) return GJ_OK;
+  if (!index || !in || !dst) return GJ_E_NULL;
+  hipLaunchKernelGGL(gj::k_unpack, dim3((unsigned)((n + gj::kThreads - 1) / gj::kThreads)), dim3(gj::kThreads), 0,
+                     (hipStream_t)stream, n, index, in, dst);
+  return gj::launch_status();
+}
+
+int gj_event_create(void** event) {
+  if (!event) return GJ_E_NULL;
+  hipEvent_t e;
+  const hipError_t rc = hipEventCreate(&e);
+  if (rc != hipSuccess) return (int)rc;
+  *event = (void*)e;
+  return GJ_OK;
+}
+int gj_event_record(void* event, void* stream) {
+  if (!event) return GJ_E_NULL;
+  return (int)hipEventRecord((hipEvent_t)event, (hipStream_t)stream);
+}
+int gj_event_elapsed_ms(void* start, void* stop, float* ms) {
+  if (!start || !stop || !ms) return GJ_E_NULL;
+  hipError_t rc = hipEventSynchronize((hipEvent_t)stop);
+  if (rc != hipSuccess) return (int)rc;
+  return (int)hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
+}
+int gj_event_destroy(void* event) {
+  if (!event) return GJ_E_NULL;
+  return (int)hipEventDestroy((hipEvent_t)event);
+}
+
+}  // extern "C"

@@ -1,0 +1,177 @@
+"""ctypes binding of libgradjune_hip.so (C ABI: include/gradjune_hip.h).
+
+There is NO fallback: if the library has not been built (``python __graft_entry__.py`` or
+``make -C gradabm-june_amd/csrc``) every compute entry point raises.  PyTorch is used only to
+own device memory and to name the HIP stream the kernels are launched on.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+GJ_ABI_VERSION = 1
+GJ_MAX_SETS = 12
+GJ_MAX_NETS = 16
+GJ_MAX_NETS_PER_SET = 8
+GJ_TABLE_SIZE = 400
+GJ_STREAM_EDGES = 2048
+
+MASK_RAW, MASK_Q, MASK_QL, MASK_QL_AGE75 = 0, 1, 2, 3
+
+_LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
+LIB_PATH = os.path.join(_LIB_DIR, "libgradjune_hip.so")
+
+_vp = C.c_void_p
+
+
+class EdgeSet(C.Structure):
+    _fields_ = [
+        ("n_venues", C.c_int64),
+        ("n_edges", C.c_int64),
+        ("v_rowptr", _vp),
+        ("v_agent", _vp),
+        ("v_pcontact", _vp),
+        ("a_rowptr", _vp),
+        ("a_venue", _vp),
+        ("cum", _vp),
+        ("cum_stride", C.c_int32),
+        ("_pad", C.c_int32),
+    ]
+
+
+class Plan(C.Structure):
+    _fields_ = [
+        ("n_agents", C.c_int64),
+        ("n_ext_agents", C.c_int64),
+        ("n_sets", C.c_int32),
+        ("n_blocks", C.c_int32),
+        ("n_long_rows", C.c_int32),
+        ("n_partial_slots", C.c_int32),
+        ("sets", EdgeSet * GJ_MAX_SETS),
+        ("blocks", _vp),
+        ("long_rows", _vp),
+        ("partial", _vp),
+        ("agent_class", _vp),
+        ("tables", _vp),
+        ("n_tables", C.c_int32),
+        ("_pad", C.c_int32),
+    ]
+
+
+class Network(C.Structure):
+    _fields_ = [
+        ("beta", C.c_float),
+        ("set", C.c_int32),
+        ("mask_kind", C.c_int32),
+        ("table", C.c_int32),
+    ]
+
+
+class StepParams(C.Structure):
+    _fields_ = [
+        ("now", C.c_float),
+        ("delta_time", C.c_float),
+        ("day_type", C.c_int32),
+        ("has_quarantine", C.c_int32),
+        ("q_threshold", C.c_float),
+        ("n_nets", C.c_int32),
+        ("seed", C.c_uint64),
+        ("step", C.c_uint64),
+        ("agent_offset", C.c_int64),
+        ("nets", Network * GJ_MAX_NETS),
+    ]
+
+
+class AgentState(C.Structure):
+    _fields_ = [
+        ("max_infectiousness", _vp),
+        ("shape", _vp),
+        ("rate", _vp),
+        ("shift", _vp),
+        ("infection_time", _vp),
+        ("is_infected", _vp),
+        ("susceptibility", _vp),
+        ("transmission", _vp),
+        ("q_transmission", _vp),
+        ("current_stage", _vp),
+    ]
+
+
+class StepIO(C.Structure):
+    _fields_ = [
+        ("not_infected_probs", _vp),
+        ("new_infected", _vp),
+        ("exp_noise", _vp),
+        ("trans_susc", _vp),
+    ]
+
+
+#: every symbol include/gradjune_hip.h declares: (restype, argtypes)
+SYMBOLS = {
+    "gj_version": (C.c_int, []),
+    "gj_error_string": (C.c_char_p, [C.c_int]),
+    "gj_transmission_update": (C.c_int, [C.POINTER(Plan), C.POINTER(AgentState), C.POINTER(StepParams), _vp]),
+    "gj_venue_reduce": (C.c_int, [C.POINTER(Plan), C.POINTER(AgentState), C.POINTER(StepParams), _vp]),
+    "gj_agent_gather": (
+        C.c_int,
+        [C.POINTER(Plan), C.POINTER(AgentState), C.POINTER(StepParams), C.POINTER(StepIO), C.c_int, _vp],
+    ),
+    "gj_sample_infect": (
+        C.c_int,
+        [C.c_int64, _vp, _vp, C.c_uint64, C.c_uint64, C.c_int64, C.c_float, _vp, _vp, _vp, _vp, _vp],
+    ),
+    "gj_step": (C.c_int, [C.POINTER(Plan), C.POINTER(AgentState), C.POINTER(StepParams), C.POINTER(StepIO), _vp]),
+    "gj_pack_f32": (C.c_int, [C.c_int64, _vp, _vp, _vp, _vp]),
+    "gj_unpack_f32": (C.c_int, [C.c_int64, _vp, _vp, _vp, _vp]),
+    "gj_event_create": (C.c_int, [C.POINTER(_vp)]),
+    "gj_event_record": (C.c_int, [_vp, _vp]),
+    "gj_event_elapsed_ms": (C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),
+    "gj_event_destroy": (C.c_int, [_vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the HIP library, binding every declared symbol.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryMissing(
+            f"{LIB_PATH} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
+            "grad_june_amd has no CPU or eager-PyTorch fallback for the infection path."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.gj_version() != GJ_ABI_VERSION:
+        raise RuntimeError(f"libgradjune_hip ABI {lib.gj_version()} != binding {GJ_ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = load().gj_error_string(code)
+        raise RuntimeError(f"{what} failed: [{code}] {msg.decode() if msg else '?'}")
+
+
+def ptr(t) -> Optional[int]:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def current_stream() -> Optional[int]:
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,279 @@
+"""One-time graph compile: the reference's unsorted int64 COO edge lists -> an immutable plan.
+
+Input is the data surface the reference's ``june_world_loader`` emits:
+per venue type ``data["attends_<set>"].edge_index`` (int64 ``[2, E]``, row 0 = agent, row 1 =
+venue, unsorted; /root/reference/grad_june/june_world_loader/network_loader.py:30-44) and
+``data[<set>].people``.  Output, per edge set, is what the gfx950 kernels stream:
+
+* CSR by venue  (``v_rowptr``, ``v_agent``)  - pass 1 reads the edge list venue-major, coalesced;
+* CSR by agent  (``a_rowptr``, ``a_venue``)  - pass 2 reads it agent-major;
+* ``v_pcontact`` = clamp(1/(people-1), 0, 1) (reference base.py:63-69), static, computed once;
+* a workgroup schedule for pass 1 (``gj_block``): consecutive venues packed into blocks of at most
+  2048 edges ("STREAM": LDS-staged, 1/4/16/64 lanes per venue chosen from the block's mean degree)
+  and venues above 2048 edges cut into chunks of ``LONG_CHUNK`` edges ("LONG": multi-workgroup,
+  partial sums combined in chunk order by a second kernel - deterministic, no float atomics).
+
+Both CSR views keep the COO order inside a row (stable sort), so a sum taken in row order has the
+reference's ``scatter_add_`` order.  All indices are int32.
+
+Host part is numpy/torch-CPU only and is covered by the CPU test-suite; :class:`DevicePlan`
+uploads it and owns the per-step workspaces.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+LONG_CHUNK = 8192        # edges per workgroup for venues above the stream capacity
+MAX_ROWS_PER_BLOCK = 2048
+
+
+@dataclass
+class HostEdgeSet:
+    name: str
+    n_venues: int
+    n_edges: int
+    v_rowptr: np.ndarray   # int32 [V+1]
+    v_agent: np.ndarray    # int32 [E]
+    v_pcontact: np.ndarray  # float32 [V]
+    a_rowptr: np.ndarray   # int32 [A+1]
+    a_venue: np.ndarray    # int32 [E]
+
+
+def p_contact(people) -> np.ndarray:
+    """clamp(1/(people-1), 0, 1) in the reference's dtype flow (int64 or float people -> fp32)."""
+    people = torch.as_tensor(np.asarray(people)) if not isinstance(people, torch.Tensor) else people.cpu()
+    pc = torch.clamp(1.0 / (people - 1), max=1.0)
+    pc = torch.clamp(pc, min=0.0)
+    return pc.to(torch.float32).numpy()
+
+
+def _csr(rows: np.ndarray, cols: np.ndarray, n_rows: int):
+    """Stable CSR of (rows -> cols): rowptr int32 [n_rows+1], cols reordered row-major."""
+    order = np.argsort(rows, kind="stable")
+    counts = np.bincount(rows, minlength=n_rows)
+    rowptr = np.zeros(n_rows + 1, dtype=np.int64)
+    np.cumsum(counts, out=rowptr[1:])
+    return rowptr.astype(np.int32), cols[order].astype(np.int32)
+
+
+def compile_edge_set(name: str, agent_index, venue_index, people, n_agents: int,
+                     n_ext_agents: Optional[int] = None) -> HostEdgeSet:
+    """COO -> two CSR views.  ``agent_index`` may reference halo agents in [n_agents, n_ext)."""
+    agent_index = np.asarray(agent_index).astype(np.int64, copy=False).ravel()
+    venue_index = np.asarray(venue_index).astype(np.int64, copy=False).ravel()
+    n_ext = n_agents if n_ext_agents is None else n_ext_agents
+    n_venues = int(len(people))
+    E = int(agent_index.shape[0])
+    if E >= 2**31 or n_ext >= 2**31 or n_venues >= 2**31:
+        raise ValueError("edge set exceeds int32 indexing")
+    if E:
+        if agent_index.min() < 0 or agent_index.max() >= n_ext:
+            raise ValueError(f"{name}: agent index out of range")
+        if venue_index.min() < 0 or venue_index.max() >= n_venues:
+            raise ValueError(f"{name}: venue index out of range")
+    v_rowptr, v_agent = _csr(venue_index, agent_index, n_venues)
+    owned = agent_index < n_agents
+    a_rowptr, a_venue = _csr(agent_index[owned], venue_index[owned], n_agents)
+    return HostEdgeSet(name, n_venues, E, v_rowptr, v_agent, p_contact(people), a_rowptr, a_venue)
+
+
+def _lanes_for(mean_degree: float) -> int:
+    if mean_degree <= 6:
+        return 1
+    if mean_degree <= 24:
+        return 4
+    if mean_degree <= 96:
+        return 16
+    return 64
+
+
+def build_schedule(v_rowptr: np.ndarray, set_id: int, slot_base: int = 0,
+                   stream_edges: int = N.GJ_STREAM_EDGES, long_chunk: int = LONG_CHUNK):
+    """Pass-1 workgroup schedule of one edge set.
+
+    Returns (blocks int32 [nb, 8], long_rows int32 [nl, 4], n_slots).  Block columns follow
+    ``gj_block``: set, kind, v0, v1, e0, e1, slot, lanes.  Every venue is covered exactly once:
+    by one STREAM block or by the LONG chunks of its own row.
+    """
+    rp = v_rowptr.astype(np.int64)
+    V = len(rp) - 1
+    deg = np.diff(rp)
+    blocks: List[tuple] = []
+    long_rows: List[tuple] = []
+    slot = slot_base
+    long_idx = np.flatnonzero(deg > stream_edges)
+    bounds = np.concatenate(([-1], long_idx, [V]))
+    for i in range(len(bounds) - 1):
+        lo, hi = bounds[i] + 1, bounds[i + 1]      # stream segment [lo, hi)
+        v = lo
+        while v < hi:
+            # largest end with rp[end]-rp[v] <= stream_edges, end <= hi, rows <= MAX_ROWS
+            end = int(np.searchsorted(rp, rp[v] + stream_edges, side="right")) - 1
+            end = min(end, hi, v + MAX_ROWS_PER_BLOCK)
+            ne = int(rp[end] - rp[v])
+            blocks.append((set_id, 0, v, end, int(rp[v]), int(rp[end]), 0, _lanes_for(ne / (end - v))))
+            v = end
+        if hi < V:                                   # the long venue that ends this segment
+            e0, e1 = int(rp[hi]), int(rp[hi + 1])
+            s0 = slot
+            for c0 in range(e0, e1, long_chunk):
+                blocks.append((set_id, 1, hi, hi + 1, c0, min(c0 + long_chunk, e1), slot, 64))
+                slot += 1
+            long_rows.append((set_id, hi, s0, slot))
+    b = np.array(blocks, dtype=np.int32).reshape(-1, 8)
+    lr = np.array(long_rows, dtype=np.int32).reshape(-1, 4)
+    return b, lr, slot - slot_base
+
+
+@dataclass
+class NetworkSpec:
+    """One configured infection network (reference: an ``InfectionNetwork`` subclass instance)."""
+    name: str
+    edge_set: str
+    mask_kind: int
+    table: Optional[np.ndarray] = None   # [2,2,100] leisure probabilities, or None
+
+
+@dataclass
+class HostPlan:
+    n_agents: int
+    n_ext_agents: int
+    sets: List[HostEdgeSet]
+    agent_class: np.ndarray              # uint8 [n_ext]
+    blocks: np.ndarray                   # int32 [nb, 8]
+    long_rows: np.ndarray                # int32 [nl, 4]
+    n_partial_slots: int
+    set_index: Dict[str, int] = field(default_factory=dict)
+
+    @property
+    def n_edges(self) -> int:
+        return sum(s.n_edges for s in self.sets)
+
+
+def agent_class_of(age, sex) -> np.ndarray:
+    age = np.asarray(age).astype(np.int64)
+    sex = np.asarray(sex).astype(np.int64)
+    if age.size and (age.min() < 0 or age.max() > 99 or sex.min() < 0 or sex.max() > 1):
+        raise ValueError("age must be in 0..99 and sex in {0,1} (leisure tables are [2,2,100])")
+    return (sex * 100 + age).astype(np.uint8)
+
+
+def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
+                 n_ext_agents: Optional[int] = None, block_order: str = "interleave") -> HostPlan:
+    """edge_sets: {name: {"agent": i64[E], "venue": i64[E], "people": [V]}} (insertion order = set ids)."""
+    if len(edge_sets) > N.GJ_MAX_SETS:
+        raise ValueError(f"at most {N.GJ_MAX_SETS} edge sets")
+    n_ext = n_agents if n_ext_agents is None else n_ext_agents
+    sets, all_blocks, all_long = [], [], []
+    slot = 0
+    for sid, (name, es) in enumerate(edge_sets.items()):
+        hs = compile_edge_set(name, es["agent"], es["venue"], es["people"], n_agents, n_ext)
+        sets.append(hs)
+        b, lr, ns = build_schedule(hs.v_rowptr, sid, slot)
+        slot += ns
+        all_blocks.append(b)
+        all_long.append(lr)
+    blocks = np.concatenate(all_blocks) if all_blocks else np.zeros((0, 8), np.int32)
+    long_rows = np.concatenate(all_long) if all_long else np.zeros((0, 4), np.int32)
+    if block_order == "interleave" and len(blocks):
+        # LONG chunks first (heaviest workgroups start early), then stream blocks
+        order = np.argsort(-(blocks[:, 5] - blocks[:, 4]), kind="stable")
+        blocks = blocks[order]
+    if age is None:
+        cls = np.zeros(n_ext, dtype=np.uint8)
+    else:
+        cls = agent_class_of(age, sex)
+        if len(cls) != n_ext:
+            raise ValueError("age/sex must cover owned + halo agents")
+    return HostPlan(n_agents, n_ext, sets, cls, np.ascontiguousarray(blocks), long_rows, slot,
+                    {s.name: i for i, s in enumerate(sets)})
+
+
+class DevicePlan:
+    """The plan resident in HBM + the ctypes ``gj_plan`` that points at it."""
+
+    def __init__(self, host: HostPlan, networks: Sequence[NetworkSpec], device):
+        self.host = host
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("grad_june_amd runs the infection path on a HIP device only (no CPU path)")
+        self.networks = {n.name: n for n in networks}
+        dev = self.device
+
+        def up(a, dtype=None):
+            t = torch.from_numpy(np.ascontiguousarray(a))
+            if dtype is not None:
+                t = t.to(dtype)
+            return t.to(dev)
+
+        # leisure tables: one [2][200] row block per network that has one
+        self.table_index: Dict[str, int] = {}
+        tabs = []
+        for n in networks:
+            if n.table is not None:
+                self.table_index[n.name] = len(tabs)
+                tabs.append(np.asarray(n.table, dtype=np.float32).reshape(N.GJ_TABLE_SIZE))
+        self.tables = up(np.stack(tabs)) if tabs else None
+
+        per_set_nets: Dict[str, int] = {}
+        for n in networks:
+            if n.edge_set not in host.set_index:
+                raise KeyError(f"network {n.name}: edge set {n.edge_set!r} not in the world")
+            per_set_nets[n.edge_set] = per_set_nets.get(n.edge_set, 0) + 1
+        self.keep = []
+        self.cum: List[torch.Tensor] = []
+        plan = N.Plan()
+        plan.n_agents = host.n_agents
+        plan.n_ext_agents = host.n_ext_agents
+        plan.n_sets = len(host.sets)
+        for i, s in enumerate(host.sets):
+            stride = max(1, per_set_nets.get(s.name, 1))
+            if stride > N.GJ_MAX_NETS_PER_SET:
+                raise ValueError(f"edge set {s.name}: more than {N.GJ_MAX_NETS_PER_SET} networks")
+            t = dict(v_rowptr=up(s.v_rowptr), v_agent=up(s.v_agent), v_pc=up(s.v_pcontact),
+                     a_rowptr=up(s.a_rowptr), a_venue=up(s.a_venue))
+            cum = torch.zeros(max(1, s.n_venues) * stride, dtype=torch.float32, device=dev)
+            self.keep.append(t)
+            self.cum.append(cum)
+            e = plan.sets[i]
+            e.n_venues, e.n_edges = s.n_venues, s.n_edges
+            e.v_rowptr, e.v_agent, e.v_pcontact = t["v_rowptr"].data_ptr(), t["v_agent"].data_ptr(), t["v_pc"].data_ptr()
+            e.a_rowptr, e.a_venue = t["a_rowptr"].data_ptr(), t["a_venue"].data_ptr()
+            e.cum, e.cum_stride = cum.data_ptr(), stride
+        self.blocks = up(host.blocks.reshape(-1)) if len(host.blocks) else None
+        self.long_rows = up(host.long_rows.reshape(-1)) if len(host.long_rows) else None
+        self.partial = (torch.zeros(host.n_partial_slots * N.GJ_MAX_NETS_PER_SET, dtype=torch.float32, device=dev)
+                        if host.n_partial_slots else None)
+        self.agent_class = up(host.agent_class)
+        plan.n_blocks = len(host.blocks)
+        plan.n_long_rows = len(host.long_rows)
+        plan.n_partial_slots = host.n_partial_slots
+        plan.blocks = N.ptr(self.blocks)
+        plan.long_rows = N.ptr(self.long_rows)
+        plan.partial = N.ptr(self.partial)
+        plan.agent_class = N.ptr(self.agent_class)
+        plan.tables = N.ptr(self.tables)
+        plan.n_tables = len(tabs)
+        self.c = plan
+
+    def cum_of(self, set_name: str) -> torch.Tensor:
+        i = self.host.set_index[set_name]
+        stride = self.c.sets[i].cum_stride
+        return self.cum[i][: self.host.sets[i].n_venues * stride].view(self.host.sets[i].n_venues, stride)
+
+    def bytes_resident(self) -> int:
+        n = 0
+        for t in self.keep:
+            n += sum(x.numel() * x.element_size() for x in t.values())
+        n += sum(c.numel() * 4 for c in self.cum)
+        for x in (self.blocks, self.long_rows, self.partial, self.agent_class, self.tables):
+            if x is not None:
+                n += x.numel() * x.element_size()
+        return n

@@ -1,0 +1,225 @@
+/*
+ * gradjune_hip.h - C ABI of the MI355X (gfx950) infection message-passing library.
+ *
+ * This is the drop-in boundary for ONE path of GradABM-JUNE: the per-timestep infection
+ * step.  The reference has no native code and no FFI for this path:
+ * it runs as eager PyTorch + torch_geometric ops on the CPU.  Each entry point below
+ * therefore names the reference PYTHON interface it replaces (paths relative to the
+ * reference tree, file:line) - these are the call sites a maintainer re-binds with the
+ * ctypes stub shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes.  No torch types, no C++ types.
+ *   - Every pointer marked "device" is a HIP device pointer valid on the current device.
+ *     Every buffer (inputs, outputs, workspace) is allocated and owned by the caller; the
+ *     library never allocates, frees or retains device memory and keeps no global state,
+ *     so it is re-entrant and one host thread per process/GPU may call it freely.
+ *   - All launches are asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
+ *     legacy default stream).  No entry point synchronises, so calls may be captured into a
+ *     hipGraph.
+ *   - Return value: 0 = ok; negative = argument error (GJ_E_*); positive = hipError_t of a
+ *     failed launch.  Nothing throws across the ABI.  gj_error_string() describes a code.
+ *   - Index arrays are int32 (the reference's int64 COO is compiled once on the host into
+ *     int32 CSR, see gj_plan below); all values are IEEE fp32, computed with FMA contraction
+ *     off so that the op sequence matches the reference's ATen ops.
+ */
+#ifndef GRADJUNE_HIP_H
+#define GRADJUNE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GJ_ABI_VERSION 1
+
+#define GJ_MAX_SETS 12        /* distinct agent<->venue edge sets in a world (reference: 6)   */
+#define GJ_MAX_NETS 16        /* infection networks active in one step (reference: <= 11)      */
+#define GJ_MAX_NETS_PER_SET 8 /* networks sharing one edge set (reference: 6 leisure classes)  */
+#define GJ_TABLE_SIZE 400     /* one leisure table: [day_type 2][sex 2][age 100] floats        */
+
+/* error codes (negative) */
+#define GJ_OK 0
+#define GJ_E_NULL (-1)     /* required pointer is NULL                      */
+#define GJ_E_RANGE (-2)    /* count / index out of the documented range     */
+#define GJ_E_PLAN (-3)     /* inconsistent plan (sizes, strides, schedule)  */
+#define GJ_E_NODEVICE (-4) /* no HIP device / wrong architecture            */
+
+/* how a network derives its per-agent transmission / susceptibility from the raw values
+ * (reference: grad_june/infection_networks/base.py:47-59,144-149;
+ *             grad_june/infection_networks/leisure_network.py:61-85,107-120)           */
+typedef enum gj_mask_kind {
+  GJ_MASK_RAW = 0,      /* household: raw transmission / susceptibility, ignores quarantine */
+  GJ_MASK_Q = 1,        /* q[a] * value                                                      */
+  GJ_MASK_QL = 2,       /* q[a] * L[day, sex[a], age[a]] * value                             */
+  GJ_MASK_QL_AGE75 = 3  /* as QL; susceptibility additionally * (age[a] > 75) (care_visit)   */
+} gj_mask_kind;
+
+/* One agent<->venue edge set, compiled once from the reference's COO
+ * `data["attends_<set>"].edge_index` (int64 [2,E], row 0 agent, row 1 venue;
+ * grad_june/june_world_loader/network_loader.py:30-44) into two int32 CSR views.
+ * Edge order inside every CSR row is the COO order (stable sort), so sums taken in row
+ * order reproduce the reference's scatter_add_ order.                                      */
+typedef struct gj_edge_set {
+  int64_t n_venues;
+  int64_t n_edges;
+  const int32_t* v_rowptr;  /* device [n_venues+1]  CSR by venue                            */
+  const int32_t* v_agent;   /* device [n_edges]     agent of each edge, venue-major         */
+  const float* v_pcontact;  /* device [n_venues]    clamp(1/(people-1),0,1), base.py:63-69  */
+  const int32_t* a_rowptr;  /* device [n_agents+1]  CSR by agent                            */
+  const int32_t* a_venue;   /* device [n_edges]     venue of each edge, agent-major         */
+  float* cum;               /* device [n_venues*cum_stride] workspace: pass-1 out, pass-2 in */
+  int32_t cum_stride;       /* floats per venue in `cum` (>= networks active on this set)   */
+  int32_t _pad;
+} gj_edge_set;
+
+/* One workgroup's share of pass 1 (built on the host by the graph compiler).
+ * kind 0: STREAM - venues [v0,v1) whose edges [e0,e1) (<= GJ_STREAM_EDGES) are staged through
+ *         LDS and reduced with `lanes` (1,4,16 or 64) lanes per venue.
+ * kind 1: LONG   - edges [e0,e1) of the single venue v0; the partial sum goes to
+ *         partial[slot*cum_stride + k] and is combined in chunk order by a second kernel.  */
+typedef struct gj_block {
+  int32_t set;
+  int32_t kind;
+  int32_t v0, v1;
+  int32_t e0, e1;
+  int32_t slot;
+  int32_t lanes;
+} gj_block;
+
+/* venue whose degree exceeds the stream capacity: partial slots [slot0,slot1) -> cum[v] */
+typedef struct gj_long_row {
+  int32_t set;
+  int32_t v;
+  int32_t slot0, slot1;
+} gj_long_row;
+
+#define GJ_STREAM_EDGES 2048 /* max edges of a STREAM block (256 threads x 8)               */
+
+/* The compiled, immutable contact graph ("plan").  Host struct; arrays it points to are device
+ * memory owned by the caller.                                                              */
+typedef struct gj_plan {
+  int64_t n_agents;           /* agents OWNED by this rank (all per-agent outputs)           */
+  int64_t n_ext_agents;       /* owned + halo agents: length of transmission, q_transmission
+                                 and agent_class, the arrays pass 1 gathers from (== n_agents
+                                 on one GPU); v_agent indexes this extended range            */
+  int32_t n_sets;
+  int32_t n_blocks;           /* entries of `blocks`                                        */
+  int32_t n_long_rows;        /* entries of `long_rows`                                     */
+  int32_t n_partial_slots;    /* slots of `partial`                                         */
+  gj_edge_set sets[GJ_MAX_SETS];
+  const gj_block* blocks;     /* device [n_blocks]                                          */
+  const gj_long_row* long_rows; /* device [n_long_rows]                                     */
+  float* partial;             /* device [n_partial_slots * GJ_MAX_NETS_PER_SET] workspace   */
+  const uint8_t* agent_class; /* device [n_ext_agents]  sex*100 + age  (0..199)             */
+  const float* tables;        /* device [n_tables * GJ_TABLE_SIZE] leisure tables           */
+  int32_t n_tables;
+  int32_t _pad;
+} gj_plan;
+
+/* One infection network active in this step
+ * (reference: one InfectionNetwork module, base.py:11-87 / leisure_network.py:7-120).      */
+typedef struct gj_network {
+  float beta;          /* 10**log_beta * active SocialDistancing factors, fp32 (base.py:36-42) */
+  int32_t set;         /* index into gj_plan.sets                                             */
+  int32_t mask_kind;   /* gj_mask_kind                                                        */
+  int32_t table;       /* index into gj_plan.tables, or -1                                    */
+} gj_network;
+
+/* Scalars of one timestep.  `nets` MUST be in the reference's accumulation order
+ * (activity hierarchy, grad_june/timer.py:14-26,139-157) with the networks of one edge set
+ * adjacent; the kernels add the per-network terms in exactly this order.                   */
+typedef struct gj_step_params {
+  float now;            /* timer.now, days (timer.py:92-95)                                 */
+  float delta_time;     /* timer.duration, days (timer.py:101-103)                          */
+  int32_t day_type;     /* 0 weekday, 1 weekend (timer.py:84-90)                            */
+  int32_t has_quarantine; /* 0: no quarantine-policy collection (mask is scalar 1.0)        */
+  float q_threshold;    /* min stage_threshold over ACTIVE quarantine policies, +inf if none */
+  int32_t n_nets;
+  uint64_t seed;        /* Philox key (perf mode)                                           */
+  uint64_t step;        /* Philox stream id: timestep counter                               */
+  int64_t agent_offset; /* global id of local agent 0 (multi-GPU: partition-invariant RNG)  */
+  gj_network nets[GJ_MAX_NETS];
+} gj_step_params;
+
+/* Per-agent state, all device fp32 [n_agents] unless noted.
+ * (reference: data["agent"].*, grad_june/runner.py:72-90)                                  */
+typedef struct gj_agent_state {
+  const float* max_infectiousness; /* infection_parameters["max_infectiousness"]            */
+  const float* shape;
+  const float* rate;
+  const float* shift;
+  float* infection_time;
+  float* is_infected;
+  float* susceptibility;
+  float* transmission;       /* out of a1; in of pass 1                                     */
+  float* q_transmission;     /* workspace: qmask*transmission; may alias `transmission` when
+                                has_quarantine == 0                                          */
+  const float* current_stage; /* symptoms["current_stage"] as fp32 (NULL iff !has_quarantine) */
+} gj_agent_state;
+
+int gj_version(void);
+const char* gj_error_string(int code);
+
+/* Which optional outputs / inputs the fused step uses. NULL = not wanted / not supplied.  */
+typedef struct gj_step_io {
+  float* not_infected_probs; /* out [n_agents] (a7), optional                               */
+  float* new_infected;       /* out [n_agents] (a8), optional                               */
+  const float* exp_noise;    /* in  [2*n_agents] Exponential(1) draws, row 0 = "not infected";
+                                NULL = draw in-kernel with Philox4x32-10(seed, step, agent)  */
+  float* trans_susc;         /* out [n_agents] pre-clamp sum over networks, optional (tests) */
+} gj_step_io;
+
+/* a1 + a2: replaces TransmissionUpdater.forward (grad_june/transmission.py:38-51) and the
+ * quarantine mask of QuarantinePolicies.apply (grad_june/policies/quarantine_policies.py:26-33).
+ * Writes state->transmission and, when has_quarantine, state->q_transmission.              */
+int gj_transmission_update(const gj_plan* plan, const gj_agent_state* state,
+                           const gj_step_params* params, void* stream);
+
+/* a3 + a4 + a5 (pass 1): replaces, for every active network, the first
+ * `self.propagate(edge_index, x=transmissions, y=beta*p_contact)` of InfectionNetwork.forward
+ * (grad_june/infection_networks/base.py:61-79).  Fills plan->sets[s].cum.                   */
+int gj_venue_reduce(const gj_plan* plan, const gj_agent_state* state,
+                    const gj_step_params* params, void* stream);
+
+/* a4 + a6 + a7 (+ a8 + a9 when `sample` != 0): replaces the second propagate
+ * (base.py:80-83), the sum over networks and clamp/exp/clamp of InfectionNetworks.forward
+ * (base.py:118-141) and, fused, IsInfectedSampler.forward (grad_june/infection.py:13-18) and
+ * GradJune.infect_people (grad_june/model.py:90-110).                                       */
+int gj_agent_gather(const gj_plan* plan, const gj_agent_state* state,
+                    const gj_step_params* params, const gj_step_io* io, int sample,
+                    void* stream);
+
+/* a8 + a9 alone on a given probability vector: replaces IsInfectedSampler.forward +
+ * infect_people for callers that hold `not_infected_probs` (e.g. infect_fraction_of_people,
+ * grad_june/infection.py:31-42).                                                            */
+int gj_sample_infect(int64_t n_agents, const float* not_infected_probs, const float* exp_noise,
+                     uint64_t seed, uint64_t step, int64_t agent_offset, float now,
+                     float* new_infected, float* susceptibility, float* is_infected,
+                     float* infection_time, void* stream);
+
+/* The production step: a1..a9 = the middle of GradJune.forward (grad_june/model.py:125-138)
+ * as three dependent launches on `stream` (+1 when the plan has long rows).                */
+int gj_step(const gj_plan* plan, const gj_agent_state* state, const gj_step_params* params,
+            const gj_step_io* io, void* stream);
+
+/* Multi-GPU halo exchange helpers (one process per GPU; the all-to-all itself is issued by
+ * the host through torch.distributed/RCCL between the two calls).
+ * pack:   out[i] = src[index[i]]            for i < n      (send buffer of owned agents)
+ * unpack: dst[index[i]] = in[i]             for i < n      (halo slots of remote agents)   */
+int gj_pack_f32(int64_t n, const int32_t* index, const float* src, float* out, void* stream);
+int gj_unpack_f32(int64_t n, const int32_t* index, const float* in, float* dst, void* stream);
+
+/* Average device time of the last-timed dominant kernel is measured by the caller with
+ * hipEvents; these two helpers let a ctypes caller do that on the stream it launches on
+ * (torch.cuda.Event only sees torch's current stream).                                      */
+int gj_event_create(void** event);
+int gj_event_record(void* event, void* stream);
+int gj_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop`       */
+int gj_event_destroy(void* event);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRADJUNE_HIP_H */

@@ -1,0 +1,101 @@
+"""Shared helpers for the test-suite: golden fixture access and engine construction."""
+from __future__ import annotations
+
+import json
+import math
+import os
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+EDGE_SETS = ["household", "company", "school", "university", "care_home", "leisure"]
+HIERARCHY = ["school", "university", "company", "care_home", "pub", "gym", "grocery", "visit",
+             "care_visit", "cinema", "household"]
+LEISURE = ("pub", "gym", "grocery", "visit", "cinema")
+
+
+def load_npz(name: str) -> Dict[str, np.ndarray]:
+    with np.load(os.path.join(GOLDEN, name), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+def world_from(npz: Dict[str, np.ndarray], prefix: str = "world/") -> dict:
+    w = {"n_agents": int(npz[prefix + "n_agents"]),
+         "age": torch.from_numpy(npz[prefix + "age"]), "sex": torch.from_numpy(npz[prefix + "sex"]),
+         "edge_sets": {}}
+    for s in EDGE_SETS:
+        k = f"{prefix}es/{s}/agent"
+        if k in npz:
+            w["edge_sets"][s] = {"agent": torch.from_numpy(npz[k]),
+                                 "venue": torch.from_numpy(npz[f"{prefix}es/{s}/venue"]),
+                                 "people": torch.from_numpy(npz[f"{prefix}es/{s}/people"])}
+    return w
+
+
+def step_record(npz, prefix: str) -> dict:
+    n = len(prefix)
+    return {k[n:]: v for k, v in npz.items() if k.startswith(prefix)}
+
+
+def pre_state(rec) -> Dict[str, torch.Tensor]:
+    return {k[4:]: torch.from_numpy(v) for k, v in rec.items() if k.startswith("pre/")}
+
+
+def step_scalars(rec):
+    active = str(rec["active"]).split(",") if str(rec["active"]) else []
+    betas = {n: float(rec["beta/" + n]) for n in active}
+    thr = None
+    if int(rec["has_quarantine"]):
+        thr = [None if np.isnan(t) else float(t) for t in rec["q_thresholds"]]
+    return dict(now=float(rec["now"]), delta_time=float(rec["dt"]), day_type=int(rec["day_type"]),
+                active=active, betas=betas, quarantine_thresholds=thr)
+
+
+def tables_from(npz) -> Dict[str, torch.Tensor]:
+    return {k[6:]: torch.from_numpy(v) for k, v in npz.items() if k.startswith("table/")}
+
+
+def q_threshold(thr) -> float:
+    """min over active thresholds; +inf if none is active (mask of ones)."""
+    act = [t for t in (thr or []) if t is not None]
+    return min(act) if act else math.inf
+
+
+# ---- engine construction (GPU) -------------------------------------------------------------
+def network_specs(world, tables: Optional[dict] = None):
+    from grad_june_amd import _native as N
+    from grad_june_amd.plan import NetworkSpec
+
+    specs = []
+    for name in HIERARCHY:
+        if name == "household":
+            kind, es, tab = N.MASK_RAW, "household", None
+        elif name in LEISURE or name == "care_visit":
+            kind = N.MASK_QL_AGE75 if name == "care_visit" else N.MASK_QL
+            es = "leisure"
+            tab = None if tables is None or name not in tables else tables[name].numpy()
+            if tab is None:
+                continue
+        else:
+            kind, es, tab = N.MASK_Q, name, None
+        if es in world["edge_sets"]:
+            specs.append(NetworkSpec(name, es, kind, tab))
+    return specs
+
+
+def make_engine(world, tables, device):
+    from grad_june_amd.engine import InfectionEngine
+    from grad_june_amd.plan import DevicePlan, compile_plan
+
+    es = {k: {kk: vv.numpy() for kk, vv in v.items()} for k, v in world["edge_sets"].items()}
+    host = compile_plan(world["n_agents"], es, age=world["age"].numpy(), sex=world["sex"].numpy())
+    plan = DevicePlan(host, network_specs(world, tables), device)
+    return InfectionEngine(plan)
+
+
+def device_state(state: Dict[str, torch.Tensor], device):
+    d = {k: v.to(torch.float32).to(device).contiguous() for k, v in state.items()}
+    d["transmission"] = torch.zeros_like(d["is_infected"])
+    return d

@@ -1,0 +1,189 @@
+"""GPU parity: the HIP path (through the C ABI) against the golden vectors recorded from the
+reference, stage by stage and as the fused production step.
+
+Tolerances (north_star: per-agent infection probabilities within 1e-5 fp32, equal infection
+counts on identical noise):
+  transmission           rtol 2e-5  (device lgammaf/powf/expf vs the host's libm)
+  cum_n[v], ts           rtol 2e-5  (+ summation order for venues summed by more than one lane)
+  not_infected_probs     atol 1e-5
+  new_infected           EXACTLY the recorded decisions when fed the recorded probabilities;
+                         in the fused step a decision may differ only where the oracle's Gumbel
+                         margin |z1-z0| is below 1e-3 (none occurs in the fixtures)
+"""
+import numpy as np
+import pytest
+import torch
+
+import gj_testlib as L
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 2e-5
+
+
+def _close(a, b, rtol=RTOL, atol=1e-9, what=""):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = np.asarray(b)
+    ok = np.allclose(a, b, rtol=rtol, atol=atol)
+    assert ok, f"{what}: max abs diff {np.abs(a - b).max():.3e}, max rel {np.max(np.abs(a - b) / (np.abs(b) + 1e-30)):.3e}"
+
+
+def _margins(p, noise):
+    p = torch.from_numpy(p)
+    z0 = (p.log() - torch.from_numpy(noise[0]).log()) / 0.1
+    z1 = ((1 - p).log() - torch.from_numpy(noise[1]).log()) / 0.1
+    return (z1 - z0).abs().numpy()
+
+
+def run_case(npz, prefix, engine, device, tables):
+    from grad_june_amd.engine import AgentBuffers
+
+    rec = L.step_record(npz, prefix)
+    sc = L.step_scalars(rec)
+    st = L.device_state(L.pre_state(rec), device)
+    A = engine.plan.host.n_agents
+    has_q = sc["quarantine_thresholds"] is not None
+    p = engine.params(now=sc["now"], delta_time=sc["delta_time"], day_type=sc["day_type"],
+                      active=sc["active"], betas=sc["betas"], has_quarantine=has_q,
+                      q_threshold=L.q_threshold(sc["quarantine_thresholds"]))
+
+    def buffers(s):
+        return AgentBuffers(engine.plan, max_infectiousness=s["max_infectiousness"], shape=s["shape"],
+                            rate=s["rate"], shift=s["shift"], infection_time=s["infection_time"],
+                            is_infected=s["is_infected"], susceptibility=s["susceptibility"],
+                            transmission=s["transmission"], current_stage=s["current_stage"])
+
+    # ---- stage by stage -------------------------------------------------------------------
+    bufs = buffers(st)
+    engine.transmission_update(bufs, p)
+    _close(st["transmission"], rec["transmission"], what=prefix + "transmission (a1)")
+    if has_q and "qmask" in rec:
+        _close(bufs.tensors["q_transmission"], rec["qmask"] * rec["transmission"], what=prefix + "q*transmission (a2)")
+
+    engine.venue_reduce(bufs, p)
+    per_set = {}
+    for name in sc["active"]:
+        spec = engine.plan.networks[name]
+        k = per_set.get(spec.edge_set, 0)
+        per_set[spec.edge_set] = k + 1
+        cum = engine.plan.cum_of(spec.edge_set)[:, k]
+        ref = rec["cum/" + name]
+        _close(cum, ref, atol=1e-12 + 1e-6 * float(np.abs(ref).max() if ref.size else 0), what=f"{prefix}cum/{name} (a5)")
+
+    probs = torch.empty(A, device=device)
+    ts = torch.empty(A, device=device)
+    engine.agent_gather(bufs, p, engine.io(not_infected_probs=probs, trans_susc=ts), sample=False)
+    ts_ref = np.zeros(A, dtype=np.float32)
+    for name in sc["active"]:
+        ts_ref += rec["ts/" + name]
+    _close(ts, ts_ref, atol=1e-7, what=prefix + "sum_n ts_n (a6)")
+    assert np.abs(probs.cpu().numpy() - rec["not_infected_probs"]).max() <= 1e-5, prefix + "not_infected_probs (a7)"
+
+    # ---- a8 + a9 teacher-forced on the recorded probabilities: decisions must be exact -------
+    s2 = {k: v.clone() for k, v in st.items()}
+    new_inf = torch.empty(A, device=device)
+    noise = torch.from_numpy(rec["exp_noise"]).to(device).contiguous()
+    engine.sample_infect(torch.from_numpy(rec["not_infected_probs"]).to(device), now=sc["now"],
+                         susceptibility=s2["susceptibility"], is_infected=s2["is_infected"],
+                         infection_time=s2["infection_time"], exp_noise=noise, new_infected=new_inf)
+    got = new_inf.cpu().numpy()
+    assert np.array_equal(got > 0.5, rec["new_infected"] > 0.5), prefix + "decisions (a8)"
+    assert np.abs(got - rec["new_infected"]).max() <= 1e-6
+    for k in ("susceptibility", "is_infected", "infection_time"):
+        _close(s2[k], rec["post/" + k], rtol=1e-6, atol=1e-6, what=prefix + "post/" + k + " (a9)")
+
+    # ---- the fused production step from the recorded pre-state -----------------------------
+    s3 = L.device_state(L.pre_state(rec), device)
+    new3 = torch.empty(A, device=device)
+    p3 = torch.empty(A, device=device)
+    engine.step(buffers(s3), p, engine.io(not_infected_probs=p3, new_infected=new3, exp_noise=noise))
+    torch.cuda.synchronize()
+    assert np.abs(p3.cpu().numpy() - rec["not_infected_probs"]).max() <= 1e-5
+    dec = new3.cpu().numpy() > 0.5
+    bad = dec != (rec["new_infected"] > 0.5)
+    if bad.any():
+        m = _margins(rec["not_infected_probs"], rec["exp_noise"])
+        assert (m[bad] < 1e-3).all(), prefix + "fused decision differs away from a tie"
+    else:
+        assert dec.sum() == (rec["new_infected"] > 0.5).sum()
+        for k in ("susceptibility", "is_infected", "infection_time"):
+            _close(s3[k], rec["post/" + k], rtol=1e-6, atol=1e-6, what=prefix + "fused post/" + k)
+    return int(bad.sum())
+
+
+def test_kat6(device):
+    """The reference's exact known-answer test (test_base.py:39-44) through the HIP path."""
+    from grad_june_amd.engine import AgentBuffers
+
+    npz = L.load_npz("kat6.npz")
+    world = L.world_from(npz)
+    eng = L.make_engine(world, None, device)
+    A = 6
+    z = lambda: torch.zeros(A, device=device)
+    trans = torch.from_numpy(npz["transmission"]).to(device)
+    susc = torch.from_numpy(npz["susceptibility"]).to(device)
+    bufs = AgentBuffers(eng.plan, infection_time=z(), is_infected=z(), susceptibility=susc, transmission=trans)
+    p = eng.params(now=0.0, delta_time=float(npz["dt"]), day_type=0, active=["school"],
+                   betas={"school": float(npz["beta/school"])})
+    probs = torch.empty(A, device=device)
+    eng.venue_reduce(bufs, p)
+    eng.agent_gather(bufs, p, eng.io(not_infected_probs=probs), sample=False)
+    expected = np.exp(-npz["expected_exponent"])
+    assert np.allclose(probs.cpu().numpy(), expected)
+    assert np.abs(probs.cpu().numpy() - npz["not_infected_probs"]).max() <= 1e-6
+
+
+def test_c100_policy_variants(device):
+    npz = L.load_npz("c100.npz")
+    world = L.world_from(npz)
+    eng = L.make_engine(world, None, device)
+    flips = 0
+    for v in str(npz["variants"]).split(","):
+        flips += run_case(npz, v + "/", eng, device, None)
+    assert flips == 0
+
+
+@pytest.mark.parametrize("name", ["june769.npz", "june769_hot.npz", "synth10k.npz"])
+def test_trajectory_teacher_forced(device, name):
+    """Every recorded step of the reference trajectories, each from its recorded pre-state."""
+    npz = L.load_npz(name)
+    world = L.world_from(npz)
+    tables = L.tables_from(npz)
+    eng = L.make_engine(world, tables, device)
+    flips = 0
+    for i in range(int(npz["n_steps"])):
+        flips += run_case(npz, f"step{i}/", eng, device, tables)
+    assert flips == 0
+
+
+@pytest.mark.parametrize("name", ["june769.npz", "june769_hot.npz"])
+def test_trajectory_chained_counts(device, name):
+    """15 chained hot-path steps on the GPU (own state carried forward; the recorded symptom
+    stage supplies the quarantine mask, symptoms being outside the path): infection counts per
+    timestep must equal the reference's cases_per_timestep under the same injected noise."""
+    from grad_june_amd.engine import AgentBuffers
+
+    npz = L.load_npz(name)
+    world = L.world_from(npz)
+    tables = L.tables_from(npz)
+    eng = L.make_engine(world, tables, device)
+    A = world["n_agents"]
+    rec0 = L.step_record(npz, "step0/")
+    st = L.device_state(L.pre_state(rec0), device)
+    cases = [float(st["is_infected"].sum().item())]
+    for i in range(int(npz["n_steps"])):
+        rec = L.step_record(npz, f"step{i}/")
+        sc = L.step_scalars(rec)
+        st["current_stage"] = torch.from_numpy(rec["pre/current_stage"]).to(torch.float32).to(device)
+        has_q = sc["quarantine_thresholds"] is not None
+        p = eng.params(now=sc["now"], delta_time=sc["delta_time"], day_type=sc["day_type"], active=sc["active"],
+                       betas=sc["betas"], has_quarantine=has_q, q_threshold=L.q_threshold(sc["quarantine_thresholds"]))
+        bufs = AgentBuffers(eng.plan, max_infectiousness=st["max_infectiousness"], shape=st["shape"], rate=st["rate"],
+                            shift=st["shift"], infection_time=st["infection_time"], is_infected=st["is_infected"],
+                            susceptibility=st["susceptibility"], transmission=st["transmission"],
+                            current_stage=st["current_stage"])
+        noise = torch.from_numpy(rec["exp_noise"]).to(device).contiguous()
+        eng.step(bufs, p, eng.io(exp_noise=noise))
+        cases.append(float(st["is_infected"].sum().item()))
+        assert np.array_equal(st["is_infected"].cpu().numpy(), rec["post/is_infected"]), f"step {i}"
+    assert np.allclose(cases, npz["cases_per_timestep"])
