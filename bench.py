@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""Benchmark of the per-timestep infection hot path (rows a1-a9 of SURVEY.md section 8) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--preset c3] [--agents A]
+
+A "step" is one pass of the hot path (transmission update -> pass 1 -> pass 2 + epilogue +
+Gumbel decision + state update) over the synthetic contact world, with every input resident in
+HBM when the timed region starts.  Default workload = BASELINE.json configs[2]: 10 M agents, 8
+infection networks on 6 edge sets, 120 M network-edges (grad_june_amd/synthetic.py, seed 1234),
+in-kernel Philox noise.  Prints ONE JSON line (rank 0).
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); the SAME world is
+partitioned across ranks (strong scaling) - see grad_june_amd/distributed.py.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "gradabm-june_amd"))
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--preset", default="c3", choices=["c2", "c3", "c5"])
+    ap.add_argument("--agents", type=int, default=None)
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--infected", type=float, default=0.01)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
+    return ap.parse_args()
+
+
+DEFAULT_LOG_BETA = {"household": -0.4, "company": -0.3, "school": -0.3, "pub": -1.2, "gym": -1.2, "grocery": -1.2,
+                    "visit": -1.2, "cinema": -1.2, "university": -0.5, "care_visit": -0.4, "care_home": -0.4}
+
+
+def network_specs(world):
+    from grad_june_amd import _native as N
+    from grad_june_amd.defaults import default_parameters
+    from grad_june_amd.infection_networks import LeisureNetwork
+    from grad_june_amd.plan import NetworkSpec
+    from grad_june_amd.synthetic import edge_set_of
+
+    leisure = default_parameters()["leisure"]
+    specs = []
+    for name in world["networks"]:
+        es = edge_set_of(name)
+        if name == "household":
+            specs.append(NetworkSpec(name, es, N.MASK_RAW, None))
+        elif es == "leisure":
+            tab = LeisureNetwork(0.0, leisure[name], device="cpu").leisure_probabilities.numpy()
+            specs.append(NetworkSpec(name, es, N.MASK_QL_AGE75 if name == "care_visit" else N.MASK_QL, tab))
+        else:
+            specs.append(NetworkSpec(name, es, N.MASK_Q, None))
+    return specs
+
+
+def betas_of(world):
+    return {n: float(torch.tensor(10.0) ** torch.tensor(DEFAULT_LOG_BETA[n])) for n in world["networks"]}
+
+
+def kernel_bytes(world, networks):
+    """Split of B_step over the three launches."""
+    from grad_june_amd.synthetic import edge_set_of
+
+    A = world["n_agents"]
+    E = {k: len(v["agent"]) for k, v in world["edge_sets"].items()}
+    V = {k: len(v["people"]) for k, v in world["edge_sets"].items()}
+    sets = {edge_set_of(n) for n in networks}
+    e_sets = sum(E[s] for s in sets)
+    e_nets = sum(E[edge_set_of(n)] for n in networks)
+    v_nets = sum(V[edge_set_of(n)] for n in networks)
+    N = len(networks)
+    return {
+        "transmission": 32 * A,                                   # 6 reads + 1 write + quarantine mask
+        "venue_reduce": 4 * e_sets + 4 * e_nets + 12 * v_nets,    # pass 1
+        "agent_gather": 4 * e_sets + 4 * e_nets + 8 * N * A + 32 * A,  # pass 2 + probs + sample + infect
+    }
+
+
+def cpu_baseline(world, networks, betas, tables, budget_s):
+    """The CPU oracle (= the reference's ATen op sequence) timed on this host, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gj_oracle as O
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    w = {"n_agents": world["n_agents"], "age": torch.from_numpy(world["age"]), "sex": torch.from_numpy(world["sex"]),
+         "edge_sets": {k: {kk: torch.from_numpy(vv) for kk, vv in v.items()} for k, v in world["edge_sets"].items()}}
+    st = {k: torch.from_numpy(v.copy()) for k, v in world["state"].items()}
+    tabs = {k: torch.from_numpy(v) for k, v in tables.items()}
+    kw = dict(delta_time=1.0, day_type=0, active=networks, betas=betas, leisure_tables=tabs,
+              quarantine_thresholds=None)
+    times = []
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        out = O.hot_path_step(w, st, now=1.0, **kw)           # warm-up (also first-touch)
+        first = time.perf_counter() - t0
+        n = 0
+        t_start = time.perf_counter()
+        while n < 10 and (time.perf_counter() - t_start + first) < budget_s:
+            for k in ("susceptibility", "is_infected", "infection_time"):
+                st[k] = out[k]
+            t0 = time.perf_counter()
+            out = O.hot_path_step(w, st, now=2.0 + n, **kw)
+            times.append(time.perf_counter() - t0)
+            n += 1
+    if not times:
+        times = [first]
+    sps = 1.0 / float(np.mean(times))
+    return {"value": sps, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} full steps of the same workload (after 1 warm-up step), torch CPU ops, no_grad",
+            "edges_per_s": sps * sum(len(world["edge_sets"][_es(n_)]["agent"]) for n_ in networks)}
+
+
+def _es(n):
+    from grad_june_amd.synthetic import edge_set_of
+
+    return edge_set_of(n)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world_size:
+        if world_size == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import __graft_entry__ as entry
+
+    if rank == 0:
+        entry.build()
+    if world_size > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)
+        dist.barrier()
+
+    from grad_june_amd.synthetic import make_world, algorithmic_bytes, network_edges
+
+    t0 = time.time()
+    world = make_world(args.preset, n_agents=args.agents, seed=args.seed, infected_fraction=args.infected)
+    networks = world["networks"]
+    betas = betas_of(world)
+    specs = network_specs(world)
+    tables = {s.name: s.table for s in specs if s.table is not None}
+    t_gen = time.time() - t0
+
+    if world_size > 1:
+        from grad_june_amd.distributed import DistributedHotPath
+
+        runner = DistributedHotPath(world, specs, betas, dev, rank, world_size, seed=args.seed)
+    else:
+        from grad_june_amd.benchrun import SingleGpuHotPath
+
+        runner = SingleGpuHotPath(world, specs, betas, dev, seed=args.seed)
+    t_setup = time.time() - t0
+
+    def sync():
+        torch.cuda.synchronize()
+        if world_size > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        runner.step()
+    sync()
+    runner.reset_timers()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        runner.step(timed=True)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world_size > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank != 0:
+        if world_size > 1:
+            dist.destroy_process_group()
+        return
+
+    sps = args.steps / elapsed
+    n_edges = network_edges(world, networks)
+    b_step = algorithmic_bytes(world, networks)
+    kb = kernel_bytes(world, networks)
+    kt = runner.kernel_ms()          # mean ms per launch, HIP events on the launch stream
+    dom = max(kt, key=kt.get)
+    share = 1.0 / world_size         # each rank streams its own partition
+    achieved = kb[dom] * share / (kt[dom] * 1e-3) / 1e9
+    out = {
+        "metric": "simulation steps/sec",
+        "value": sps,
+        "unit": "steps/s",
+        "n_gpus": world_size,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{args.preset}: {world['n_agents']} agents, {len(networks)} infection networks on "
+                               f"{len(world['edge_sets'])} edge sets, {n_edges} network-edges, seed {args.seed}, "
+                               f"{args.infected:.0%} infected, Philox noise",
+                   "preset": args.preset, "n_agents": world["n_agents"], "network_edges": n_edges,
+                   "parallelism": f"agents partitioned over {world_size} GPU(s)"},
+        "edges_per_s": sps * n_edges,
+        "algorithmic_bytes_per_step": b_step,
+        "step_roofline_frac": b_step * sps / (HBM_PEAK_GBS * 1e9 * world_size),
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": kb[dom] * share, "ms_per_launch": kt[dom]},
+        "kernel_ms": kt,
+        "setup_s": {"generate": t_gen, "total": t_setup},
+    }
+    if not args.no_cpu_baseline and world_size == 1:
+        out["cpu_baseline"] = cpu_baseline(world, networks, betas, tables, args.cpu_seconds)
+    print(json.dumps(out))
+    if world_size > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

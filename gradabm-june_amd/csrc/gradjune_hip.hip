@@ -374,13 +374,21 @@ __global__ __launch_bounds__(kThreads) void k_sample_infect(int64_t n, const flo
   }
   const float nw = gumbel_new_infected(p_not[a], e0, e1);
   if (new_inf) new_inf[a] = nw;
-  if (nw != 0.0f) {
+  if (susc != nullptr && nw != 0.0f) {   // state pointers NULL: sample only
     float s = susc[a], i = inf[a], t = t_inf[a];
     infect(nw, now, s, i, t);
     susc[a] = s;
     inf[a] = i;
     t_inf[a] = t;
   }
+}
+
+// a2 alone: q*transmission for a caller-supplied transmission vector
+__global__ __launch_bounds__(kThreads) void k_quarantine_transmission(int64_t n, const float* __restrict__ stage,
+                                                                      const float* __restrict__ trans,
+                                                                      float* __restrict__ qtrans, float q_thr) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) qtrans[i] = (stage[i] < q_thr ? 1.0f : 0.0f) * trans[i];
 }
 
 // halo pack / unpack
@@ -625,6 +633,21 @@ int gj_transmission_update(const gj_plan* plan, const gj_agent_state* state, con
   return gj::do_transmission(plan, state, params, (hipStream_t)stream);
 }
 
+int gj_quarantine_transmission(const gj_plan* plan, const gj_agent_state* state, const gj_step_params* params,
+                               void* stream) {
+  int rc = gj::check_plan(plan);
+  if (rc) return rc;
+  if (!params) return GJ_E_NULL;
+  rc = gj::check_state(plan, state, params);
+  if (rc) return rc;
+  if (!params->has_quarantine || plan->n_agents == 0) return GJ_OK;
+  const int64_t n = plan->n_agents;
+  hipLaunchKernelGGL(gj::k_quarantine_transmission, dim3((unsigned)((n + gj::kThreads - 1) / gj::kThreads)),
+                     dim3(gj::kThreads), 0, (hipStream_t)stream, n, state->current_stage, state->transmission,
+                     state->q_transmission, params->q_threshold);
+  return gj::launch_status();
+}
+
 int gj_venue_reduce(const gj_plan* plan, const gj_agent_state* state, const gj_step_params* params, void* stream) {
   int rc = gj::check_plan(plan);
   if (rc) return rc;
@@ -653,7 +676,10 @@ int gj_sample_infect(int64_t n_agents, const float* not_infected_probs, const fl
                      float* is_infected, float* infection_time, void* stream) {
   if (n_agents < 0) return GJ_E_RANGE;
   if (n_agents == 0) return GJ_OK;
-  if (!not_infected_probs || !susceptibility || !is_infected || !infection_time) return GJ_E_NULL;
+  if (!not_infected_probs) return GJ_E_NULL;
+  const int n_state = (susceptibility != nullptr) + (is_infected != nullptr) + (infection_time != nullptr);
+  if (n_state != 0 && n_state != 3) return GJ_E_NULL;   // all three or none (sample only)
+  if (n_state == 0 && !new_infected) return GJ_E_NULL;
   const int64_t blocks = (n_agents + gj::kThreads - 1) / gj::kThreads;
   hipLaunchKernelGGL(gj::k_sample_infect, dim3((unsigned)blocks), dim3(gj::kThreads), 0, (hipStream_t)stream, n_agents,
                      not_infected_probs, exp_noise, seed, step, agent_offset, now, new_infected, susceptibility,

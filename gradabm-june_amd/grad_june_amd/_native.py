@@ -112,6 +112,7 @@ SYMBOLS = {
     "gj_version": (C.c_int, []),
     "gj_error_string": (C.c_char_p, [C.c_int]),
     "gj_transmission_update": (C.c_int, [C.POINTER(Plan), C.POINTER(AgentState), C.POINTER(StepParams), _vp]),
+    "gj_quarantine_transmission": (C.c_int, [C.POINTER(Plan), C.POINTER(AgentState), C.POINTER(StepParams), _vp]),
     "gj_venue_reduce": (C.c_int, [C.POINTER(Plan), C.POINTER(AgentState), C.POINTER(StepParams), _vp]),
     "gj_agent_gather": (
         C.c_int,

@@ -1,0 +1,96 @@
+"""Hot-path stepping on one GPU for bench.py and the large-size tests: plan upload, state upload,
+a step loop with HIP events between the launches (on the stream the kernels run on)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Sequence
+
+import numpy as np
+import torch
+
+from . import _native as N
+from .engine import AgentBuffers, InfectionEngine
+from .plan import DevicePlan, NetworkSpec, compile_plan
+
+
+class EventLog:
+    """hipEvent marks recorded during the timed region, resolved after it."""
+
+    def __init__(self):
+        self.lib = N.load()
+        self.marks: List[tuple] = []
+
+    def mark(self, label: str):
+        e = C.c_void_p()
+        N.check(self.lib.gj_event_create(C.byref(e)), "gj_event_create")
+        N.check(self.lib.gj_event_record(e, N.current_stream()), "gj_event_record")
+        self.marks.append((label, e))
+
+    def spans(self) -> Dict[str, List[float]]:
+        """label of mark i = the kernel launched between mark i-1 and mark i."""
+        out: Dict[str, List[float]] = {}
+        ms = C.c_float()
+        for (_, a), (label, b) in zip(self.marks[:-1], self.marks[1:]):
+            if label == "begin":
+                continue
+            N.check(self.lib.gj_event_elapsed_ms(a, b, C.byref(ms)), "gj_event_elapsed_ms")
+            out.setdefault(label, []).append(float(ms.value))
+        return out
+
+    def clear(self):
+        for _, e in self.marks:
+            self.lib.gj_event_destroy(e)
+        self.marks = []
+
+
+class SingleGpuHotPath:
+    def __init__(self, world: dict, specs: Sequence[NetworkSpec], betas: Dict[str, float], device,
+                 seed: int = 0, quarantine_threshold=None, exp_noise=None):
+        self.device = torch.device(device)
+        host = compile_plan(world["n_agents"], world["edge_sets"], age=world["age"], sex=world["sex"])
+        self.engine = InfectionEngine(DevicePlan(host, specs, self.device))
+        self.networks = list(world["networks"])
+        self.betas = betas
+        self.seed = seed
+        self.q_thr = quarantine_threshold
+        st = world["state"]
+        self.state = {k: torch.from_numpy(np.ascontiguousarray(v)).to(self.device) for k, v in st.items()}
+        A = world["n_agents"]
+        self.state["transmission"] = torch.zeros(A, dtype=torch.float32, device=self.device)
+        self.new_infected = torch.empty(A, dtype=torch.float32, device=self.device)
+        self.probs = torch.empty(A, dtype=torch.float32, device=self.device)
+        s = self.state
+        self.bufs = AgentBuffers(self.engine.plan, max_infectiousness=s["max_infectiousness"], shape=s["shape"],
+                                 rate=s["rate"], shift=s["shift"], infection_time=s["infection_time"],
+                                 is_infected=s["is_infected"], susceptibility=s["susceptibility"],
+                                 transmission=s["transmission"], current_stage=s["current_stage"])
+        self.io = self.engine.io(not_infected_probs=self.probs, new_infected=self.new_infected, exp_noise=exp_noise)
+        self.t = 0
+        self.log = EventLog()
+
+    def params(self):
+        has_q = self.q_thr is not None
+        return self.engine.params(now=1.0 + self.t, delta_time=1.0, day_type=0, active=self.networks,
+                                  betas=self.betas, has_quarantine=has_q,
+                                  q_threshold=self.q_thr if has_q else float("inf"), seed=self.seed, step=self.t)
+
+    def step(self, timed: bool = False):
+        p = self.params()
+        e = self.engine
+        if not timed:
+            e.step(self.bufs, p, self.io)
+        else:
+            self.log.mark("begin")
+            e.transmission_update(self.bufs, p)
+            self.log.mark("transmission")
+            e.venue_reduce(self.bufs, p)
+            self.log.mark("venue_reduce")
+            e.agent_gather(self.bufs, p, self.io, sample=True)
+            self.log.mark("agent_gather")
+        self.t += 1
+
+    def reset_timers(self):
+        self.log.clear()
+
+    def kernel_ms(self) -> Dict[str, float]:
+        return {k: float(np.mean(v)) for k, v in self.log.spans().items()}

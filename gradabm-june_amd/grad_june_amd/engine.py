@@ -96,6 +96,11 @@ class InfectionEngine:
         N.check(self.lib.gj_transmission_update(C.byref(self.plan.c), C.byref(bufs.c), C.byref(p),
                                                 N.current_stream()), "gj_transmission_update")
 
+    def quarantine_transmission(self, bufs: AgentBuffers, p: N.StepParams):
+        self._prep(bufs, p)
+        N.check(self.lib.gj_quarantine_transmission(C.byref(self.plan.c), C.byref(bufs.c), C.byref(p),
+                                                    N.current_stream()), "gj_quarantine_transmission")
+
     def venue_reduce(self, bufs: AgentBuffers, p: N.StepParams):
         self._prep(bufs, p)
         N.check(self.lib.gj_venue_reduce(C.byref(self.plan.c), C.byref(bufs.c), C.byref(p),

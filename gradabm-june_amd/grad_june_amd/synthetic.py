@@ -1,0 +1,162 @@
+"""Seeded synthetic contact worlds in the reference's graph format.
+
+The reference ships one 769-agent world; its "London" world is not in the tree.  Benchmarks and
+large-size tests therefore use worlds generated here with ``numpy.random.default_rng(seed)``:
+unsorted COO edge lists per venue type, ``people[v]`` = degree, agent age/sex, the four
+per-agent infection parameters drawn from the default distributions
+(configs/default.yaml:100-116), 1 % of the agents infected at U[-10, 0] days.
+
+Presets (BASELINE.json configs):
+  "c2"  1 M agents, household/school/company, 5 memberships per agent and network (15 M edges)
+  "c3"  10 M agents, household, care_home, company, school, university + pub/grocery/gym on one
+        shared leisure set; every edge set 15 M edges (90 M set-edges, 120 M network-edges)
+  "c5"  power-law venue degrees (Zipf alpha=2 truncated to [1, 50 000])
+All presets scale with ``n_agents`` (edges per agent are kept).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+
+PRESETS = {
+    # set -> (memberships per agent, size distribution)
+    "c2": {
+        "household": (5.0, ("poisson1", 1.5)),
+        "school": (5.0, ("lognormal", 500.0, 0.5)),
+        "company": (5.0, ("lognormal", 20.0, 1.0)),
+    },
+    "c3": {
+        "household": (1.5, ("poisson1", 1.5)),
+        "care_home": (1.5, ("lognormal", 50.0, 0.5)),
+        "company": (1.5, ("lognormal", 20.0, 1.0)),
+        "school": (1.5, ("lognormal", 500.0, 0.5)),
+        "university": (1.5, ("lognormal", 2000.0, 0.5)),
+        "leisure": (1.5, ("lognormal", 5000.0, 0.5)),
+    },
+    "c5": {
+        s: (1.5, ("zipf", 2.0, 50_000))
+        for s in ("household", "care_home", "company", "school", "university", "leisure")
+    },
+}
+
+NETWORKS = {
+    "c2": ["school", "company", "household"],
+    "c3": ["school", "university", "company", "care_home", "pub", "gym", "grocery", "household"],
+    "c5": ["school", "university", "company", "care_home", "pub", "gym", "grocery", "household"],
+}
+
+
+def _venue_sizes(rng, dist, n_edges: int) -> np.ndarray:
+    """Draw venue sizes until they sum to ``n_edges`` (last venue takes the remainder)."""
+    kind = dist[0]
+    if kind == "poisson1":
+        mean = 1.0 + dist[1]
+        draw = lambda m: 1 + rng.poisson(dist[1], m)
+    elif kind == "lognormal":
+        mean_target, sigma = dist[1], dist[2]
+        mu = np.log(mean_target) - 0.5 * sigma * sigma
+        mean = mean_target
+        draw = lambda m: np.maximum(1, rng.lognormal(mu, sigma, m)).astype(np.int64)
+    elif kind == "zipf":
+        alpha, cap = dist[1], dist[2]
+        mean = 12.0
+        draw = lambda m: np.minimum(rng.zipf(alpha, m), cap).astype(np.int64)
+    else:
+        raise ValueError(kind)
+    sizes = np.zeros(0, dtype=np.int64)
+    total = 0
+    while total < n_edges:
+        m = int((n_edges - total) / mean * 1.05) + 16
+        sizes = np.concatenate([sizes, draw(m).astype(np.int64)])
+        total = int(sizes.sum())
+    cs = np.cumsum(sizes)
+    last = int(np.searchsorted(cs, n_edges, side="left"))
+    sizes = sizes[: last + 1].copy()
+    sizes[last] -= cs[last] - n_edges
+    return sizes[sizes > 0]
+
+
+def _edge_set(rng, n_agents: int, n_edges: int, dist) -> dict:
+    sizes = _venue_sizes(rng, dist, n_edges)
+    V = len(sizes)
+    venue = np.repeat(np.arange(V, dtype=np.int64), sizes)
+    # every agent gets floor(E/A) memberships, a random subset one more
+    base, extra = divmod(n_edges, n_agents)
+    parts = [np.tile(np.arange(n_agents, dtype=np.int64), base)] if base else []
+    if extra:
+        parts.append(rng.choice(n_agents, extra, replace=False).astype(np.int64))
+    agent = np.concatenate(parts)
+    rng.shuffle(agent)
+    # no duplicate (agent, venue) pair: move the few collisions to the next venue
+    for _ in range(4):
+        key = agent * V + venue
+        order = np.argsort(key, kind="stable")
+        dup = np.zeros(len(key), dtype=bool)
+        dup[order[1:]] = key[order[1:]] == key[order[:-1]]
+        if not dup.any():
+            break
+        venue[dup] = (venue[dup] + 1) % V
+    perm = rng.permutation(n_edges)          # the reference format is unsorted COO
+    agent, venue = agent[perm], venue[perm]
+    people = np.bincount(venue, minlength=V).astype(np.int64)
+    return {"agent": agent, "venue": venue, "people": people}
+
+
+def make_world(preset: str = "c3", n_agents: Optional[int] = None, seed: int = 1234,
+               infected_fraction: float = 0.01, sets=None) -> Dict:
+    """Returns {"n_agents", "age", "sex", "edge_sets", "networks", "state"} as numpy arrays."""
+    spec = PRESETS[preset]
+    if n_agents is None:
+        n_agents = {"c2": 1_000_000, "c3": 10_000_000, "c5": 100_000_000}[preset]
+    rng = np.random.default_rng(seed)
+    A = int(n_agents)
+    world = {
+        "preset": preset,
+        "n_agents": A,
+        "age": rng.integers(0, 100, A, dtype=np.int64),
+        "sex": rng.integers(0, 2, A, dtype=np.int64),
+        "edge_sets": {},
+        "networks": list(NETWORKS[preset]),
+    }
+    for name, (per_agent, dist) in spec.items():
+        if sets is not None and name not in sets:
+            continue
+        world["edge_sets"][name] = _edge_set(rng, A, int(round(per_agent * A)), dist)
+    inf = (rng.random(A) < infected_fraction).astype(np.float32)
+    world["state"] = {
+        "max_infectiousness": rng.lognormal(0.0, 0.5, A).astype(np.float32),
+        "shape": rng.normal(1.56, 0.08, A).astype(np.float32),
+        "rate": rng.normal(0.53, 0.03, A).astype(np.float32),
+        "shift": rng.normal(-2.12, 0.1, A).astype(np.float32),
+        "is_infected": inf,
+        "susceptibility": (1.0 - inf).astype(np.float32),
+        "infection_time": (-10.0 * rng.random(A)).astype(np.float32) * inf,
+        "current_stage": np.where(inf > 0, rng.integers(2, 6, A), 1).astype(np.float32),
+    }
+    return world
+
+
+def edge_set_of(network: str) -> str:
+    return "leisure" if network in ("pub", "gym", "grocery", "visit", "cinema", "care_visit") else network
+
+
+def algorithmic_bytes(world_or_sizes, networks) -> int:
+    """B_step of SURVEY.md section 8(d) (fp32 values, int32 indices, no temporaries):
+    8*sum_sets E_s + 8*sum_n E_n + 12*sum_n V_n + (8*N + 64)*A."""
+    A = world_or_sizes["n_agents"]
+    es = world_or_sizes["edge_sets"]
+    E = {k: (len(v["agent"]) if "agent" in v else v["n_edges"]) for k, v in es.items()}
+    V = {k: (len(v["people"]) if "people" in v else v["n_venues"]) for k, v in es.items()}
+    sets = {edge_set_of(n) for n in networks}
+    b = 8 * sum(E[s] for s in sets)
+    b += 8 * sum(E[edge_set_of(n)] for n in networks)
+    b += 12 * sum(V[edge_set_of(n)] for n in networks)
+    b += (8 * len(networks) + 64) * A
+    return int(b)
+
+
+def network_edges(world_or_sizes, networks) -> int:
+    es = world_or_sizes["edge_sets"]
+    return int(sum((len(es[edge_set_of(n)]["agent"]) if "agent" in es[edge_set_of(n)] else es[edge_set_of(n)]["n_edges"])
+                   for n in networks))

@@ -1,0 +1,123 @@
+"""Bridge between the reference-shaped ``HeteroData`` world and the compiled device plan.
+
+``engine_for(data, networks)`` compiles ``data`` once (plan.py) and caches the plan + engine
+against the identity of the world's edge tensors, so the Python API mirrors
+(``InfectionNetworks.forward``, ``GradJune.forward``) can be called with the same ``data``
+object every timestep - exactly how the reference's Runner drives them (runner.py:163-166).
+"""
+from __future__ import annotations
+
+import weakref
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .engine import AgentBuffers, InfectionEngine
+from .plan import DevicePlan, NetworkSpec, compile_plan
+
+_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
+def _np(x) -> np.ndarray:
+    if isinstance(x, torch.Tensor):
+        return x.detach().cpu().numpy()
+    return np.asarray(x)
+
+
+def require_hip(device) -> torch.device:
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError(
+            f"grad_june_amd computes the infection path on a HIP device only; got device={device}. "
+            "There is no CPU or eager-PyTorch fallback (set system.device: cuda:0)."
+        )
+    return device
+
+
+def edge_sets_of(data, set_names: Sequence[str]) -> Dict[str, dict]:
+    """Forward COO of every requested edge set present in ``data`` (reference format)."""
+    out = {}
+    for s in set_names:
+        key = "attends_" + s
+        if key not in data:
+            continue
+        ei = data[key].edge_index
+        out[s] = {"agent": _np(ei[0]), "venue": _np(ei[1]), "people": _np(data[s]["people"]), "_ei": ei}
+    return out
+
+
+def _signature(data, set_names, networks) -> Tuple:
+    sig = []
+    for s in set_names:
+        key = "attends_" + s
+        if key in data:
+            ei = data[key].edge_index
+            people = data[s]["people"]
+            sig.append((s, ei.data_ptr(), tuple(ei.shape),
+                        people.data_ptr() if isinstance(people, torch.Tensor) else id(people)))
+    nets = tuple((n.name, n.edge_set, n.mask_kind, None if n.table is None else n.table.tobytes())
+                 for n in networks)
+    return tuple(sig), nets, len(data["agent"]["id"])
+
+
+def engine_for(data, specs: Sequence[NetworkSpec], device) -> InfectionEngine:
+    """Compile (or fetch the cached) plan for ``data`` and the configured networks."""
+    device = require_hip(device)
+    set_names = []
+    for n in specs:
+        if n.edge_set not in set_names:
+            set_names.append(n.edge_set)
+    sig = _signature(data, set_names, specs) + (str(device),)
+    hit = _CACHE.get(data)
+    if hit is not None and hit[0] == sig:
+        return hit[1]
+    sets = edge_sets_of(data, set_names)
+    agent = data["agent"]
+    n_agents = len(agent["id"])
+    age = _np(agent["age"]) if "age" in agent else None
+    sex = _np(agent["sex"]) if "sex" in agent else None
+    if age is None and any(n.table is not None for n in specs):
+        raise KeyError("leisure networks need data['agent'].age and .sex")
+    host = compile_plan(n_agents, {k: {kk: vv for kk, vv in v.items() if kk != "_ei"} for k, v in sets.items()},
+                        age=age, sex=sex)
+    present = [n for n in specs if n.edge_set in host.set_index]
+    engine = InfectionEngine(DevicePlan(host, present, device))
+    _CACHE[data] = (sig, engine)
+    return engine
+
+
+def _f32(store, key, device, n):
+    """Fetch a per-agent tensor as contiguous float32 on ``device`` (converted in place in the store)."""
+    t = store[key]
+    if not isinstance(t, torch.Tensor):
+        t = torch.as_tensor(t)
+    if t.dtype != torch.float32 or t.device != device or not t.is_contiguous():
+        t = t.detach().to(device=device, dtype=torch.float32).contiguous()
+        store[key] = t
+    if t.numel() != n:
+        raise ValueError(f"agent.{key}: expected {n} values, got {t.numel()}")
+    return t
+
+
+def agent_buffers(engine: InfectionEngine, data, *, need_params: bool, need_stage: bool) -> AgentBuffers:
+    """Device views of ``data['agent']`` for one launch.  State tensors are used IN PLACE."""
+    dev = engine.plan.device
+    ag = data["agent"]
+    n = engine.plan.host.n_agents
+    kw = {}
+    if need_params:
+        ip = ag["infection_parameters"]
+        for k in ("max_infectiousness", "shape", "rate", "shift"):
+            kw[k] = _f32(ip, k, dev, n)
+    for k in ("infection_time", "is_infected", "susceptibility"):
+        kw[k] = _f32(ag, k, dev, n)
+    if "transmission" not in ag:
+        ag["transmission"] = torch.zeros(n, dtype=torch.float32, device=dev)
+    kw["transmission"] = _f32(ag, "transmission", dev, n)
+    if need_stage:
+        stage = ag["symptoms"]["current_stage"]
+        if stage.dtype != torch.float32 or stage.device != dev or not stage.is_contiguous():
+            stage = stage.detach().to(device=dev, dtype=torch.float32).contiguous()   # copy for this call
+        kw["current_stage"] = stage
+    return AgentBuffers(engine.plan, **kw)

@@ -177,6 +177,12 @@ typedef struct gj_step_io {
 int gj_transmission_update(const gj_plan* plan, const gj_agent_state* state,
                            const gj_step_params* params, void* stream);
 
+/* a2 alone: q_transmission[a] = (current_stage[a] < q_threshold) * transmission[a] for a
+ * transmission vector the caller filled itself (the contract of InfectionNetworks.forward,
+ * base.py:118-141, which reads data["agent"].transmission).  No-op when !has_quarantine.     */
+int gj_quarantine_transmission(const gj_plan* plan, const gj_agent_state* state,
+                               const gj_step_params* params, void* stream);
+
 /* a3 + a4 + a5 (pass 1): replaces, for every active network, the first
  * `self.propagate(edge_index, x=transmissions, y=beta*p_contact)` of InfectionNetwork.forward
  * (grad_june/infection_networks/base.py:61-79).  Fills plan->sets[s].cum.                   */
@@ -193,7 +199,8 @@ int gj_agent_gather(const gj_plan* plan, const gj_agent_state* state,
 
 /* a8 + a9 alone on a given probability vector: replaces IsInfectedSampler.forward +
  * infect_people for callers that hold `not_infected_probs` (e.g. infect_fraction_of_people,
- * grad_june/infection.py:31-42).                                                            */
+ * grad_june/infection.py:31-42).  The three state pointers may ALL be NULL: then only
+ * `new_infected` is produced (IsInfectedSampler.forward alone).                             */
 int gj_sample_infect(int64_t n_agents, const float* not_infected_probs, const float* exp_noise,
                      uint64_t seed, uint64_t step, int64_t agent_offset, float now,
                      float* new_infected, float* susceptibility, float* is_infected,

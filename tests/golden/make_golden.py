@@ -394,8 +394,8 @@ def make_june769(tag="june769", beta_shift=0.0, write_world=True):
     out = {}
     flat_world(world, out)
     with open(os.path.join(HERE, "default_params.json"), "w") as f:
-        json.dump(jsonable(default_params()), f, indent=1, sort_keys=True)
-    out["params_json"] = np.array(json.dumps(jsonable(params), sort_keys=True))
+        json.dump(jsonable(default_params()), f, indent=1)  # key order matters (age-bin parsing)
+    out["params_json"] = np.array(json.dumps(jsonable(params)))
     tabs = tables_of(runner.model)
     for n, t in tabs.items():
         out["table/" + n] = t.numpy()
