@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--agents", type=int, default=None)
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--infected", type=float, default=0.01)
+    ap.add_argument("--edge-mult", type=float, default=1.0, help="experiments: memberships per agent x this")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
     return ap.parse_args()
@@ -96,7 +97,12 @@ def cpu_baseline(world, networks, betas, tables, budget_s):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import gj_oracle as O
 
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU's job a 16-core CPU share; os.cpu_count() reports the whole host
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, int(os.environ.get("GJ_CPU_THREADS", "16"))))
     torch.set_num_threads(cores)
     w = {"n_agents": world["n_agents"], "age": torch.from_numpy(world["age"]), "sex": torch.from_numpy(world["sex"]),
          "edge_sets": {k: {kk: torch.from_numpy(vv) for kk, vv in v.items()} for k, v in world["edge_sets"].items()}}
@@ -158,7 +164,8 @@ def main():
     from grad_june_amd.synthetic import make_world, algorithmic_bytes, network_edges
 
     t0 = time.time()
-    world = make_world(args.preset, n_agents=args.agents, seed=args.seed, infected_fraction=args.infected)
+    world = make_world(args.preset, n_agents=args.agents, seed=args.seed, infected_fraction=args.infected,
+                       edge_mult=args.edge_mult)
     networks = world["networks"]
     betas = betas_of(world)
     specs = network_specs(world)

@@ -104,7 +104,7 @@ def _edge_set(rng, n_agents: int, n_edges: int, dist) -> dict:
 
 
 def make_world(preset: str = "c3", n_agents: Optional[int] = None, seed: int = 1234,
-               infected_fraction: float = 0.01, sets=None) -> Dict:
+               infected_fraction: float = 0.01, sets=None, edge_mult: float = 1.0) -> Dict:
     """Returns {"n_agents", "age", "sex", "edge_sets", "networks", "state"} as numpy arrays."""
     spec = PRESETS[preset]
     if n_agents is None:
@@ -122,7 +122,7 @@ def make_world(preset: str = "c3", n_agents: Optional[int] = None, seed: int = 1
     for name, (per_agent, dist) in spec.items():
         if sets is not None and name not in sets:
             continue
-        world["edge_sets"][name] = _edge_set(rng, A, int(round(per_agent * A)), dist)
+        world["edge_sets"][name] = _edge_set(rng, A, int(round(per_agent * edge_mult * A)), dist)
     inf = (rng.random(A) < infected_fraction).astype(np.float32)
     world["state"] = {
         "max_infectiousness": rng.lognormal(0.0, 0.5, A).astype(np.float32),
