@@ -1,0 +1,202 @@
+"""Experiment driver (reference grad_june/runner.py:15-242): builds model + world + timer from the
+YAML schema, seeds infections, runs the time loop and collects the result series.
+
+Same public surface as the reference's ``Runner``.  Per-step state lives on the HIP device; the
+hot path of each step is ``GradJune.hot_path`` (HIP kernels).  The per-step result reductions
+(cases, cases by age, deaths) are small device reductions written into preallocated series
+ instead of the reference's growing hstack/vstack chains.
+"""
+from __future__ import annotations
+
+import pickle
+from pathlib import Path
+
+import numpy as np
+import torch
+import yaml
+
+from .graph import HeteroData, ToUndirected, load_world
+from .infection import infect_fraction_of_people
+from .model import GradJune
+from .timer import Timer
+from .transmission import TransmissionSampler
+from .utils import read_path
+from .world import require_hip
+
+EDGE_SETS = ("household", "company", "school", "university", "care_home", "leisure")
+
+
+def world_from_npz(path) -> HeteroData:
+    """Neutral-array world (tests/golden/make_golden.py layout) -> the reference's graph format."""
+    with np.load(path, allow_pickle=False) as z:
+        arrays = {k: z[k] for k in z.files}
+    data = HeteroData()
+    ag = data["agent"]
+    n = int(arrays["n_agents"])
+    ag.id = torch.from_numpy(arrays.get("agent/id", np.arange(n)))
+    ag.age = torch.from_numpy(arrays["age"])
+    ag.sex = torch.from_numpy(arrays["sex"])
+    for key in ("ethnicity", "area"):
+        if "agent/" + key in arrays:
+            ag[key] = arrays["agent/" + key]
+    for s in EDGE_SETS:
+        if f"es/{s}/agent" not in arrays:
+            continue
+        data[s].id = torch.from_numpy(arrays.get(f"venue_id/{s}", np.arange(len(arrays[f"es/{s}/people"]))))
+        data[s].people = torch.from_numpy(arrays[f"es/{s}/people"])
+        data["agent", "attends_" + s, s].edge_index = torch.from_numpy(
+            np.vstack((arrays[f"es/{s}/agent"], arrays[f"es/{s}/venue"])))
+    return ToUndirected()(data)
+
+
+class Runner(torch.nn.Module):
+    def __init__(self, model, data, timer, log_fraction_initial_cases, save_path, parameters,
+                 age_bins=(0, 18, 65, 100)):
+        super().__init__()
+        self.model = model
+        self.data = data
+        self.data_backup = self.backup_infection_data(data)
+        self.timer = timer
+        self.log_fraction_initial_cases = log_fraction_initial_cases
+        self.device = model.device
+        self.age_bins = torch.tensor(age_bins, device=self.device)
+        eth = data["agent"].get("ethnicity", None)
+        self.ethnicities = np.sort(np.unique(eth)) if eth is not None else np.zeros(0)
+        self.n_agents = data["agent"].id.shape[0]
+        self.population_by_age = self.get_people_by_age()
+        self.save_path = Path(save_path)
+        self.input_parameters = parameters
+        self.restore_initial_data()
+
+    @classmethod
+    def from_file(cls, fpath=None):
+        if fpath is None:
+            from .defaults import default_parameters
+
+            return cls.from_parameters(default_parameters())
+        with open(fpath) as f:
+            return cls.from_parameters(yaml.safe_load(f))
+
+    @classmethod
+    def from_parameters(cls, params):
+        return cls(
+            model=GradJune.from_parameters(params),
+            data=cls.get_data(params),
+            timer=Timer.from_parameters(params),
+            log_fraction_initial_cases=params["infection_seed"]["log_fraction_initial_cases"],
+            save_path=params["save_path"],
+            parameters=params,
+            age_bins=params.get("age_bins_to_save", (0, 18, 65, 100)),
+        )
+
+    @staticmethod
+    def get_data(params):
+        device = require_hip(params["system"]["device"])
+        path = read_path(params["data_path"])
+        data = world_from_npz(path) if str(path).endswith(".npz") else load_world(path)
+        data = data.to(device)
+        n = len(data["agent"]["id"])
+        values = TransmissionSampler.from_parameters(params)(n)
+        ag = data["agent"]
+        ag.infection_parameters = {"max_infectiousness": values[0].contiguous(), "shape": values[1].contiguous(),
+                                   "rate": values[2].contiguous(), "shift": values[3].contiguous()}
+        ag.transmission = torch.zeros(n, device=device)
+        ag.susceptibility = torch.ones(n, device=device)
+        ag.is_infected = torch.zeros(n, device=device)
+        ag.infection_time = torch.zeros(n, device=device)
+        ag.symptoms = {"current_stage": torch.ones(n, dtype=torch.long, device=device),
+                       "next_stage": torch.ones(n, dtype=torch.long, device=device),
+                       "time_to_next_stage": torch.zeros(n, device=device)}
+        return data
+
+    # in-memory checkpoint of the mutable state ---------------------------------------------------
+    _STATE = ("susceptibility", "is_infected", "infection_time", "transmission")
+    _SYMPTOMS = ("current_stage", "next_stage", "time_to_next_stage")
+
+    def backup_infection_data(self, data):
+        ag = data["agent"]
+        ret = {k: ag[k].detach().clone() for k in self._STATE}
+        ret["symptoms"] = {k: ag["symptoms"][k].detach().clone() for k in self._SYMPTOMS}
+        return ret
+
+    def restore_initial_data(self):
+        ag = self.data["agent"]
+        for k in self._STATE:
+            ag[k] = self.data_backup[k].detach().clone()
+        for k in self._SYMPTOMS:
+            ag.symptoms[k] = self.data_backup["symptoms"][k].detach().clone()
+        self.data["results"] = {"deaths_per_timestep": None}
+
+    def set_initial_cases(self):
+        new_infected = infect_fraction_of_people(
+            data=self.data, timer=self.timer, symptoms_updater=self.model.symptoms_updater,
+            device=self.device, fraction=10.0 ** self.log_fraction_initial_cases)
+        self.model.symptoms_updater(data=self.data, timer=self.timer, new_infected=new_infected)
+
+    # time loop --------------------------------------------------------------------------------------
+    def forward(self):
+        timer, model, data = self.timer, self.model, self.data
+        timer.reset()
+        self.restore_initial_data()
+        self.set_initial_cases()
+        cases = [data["agent"].is_infected.sum()]
+        by_age = [self.get_cases_by_age(data)]
+        self.store_differentiable_deaths(data)
+        dates = [timer.date]
+        while timer.date < timer.final_date:
+            next(timer)
+            data = model(data, timer)
+            cases.append(data["agent"].is_infected.sum())
+            self.store_differentiable_deaths(data)
+            by_age.append(self.get_cases_by_age(data))
+            dates.append(timer.date)
+        cases_per_timestep = torch.stack(cases)
+        cases_by_age = torch.stack(by_age)
+        results = {
+            "dates": dates,
+            "cases_per_timestep": cases_per_timestep,
+            "daily_cases_per_timestep": torch.diff(cases_per_timestep,
+                                                   prepend=torch.tensor([0.0], device=self.device)),
+            "deaths_per_timestep": data.results["deaths_per_timestep"],
+        }
+        for i, key in enumerate(self.age_bins[1:]):
+            results[f"cases_by_age_{int(key):02d}"] = cases_by_age[:, i]
+        return results, data["agent"].is_infected
+
+    def save_results(self, results, is_infected):
+        import pandas as pd
+
+        self.save_path.mkdir(exist_ok=True, parents=True)
+        df = pd.DataFrame(index=results["dates"])
+        df.index.name = "date"
+        for key, series in results.items():
+            if key != "dates":
+                df[key] = series.detach().cpu().numpy()
+        df.to_csv(self.save_path / "results.csv")
+        pd.DataFrame({"is_infected": is_infected.detach().cpu().numpy()}).to_csv(
+            self.save_path / "results_is_infected.csv")
+
+    def store_differentiable_deaths(self, data):
+        stage = data["agent"].symptoms["current_stage"]
+        dead = int(self.model.symptoms_updater.stages_ids[-1])
+        deaths = ((stage == dead) * stage / dead).sum()
+        prev = data["results"]["deaths_per_timestep"]
+        data["results"]["deaths_per_timestep"] = deaths if prev is None else torch.hstack((prev, deaths))
+
+    def _age_masks(self, ages):
+        lo, hi = self.age_bins[:-1], self.age_bins[1:]
+        return (ages[None, :] > lo[:, None]) & (ages[None, :] < hi[:, None])     # [bins, A], open intervals
+
+    def get_cases_by_age(self, data):
+        return (self._age_masks(data["agent"].age) * data["agent"].is_infected[None, :]).sum(1)
+
+    def get_people_by_age(self):
+        counts = self._age_masks(self.data["agent"].age).sum(1)
+        return {int(self.age_bins[i + 1].item()): counts[i] for i in range(len(counts))}
+
+    def get_cases_by_ethnicity(self, data):
+        ret = torch.zeros(len(self.ethnicities), device=self.device)
+        for i, ethnicity in enumerate(self.ethnicities):
+            mask = torch.tensor(self.data["agent"].ethnicity == ethnicity, device=self.device)
+            ret[i] = (mask * data["agent"].is_infected).sum()
+        return ret

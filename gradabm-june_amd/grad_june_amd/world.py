@@ -69,9 +69,17 @@ def engine_for(data, specs: Sequence[NetworkSpec], device) -> InfectionEngine:
         if n.edge_set not in set_names:
             set_names.append(n.edge_set)
     sig = _signature(data, set_names, specs) + (str(device),)
-    hit = _CACHE.get(data)
-    if hit is not None and hit[0] == sig:
-        return hit[1]
+    per_data = _CACHE.get(data)
+    if per_data is None:
+        per_data = _CACHE[data] = {}
+    hit = per_data.get(sig)
+    if hit is not None:
+        return hit
+    if not specs:
+        # a launch that needs no edge set (transmission profile) can ride on any plan of this world
+        for other_sig, eng in per_data.items():
+            if other_sig[2] == sig[2] and other_sig[3] == sig[3]:
+                return eng
     sets = edge_sets_of(data, set_names)
     agent = data["agent"]
     n_agents = len(agent["id"])
@@ -83,7 +91,9 @@ def engine_for(data, specs: Sequence[NetworkSpec], device) -> InfectionEngine:
                         age=age, sex=sex)
     present = [n for n in specs if n.edge_set in host.set_index]
     engine = InfectionEngine(DevicePlan(host, present, device))
-    _CACHE[data] = (sig, engine)
+    if len(per_data) >= 4:          # worlds whose edges are rebuilt repeatedly: keep the cache small
+        per_data.pop(next(iter(per_data)))
+    per_data[sig] = engine
     return engine
 
 

@@ -1,0 +1,284 @@
+"""GPU: the reference-shaped Python API (InfectionNetworks / GradJune / Runner ...) running on the
+HIP kernels.  Each test restates a test of the reference's own suite (named in its docstring,
+paths relative to /root/reference/test/unit/) against this package."""
+import datetime
+
+import numpy as np
+import pytest
+import torch
+
+import gj_oracle as O
+import gj_testlib as L
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def G(device):
+    import grad_june_amd as g
+
+    return g
+
+
+def conftest_world(G, device, seed=999):
+    """The reference's 100-agent fixture graph (conftest.py:36-89): 4 schools x 25, 4 companies x 25,
+    25 households x 4, every 10th agent infected at t=0."""
+    torch.manual_seed(seed)
+    from grad_june_amd.defaults import default_parameters
+    from grad_june_amd.infection import infect_people_at_indices
+
+    n = 100
+    d = G.HeteroData()
+    ag = d["agent"]
+    ag.id = torch.arange(n)
+    ag.age = torch.randint(0, 100, (n,))
+    ag.sex = torch.randint(0, 2, (n,))
+    v = G.TransmissionSampler.from_parameters(default_parameters("cpu"))(n)
+    ag.infection_parameters = {"max_infectiousness": v[0], "shape": v[1], "rate": v[2], "shift": v[3]}
+    ag.transmission = torch.zeros(n)
+    ag.susceptibility = torch.ones(n)
+    ag.is_infected = torch.zeros(n)
+    ag.infection_time = torch.zeros(n)
+    ag.symptoms = {"current_stage": torch.ones(n, dtype=torch.long), "next_stage": torch.ones(n, dtype=torch.long),
+                   "time_to_next_stage": torch.zeros(n)}
+    for name, nv, per in (("school", 4, 25), ("company", 4, 25), ("household", 25, 4)):
+        d[name].id = torch.arange(nv)
+        d[name].people = per * torch.ones(nv)
+        d["agent", "attends_" + name, name].edge_index = torch.vstack(
+            (torch.arange(n), torch.tensor(np.repeat(np.arange(nv), per))))
+    d = G.ToUndirected()(d).to(device)
+    return infect_people_at_indices(d, list(range(0, 100, 10)), device=device)
+
+
+def day_timer(G, acts, weekend=None, day="2022-02-01"):
+    return G.Timer(initial_day=day, total_days=10, weekday_step_duration=(24,), weekend_step_duration=(24,),
+                   weekday_activities=(tuple(acts),), weekend_activities=(tuple(weekend or acts),))
+
+
+def nets_of(G, device, **log_betas):
+    from grad_june_amd import infection_networks as inw
+
+    cls = {"school": inw.SchoolNetwork, "company": inw.CompanyNetwork, "household": inw.HouseholdNetwork}
+    return G.InfectionNetworks(device=device, **{k: cls[k](log_beta=v, device=device) for k, v in log_betas.items()})
+
+
+def test_infection_passing_kat(G, device):
+    """infection_networks/test_base.py:16-44 (exact known answer)."""
+    d = G.HeteroData()
+    d["agent"].id = torch.arange(6)
+    d["agent"].transmission = torch.tensor([0.1, 0.2, 0.3, 0.4, 0.5, 0.6])
+    d["agent"].susceptibility = torch.tensor([1, 2, 3, 0.5, 0.7, 1.0])
+    d["school"].id = torch.arange(2)
+    d["school"].people = torch.tensor([2, 2])
+    d["agent", "attends_school", "school"].edge_index = torch.vstack((torch.arange(6), torch.tensor([0, 0, 0, 1, 1, 1])))
+    d = G.ToUndirected()(d).to(device)
+    nets = nets_of(G, device, school=np.log10(2.0))
+    p = nets(data=d, timer=day_timer(G, ["school"]), policies=G.Policies())
+    assert np.allclose(p.cpu().numpy(), np.exp(-np.array([1.2, 2.4, 3.6, 1.5, 2.1, 3])))
+    ts = nets["school"](data=d, timer=day_timer(G, ["school"]), policies=G.Policies())     # single-network term
+    assert np.allclose(ts.cpu().numpy(), [1.2, 2.4, 3.6, 1.5, 2.1, 3.0])
+
+
+def test_leisure_network_masks(G, device):
+    """infection_networks/test_leisure_network.py:41-77."""
+    from grad_june_amd.infection_networks import LeisureNetwork
+
+    d = G.HeteroData()
+    d["agent"].id = torch.arange(5)
+    d["agent"].age = torch.tensor([1, 60, 20, 30, 50])
+    d["agent"].sex = torch.tensor([0, 1, 1, 0, 0])
+    d["agent"].susceptibility = 0.5 * torch.ones(5)
+    d["agent"].transmission = 2.0 * torch.ones(5)
+    d["leisure"].id = torch.arange(3)
+    d["agent", "attends_leisure", "leisure"].edge_index = torch.tensor([[0, 1, 2], [0, 0, 0]])
+    d = G.ToUndirected()(d).to(device)
+    probs = {"weekday": {"male": {"0-50": 0.5, "50-100": 0.2}, "female": {"0-100": 0.5}},
+             "weekend": {"male": {"0-100": 1.0}, "female": {"0-100": 1.0}}}
+    ln = LeisureNetwork(log_beta=0.0, device=device, leisure_probabilities=probs)
+    ln.initialize_leisure_probabilities(d)
+    assert (ln.weekday_probabilities.cpu() == torch.tensor([0.5, 0.5, 0.5, 0.5, 0.2])).all()
+    assert (ln.weekend_probabilities.cpu() == torch.ones(5)).all()
+    assert (ln._get_edge_index(d) == d["agent", "attends_leisure", "leisure"].edge_index).all()
+    assert (ln._get_reverse_edge_index(d) == d["leisure", "rev_attends_leisure", "agent"].edge_index).all()
+    t = G.Timer(initial_day="2022-05-20")          # a Friday
+    pol = G.Policies()
+    assert (ln._get_susceptibilities(d, pol, t).cpu() == 0.5 * torch.tensor([0.5, 0.5, 0.5, 0.5, 0.2])).all()
+    next(t); next(t)                                # Saturday
+    assert (ln._get_transmissions(d, pol, t).cpu() == 2.0 * torch.ones(5)).all()
+
+
+def test_close_venue_integration(G, device):
+    """policies/test_close_venue_policies.py:46-69."""
+    from grad_june_amd.policies import CloseVenue
+
+    d = conftest_world(G, device)
+    d["agent"]["transmission"] = d["agent"]["transmission"] + 1.0
+    nets = nets_of(G, device, company=3.0)
+    t = day_timer(G, ["company"])
+    ret = nets(data=d, timer=t, policies=G.Policies.from_policy_list([]))
+    assert np.isclose(ret.sum().item(), 10.0)
+    pol = G.Policies.from_policy_list([CloseVenue(names=("company",), start_date="2022-02-01", end_date="2022-02-05")])
+    assert np.isclose(nets(data=d, timer=t, policies=pol).sum().item(), 100)
+
+
+def test_quarantine_integration(G, device):
+    """policies/test_quarantine_policies.py:40-72."""
+    from grad_june_amd.policies import Quarantine
+
+    d = conftest_world(G, device)
+    d["agent"]["transmission"] = d["agent"]["transmission"] + 1.0
+    d["agent"]["symptoms"]["current_stage"] = 5 * torch.ones(100, device=device)
+    nets = nets_of(G, device, company=3.0, household=3.0)
+    t = day_timer(G, ["company"], weekend=["company", "household"])
+    pol = G.Policies.from_policy_list([Quarantine(stage_threshold=3, start_date="2022-02-01", end_date="2022-03-15")])
+    assert np.isclose(nets(data=d, timer=t, policies=pol).sum().item(), 100)
+    while not t.is_weekend:
+        next(t)
+    assert np.isclose(nets(data=d, timer=t, policies=pol).sum().item(), 10.0)
+
+
+def test_social_distancing_integration(G, device):
+    """policies/test_interaction_policies.py:92-123: exact ratio of exposures under two factors."""
+    from grad_june_amd.policies import SocialDistancing
+
+    d = conftest_world(G, device)
+    d["agent"]["transmission"] = d["agent"]["transmission"] + 1.0
+    nets = nets_of(G, device, school=2.0, company=0.0)
+    t = day_timer(G, ["company"])
+    out = []
+    for f in ({"school": 0.3, "company": 0.5}, {"school": 0.6, "company": 0.2}):
+        pol = G.Policies.from_policy_list([SocialDistancing(start_date="2022-02-01", end_date="2022-02-05", beta_factors=f)])
+        ts = -torch.log(nets(data=d, timer=t, policies=pol)) * t.duration
+        out.append(ts.cpu())
+    keep = out[0] > 5e-6
+    assert np.allclose((out[1][keep] / out[0][keep]).numpy(), 0.2 / 0.5)
+
+
+def test_model_step_and_new_case_stage(G, device):
+    """test_model.py:25-33 and :169-185: a step at t=3 infects people; new cases are 'exposed' (2)."""
+    d = conftest_world(G, device)
+    model = G.GradJune(infection_networks=nets_of(G, device, company=0.5, household=0.5, school=0.5),
+                       policies=G.Policies.from_policy_list([]), device=device)
+    t = G.Timer(initial_day="2022-02-01", total_days=10, weekday_step_duration=(8, 8, 8), weekend_step_duration=(12, 12),
+                weekday_activities=(("company", "school", "household"), ("household",), ("household",)),
+                weekend_activities=(("household",), ("household",)))
+    while t.now < 3:
+        next(t)
+    before = d["agent"].is_infected.clone()
+    with torch.no_grad():
+        res = model(timer=t, data=d)
+    assert res["agent"]["is_infected"].sum() > 10 and res["agent"]["susceptibility"].sum() < 90
+    new = (res["agent"].is_infected - before) > 0.5
+    assert (res["agent"].symptoms["current_stage"][new & (before < 0.5)] == 2).all()
+    assert (res["agent"].infection_time[new & (before < 0.5)] == t.now).all()
+
+
+def test_model_matches_oracle_with_injected_noise(G, device):
+    """GradJune.hot_path through the API == CPU oracle on the same noise (probabilities 1e-5, decisions equal)."""
+    d = conftest_world(G, device)
+    model = G.GradJune(infection_networks=nets_of(G, device, company=0.5, household=0.3, school=0.4),
+                       policies=G.Policies.from_policy_list([]), device=device)
+    t = day_timer(G, ["company", "school", "household"])
+    for _ in range(3):
+        next(t)
+    ag = d["agent"]
+    world = {"n_agents": 100, "age": ag.age.cpu(), "sex": ag.sex.cpu(), "edge_sets": {
+        s: {"agent": d["attends_" + s].edge_index[0].cpu(), "venue": d["attends_" + s].edge_index[1].cpu(),
+            "people": d[s].people.cpu()} for s in ("school", "company", "household")}}
+    st = {k: ag["infection_parameters"][k].cpu() for k in ("max_infectiousness", "shape", "rate", "shift")}
+    st.update({k: ag[k].cpu().clone() for k in ("infection_time", "is_infected", "susceptibility")})
+    st["current_stage"] = ag.symptoms["current_stage"].cpu()
+    noise = O.draw_exp_noise(100)
+    betas = {n.name: n.beta_value(model.policies, t) for n in model.infection_networks.networks.values()}
+    ref = O.hot_path_step(world, st, now=t.now, delta_time=t.duration, day_type=0, active=list(betas), betas=betas,
+                          quarantine_thresholds=[], exp_noise=noise)
+    with torch.no_grad():
+        new, probs = model.hot_path(d, t, exp_noise=noise, want_probs=True)
+    assert np.abs(probs.cpu().numpy() - ref["not_infected_probs"].numpy()).max() <= 1e-5
+    assert np.array_equal(new.cpu().numpy() > 0.5, ref["new_infected"].numpy() > 0.5)
+    assert np.array_equal(ag.is_infected.cpu().numpy(), ref["is_infected"].numpy())
+    assert np.allclose(ag.transmission.cpu().numpy(), ref["transmission"].numpy(), rtol=2e-5, atol=1e-9)
+
+
+def test_transmission_updater_and_sampler(G, device):
+    """test_transmission.py:9-33."""
+    from grad_june_amd.defaults import default_parameters
+
+    torch.manual_seed(999)
+    s = G.TransmissionSampler.from_parameters(default_parameters("cpu"))(20000)
+    assert np.allclose(s.mean(1).numpy(), [1.1331, 1.56, 0.53, -2.12], rtol=2e-2)
+    d = conftest_world(G, device)
+    t = day_timer(G, ["household"])
+    for _ in range(5):
+        next(t)
+    tr = G.TransmissionUpdater()(data=d, timer=t).cpu()
+    assert (tr[::10] > 0).all() and tr.sum() == tr[::10].sum()
+    d["agent"].is_infected = torch.zeros(100, device=device)
+    assert G.TransmissionUpdater()(data=d, timer=t).sum() == 0
+
+
+def test_is_infected_sampler_statistics(G, device):
+    """infection_networks/test_is_infected_sampler.py:7-24 (mean of 2000 draws ~ 1-p, rtol 0.1)."""
+    sampler = G.IsInfectedSampler()
+    p = torch.tensor([0.2, 0.5, 0.7, 0.3], device=device).repeat(500)       # 2000 draws of each in one launch
+    x = sampler(p).cpu().view(500, 4)
+    assert set(np.unique(x.numpy()).tolist()) <= {0.0, 1.0}
+    assert np.allclose(x.mean(0).numpy(), [0.8, 0.5, 0.3, 0.7], rtol=0.1)
+    noise = O.draw_exp_noise(2000)
+    assert torch.equal(sampler(p, exp_noise=noise).cpu() > 0.5, O.sample_infected(p.cpu(), noise) > 0.5)
+
+
+def test_gradient_request_fails_loudly(G, device):
+    d = conftest_world(G, device)
+    nets = nets_of(G, device, company=torch.nn.Parameter(torch.tensor(0.5)))
+    with pytest.raises(NotImplementedError, match="forward-only"):
+        nets(data=d, timer=day_timer(G, ["company"]), policies=G.Policies())
+
+
+def params_on(device, days=15):
+    from grad_june_amd.defaults import default_parameters
+
+    p = default_parameters(str(device))
+    p["timer"]["total_days"] = days
+    return p
+
+
+def test_runner_records_and_csv(G, device, tmp_path):
+    """test_runner.py:25-90: 16 records for 15 days, result keys, CSV round trip."""
+    import pandas as pd
+
+    p = params_on(device)
+    p["save_path"] = str(tmp_path / "out")
+    torch.manual_seed(769)
+    runner = G.Runner.from_parameters(p)
+    assert runner.n_agents == 769
+    with torch.no_grad():
+        runner.set_initial_cases()
+        assert np.isclose(runner.data["agent"].is_infected.sum().item(), 0.10 * 769, rtol=3e-1)
+        results, is_inf = runner()
+    assert len(results["dates"]) == 16 and results["dates"][0] == datetime.datetime(2022, 2, 1)
+    for key in ("cases_per_timestep", "daily_cases_per_timestep", "deaths_per_timestep", "cases_by_age_18",
+                "cases_by_age_65", "cases_by_age_100"):
+        assert results[key].shape[0] == 16, key
+    c = results["cases_per_timestep"].cpu().numpy()
+    assert (np.diff(c) >= 0).all() and c[-1] >= c[0] > 0
+    assert is_inf.shape[0] == 769
+    runner.save_results(results, is_inf)
+    df = pd.read_csv(tmp_path / "out" / "results.csv", index_col=0)
+    assert len(df) == 16 and np.allclose(df["cases_per_timestep"].values, c)
+    assert len(pd.read_csv(tmp_path / "out" / "results_is_infected.csv")) == 769
+    # restore_initial_data: everyone back to susceptible
+    runner.restore_initial_data()
+    assert runner.data["agent"].symptoms["current_stage"].sum().item() == 769
+
+
+def test_config1_plumbing_30_timesteps(G, device):
+    """BASELINE.json configs[0]: the shipped 769-agent world (the London blob is absent), default
+    parameters, 30 timesteps through Runner - every step on the HIP path."""
+    torch.manual_seed(1)
+    runner = G.Runner.from_parameters(params_on(device, days=30))
+    with torch.no_grad():
+        results, _ = runner()
+    assert len(results["dates"]) == 31
+    assert runner.model.n_steps == 30
+    assert torch.isfinite(results["cases_per_timestep"]).all()
