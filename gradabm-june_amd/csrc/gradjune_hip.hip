@@ -468,10 +468,12 @@ static int group_networks(const gj_plan* plan, const gj_step_params* p, Groups* 
   return GJ_OK;
 }
 
-static int check_state(const gj_plan* plan, const gj_agent_state* st, const gj_step_params* p) {
+// full: the launch reads/writes is_infected and infection_time too (a1, a9)
+static int check_state(const gj_plan* plan, const gj_agent_state* st, const gj_step_params* p, bool full = true) {
   if (!st) return GJ_E_NULL;
   if (plan->n_agents == 0) return GJ_OK;
-  if (!st->transmission || !st->susceptibility || !st->is_infected || !st->infection_time) return GJ_E_NULL;
+  if (!st->transmission || !st->susceptibility) return GJ_E_NULL;
+  if (full && (!st->is_infected || !st->infection_time)) return GJ_E_NULL;
   if (p->has_quarantine && (!st->current_stage || !st->q_transmission)) return GJ_E_NULL;
   return GJ_OK;
 }
@@ -638,7 +640,7 @@ int gj_quarantine_transmission(const gj_plan* plan, const gj_agent_state* state,
   int rc = gj::check_plan(plan);
   if (rc) return rc;
   if (!params) return GJ_E_NULL;
-  rc = gj::check_state(plan, state, params);
+  rc = gj::check_state(plan, state, params, false);
   if (rc) return rc;
   if (!params->has_quarantine || plan->n_agents == 0) return GJ_OK;
   const int64_t n = plan->n_agents;
@@ -654,7 +656,7 @@ int gj_venue_reduce(const gj_plan* plan, const gj_agent_state* state, const gj_s
   gj::Groups G;
   rc = gj::group_networks(plan, params, &G);
   if (rc) return rc;
-  rc = gj::check_state(plan, state, params);
+  rc = gj::check_state(plan, state, params, false);
   if (rc) return rc;
   return gj::do_venue_reduce(plan, state, params, G, (hipStream_t)stream);
 }
@@ -666,7 +668,7 @@ int gj_agent_gather(const gj_plan* plan, const gj_agent_state* state, const gj_s
   gj::Groups G;
   rc = gj::group_networks(plan, params, &G);
   if (rc) return rc;
-  rc = gj::check_state(plan, state, params);
+  rc = gj::check_state(plan, state, params, sample != 0);
   if (rc) return rc;
   return gj::do_agent_gather(plan, state, params, G, io, sample, (hipStream_t)stream);
 }

@@ -23,7 +23,7 @@ class AgentBuffers:
             "susceptibility", "transmission")
 
     def __init__(self, plan: DevicePlan, *, max_infectiousness=None, shape=None, rate=None, shift=None,
-                 infection_time, is_infected, susceptibility, transmission, q_transmission=None,
+                 infection_time=None, is_infected=None, susceptibility, transmission, q_transmission=None,
                  current_stage=None):
         n, n_ext = plan.host.n_agents, plan.host.n_ext_agents
         self.tensors = dict(max_infectiousness=max_infectiousness, shape=shape, rate=rate, shift=shift,

@@ -230,7 +230,7 @@ def _run_networks(active_networks, data, timer, policies, device, want="probs", 
     if hasattr(policies, "apply"):
         policies.apply(timer=timer, data=data)
     engine, params, has_q = _step_inputs(active_networks, all_networks or active_networks, data, timer, policies, device)
-    bufs = agent_buffers(engine, data, need_params=False, need_stage=has_q)
+    bufs = agent_buffers(engine, data, need_params=False, need_stage=has_q, need_infection_state=False)
     n = engine.plan.host.n_agents
     out = torch.empty(n, dtype=torch.float32, device=device)
     # q*transmission is normally produced by the transmission kernel; callers of this entry set

@@ -110,7 +110,8 @@ def _f32(store, key, device, n):
     return t
 
 
-def agent_buffers(engine: InfectionEngine, data, *, need_params: bool, need_stage: bool) -> AgentBuffers:
+def agent_buffers(engine: InfectionEngine, data, *, need_params: bool, need_stage: bool,
+                  need_infection_state: bool = True) -> AgentBuffers:
     """Device views of ``data['agent']`` for one launch.  State tensors are used IN PLACE."""
     dev = engine.plan.device
     ag = data["agent"]
@@ -121,7 +122,10 @@ def agent_buffers(engine: InfectionEngine, data, *, need_params: bool, need_stag
         for k in ("max_infectiousness", "shape", "rate", "shift"):
             kw[k] = _f32(ip, k, dev, n)
     for k in ("infection_time", "is_infected", "susceptibility"):
-        kw[k] = _f32(ag, k, dev, n)
+        if need_infection_state or k == "susceptibility":
+            kw[k] = _f32(ag, k, dev, n)
+        else:
+            kw[k] = None
     if "transmission" not in ag:
         ag["transmission"] = torch.zeros(n, dtype=torch.float32, device=dev)
     kw["transmission"] = _f32(ag, "transmission", dev, n)
