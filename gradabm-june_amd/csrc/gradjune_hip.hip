@@ -16,6 +16,7 @@
 
 #include "../../include/gradjune_hip.h"
 #include "gj_device.h"
+#include "gj_tiled.h"
 
 namespace gj {
 
@@ -411,6 +412,8 @@ static inline int launch_status() {
   return e == hipSuccess ? GJ_OK : (int)e;
 }
 
+static int check_tiled(const gj_plan* plan);
+
 static int check_plan(const gj_plan* plan) {
   if (!plan) return GJ_E_NULL;
   if (plan->n_agents < 0 || plan->n_ext_agents < plan->n_agents) return GJ_E_RANGE;
@@ -420,10 +423,13 @@ static int check_plan(const gj_plan* plan) {
     const gj_edge_set& S = plan->sets[s];
     if (S.n_edges < 0 || S.n_edges > INT32_MAX || S.n_venues < 0 || S.n_venues > INT32_MAX) return GJ_E_RANGE;
     if (S.cum_stride < 1 || S.cum_stride > GJ_MAX_NETS_PER_SET) return GJ_E_PLAN;
-    if (!S.v_rowptr || !S.a_rowptr || !S.v_pcontact) return GJ_E_NULL;
-    if (S.n_edges > 0 && (!S.v_agent || !S.a_venue)) return GJ_E_NULL;
+    if (!S.v_pcontact && S.n_venues > 0) return GJ_E_NULL;
     if (S.n_venues > 0 && !S.cum) return GJ_E_NULL;
+    if (plan->tiled) continue;
+    if (!S.v_rowptr || !S.a_rowptr) return GJ_E_NULL;
+    if (S.n_edges > 0 && (!S.v_agent || !S.a_venue)) return GJ_E_NULL;
   }
+  if (plan->tiled) return check_tiled(plan);
   if (plan->n_blocks < 0 || (plan->n_blocks > 0 && !plan->blocks)) return GJ_E_PLAN;
   if (plan->n_long_rows < 0 || (plan->n_long_rows > 0 && (!plan->long_rows || !plan->partial))) return GJ_E_PLAN;
   return GJ_OK;
@@ -603,7 +609,153 @@ static int do_agent_gather(const gj_plan* plan, const gj_agent_state* st, const 
   return launch_status();
 }
 
+// ------------------------------------------------------------------------------------------
+// tiled layout: host side
+// ------------------------------------------------------------------------------------------
+static int check_tiled(const gj_plan* plan) {
+  const gj_tiled* T = plan->tiled;
+  if (T->n_slices < 1 || T->slice_agents < 64 || T->slice_agents % 64 || T->slice_agents > 40448) return GJ_E_PLAN;
+  if ((int64_t)T->n_slices * T->slice_agents < plan->n_agents) return GJ_E_PLAN;
+  if (plan->n_ext_agents != plan->n_agents) return GJ_E_PLAN;   // no halo agents in the tiled layout
+  if (T->n_work < 0 || (T->n_work > 0 && !T->work)) return GJ_E_PLAN;
+  for (int s = 0; s < plan->n_sets; ++s) {
+    const gj_tiled_set& S = T->sets[s];
+    if (S.n_blocks < 0) return GJ_E_PLAN;
+    if (S.n_blocks == 0) continue;
+    if (!S.blk_v0 || !S.blk_e0 || !S.tile_sptr || !S.tile_jpos) return GJ_E_NULL;
+    if (plan->sets[s].n_edges > 0 && (!S.e_lv || !S.a_la || !S.val)) return GJ_E_NULL;
+    if (S.max_block_venues < 1 || S.max_block_venues > 65536) return GJ_E_PLAN;
+  }
+  return GJ_OK;
+}
+
+template <typename K>
+static int allow_lds(K kernel, size_t bytes) {
+  if (bytes > 160 * 1024) return GJ_E_PLAN;
+  if (bytes > 64 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return (int)e;
+  }
+  return GJ_OK;
+}
+
+static void fill_set_a(const gj_plan* plan, const gj_step_params* p, const Groups& G, TSetA* sets) {
+  const gj_tiled* T = plan->tiled;
+  for (int s = 0; s < GJ_MAX_SETS; ++s) sets[s] = TSetA{};
+  for (int g = 0; g < G.n; ++g) {
+    const int s = G.set[g];
+    const gj_tiled_set& S = T->sets[s];
+    sets[s].a_la = S.a_la;
+    sets[s].tile_sptr = S.tile_sptr;
+    sets[s].tile_jpos = S.tile_jpos;
+    sets[s].val = S.val;
+    sets[s].J = S.n_blocks;
+    sets[s].active = (S.n_blocks > 0 && plan->sets[s].n_edges > 0) ? G.nk[g] : 0;
+    sets[s].raw = p->nets[G.first[g]].mask_kind == GJ_MASK_RAW;
+  }
+}
+
+static int tiled_scatter(const gj_plan* plan, const gj_agent_state* st, const gj_step_params* p, const Groups& G,
+                         hipStream_t stream) {
+  const gj_tiled* T = plan->tiled;
+  if (plan->n_agents == 0 || G.n == 0) return GJ_OK;
+  TileAArgs A;
+  fill_set_a(plan, p, G, A.sets);
+  A.n_sets = plan->n_sets;
+  A.slice_agents = T->slice_agents;
+  A.n_agents = plan->n_agents;
+  A.trans = st->transmission;
+  A.qtrans = p->has_quarantine ? st->q_transmission : st->transmission;
+  const size_t lds = (size_t)T->slice_agents * sizeof(float);
+  int rc = allow_lds(k_tile_scatter, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)T->n_slices), dim3(kTileThreads), lds, stream, A);
+  return launch_status();
+}
+
+static int tiled_venues(const gj_plan* plan, const gj_step_params* p, const Groups& G, int mode, hipStream_t stream) {
+  const gj_tiled* T = plan->tiled;
+  if (T->n_work == 0 || G.n == 0) return GJ_OK;
+  TileBArgs B;
+  for (int s = 0; s < GJ_MAX_SETS; ++s) B.sets[s] = TSetB{};
+  size_t lds = 16;
+  for (int g = 0; g < G.n; ++g) {
+    const int s = G.set[g];
+    const gj_tiled_set& S = T->sets[s];
+    const gj_edge_set& E = plan->sets[s];
+    TSetB& X = B.sets[s];
+    X.blk_v0 = S.blk_v0;
+    X.blk_e0 = S.blk_e0;
+    X.e_lv = S.e_lv;
+    X.e_cls = S.e_cls;
+    X.val = S.val;
+    X.v_pc = E.v_pcontact;
+    X.cum = E.cum;
+    X.stride = E.cum_stride;
+    X.nk = S.n_blocks > 0 ? G.nk[g] : 0;
+    X.leisure = 0;
+    for (int k = 0; k < G.nk[g]; ++k) {
+      const gj_network& N = p->nets[G.first[g] + k];
+      X.beta[k] = N.beta;
+      X.table[k] = N.mask_kind >= GJ_MASK_QL ? N.table : -1;
+      X.age75[k] = N.mask_kind == GJ_MASK_QL_AGE75;
+      if (N.mask_kind >= GJ_MASK_QL) X.leisure = 1;
+    }
+    if (X.leisure) {
+      if (!S.e_cls && E.n_edges > 0) return GJ_E_PLAN;
+      for (int k = 0; k < G.nk[g]; ++k)
+        if (X.table[k] < 0) return GJ_E_PLAN;
+    } else if (G.nk[g] != 1) {
+      return GJ_E_PLAN;   // several networks on one set need per-network tables
+    }
+    const size_t need = ((size_t)X.nk * S.max_block_venues + (X.leisure ? 2 * 200 * (size_t)X.nk : 0)) * sizeof(float);
+    if (X.nk && need > lds) lds = need;
+  }
+  B.work = T->work;
+  B.tables = plan->tables;
+  B.day_type = p->day_type;
+  B.mode = mode;
+  int rc = allow_lds(k_tile_venues, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_tile_venues, dim3((unsigned)T->n_work), dim3(kTileThreads), lds, stream, B);
+  return launch_status();
+}
+
+static int tiled_agents(const gj_plan* plan, const gj_agent_state* st, const gj_step_params* p, const Groups& G,
+                        const gj_step_io* io, int sample, hipStream_t stream) {
+  const gj_tiled* T = plan->tiled;
+  if (plan->n_agents == 0) return GJ_OK;
+  TileDArgs D;
+  fill_set_a(plan, p, G, D.sets);
+  D.n_sets = plan->n_sets;
+  D.slice_agents = T->slice_agents;
+  D.n_agents = plan->n_agents;
+  D.stage = st->current_stage;
+  D.susceptibility = st->susceptibility;
+  D.is_infected = st->is_infected;
+  D.infection_time = st->infection_time;
+  D.not_infected_probs = io ? io->not_infected_probs : nullptr;
+  D.new_infected = io ? io->new_infected : nullptr;
+  D.trans_susc = io ? io->trans_susc : nullptr;
+  D.exp_noise = io ? io->exp_noise : nullptr;
+  D.now = p->now;
+  D.dt = p->delta_time;
+  D.q_thr = p->q_threshold;
+  D.has_q = p->has_quarantine;
+  D.sample = sample;
+  D.seed = p->seed;
+  D.step = p->step;
+  D.agent_offset = p->agent_offset;
+  const size_t lds = (size_t)T->slice_agents * sizeof(float);
+  int rc = allow_lds(k_tile_agents, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_tile_agents, dim3((unsigned)T->n_slices), dim3(kTileThreads), lds, stream, D);
+  return launch_status();
+}
+
 }  // namespace gj
+
 
 // ------------------------------------------------------------------------------------------
 // C ABI
@@ -658,6 +810,11 @@ int gj_venue_reduce(const gj_plan* plan, const gj_agent_state* state, const gj_s
   if (rc) return rc;
   rc = gj::check_state(plan, state, params, false);
   if (rc) return rc;
+  if (plan->tiled) {
+    rc = gj::tiled_scatter(plan, state, params, G, (hipStream_t)stream);
+    if (rc) return rc;
+    return gj::tiled_venues(plan, params, G, 1, (hipStream_t)stream);
+  }
   return gj::do_venue_reduce(plan, state, params, G, (hipStream_t)stream);
 }
 
@@ -670,6 +827,11 @@ int gj_agent_gather(const gj_plan* plan, const gj_agent_state* state, const gj_s
   if (rc) return rc;
   rc = gj::check_state(plan, state, params, sample != 0);
   if (rc) return rc;
+  if (plan->tiled) {
+    rc = gj::tiled_venues(plan, params, G, 2, (hipStream_t)stream);
+    if (rc) return rc;
+    return gj::tiled_agents(plan, state, params, G, io, sample, (hipStream_t)stream);
+  }
   return gj::do_agent_gather(plan, state, params, G, io, sample, (hipStream_t)stream);
 }
 
@@ -700,6 +862,13 @@ int gj_step(const gj_plan* plan, const gj_agent_state* state, const gj_step_para
   if (rc) return rc;
   rc = gj::do_transmission(plan, state, params, (hipStream_t)stream);
   if (rc) return rc;
+  if (plan->tiled) {
+    rc = gj::tiled_scatter(plan, state, params, G, (hipStream_t)stream);
+    if (rc) return rc;
+    rc = gj::tiled_venues(plan, params, G, 0, (hipStream_t)stream);
+    if (rc) return rc;
+    return gj::tiled_agents(plan, state, params, G, io, 1, (hipStream_t)stream);
+  }
   rc = gj::do_venue_reduce(plan, state, params, G, (hipStream_t)stream);
   if (rc) return rc;
   return gj::do_agent_gather(plan, state, params, G, io, 1, (hipStream_t)stream);

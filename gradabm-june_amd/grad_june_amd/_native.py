@@ -40,6 +40,32 @@ class EdgeSet(C.Structure):
     ]
 
 
+class TiledSet(C.Structure):
+    _fields_ = [
+        ("n_blocks", C.c_int32),
+        ("max_block_venues", C.c_int32),
+        ("blk_v0", _vp),
+        ("blk_e0", _vp),
+        ("e_lv", _vp),
+        ("e_cls", _vp),
+        ("a_la", _vp),
+        ("tile_sptr", _vp),
+        ("tile_jpos", _vp),
+        ("val", _vp),
+    ]
+
+
+class Tiled(C.Structure):
+    _fields_ = [
+        ("n_slices", C.c_int32),
+        ("slice_agents", C.c_int32),
+        ("_pad", C.c_int32),
+        ("n_work", C.c_int32),
+        ("work", _vp),
+        ("sets", TiledSet * GJ_MAX_SETS),
+    ]
+
+
 class Plan(C.Structure):
     _fields_ = [
         ("n_agents", C.c_int64),
@@ -56,6 +82,7 @@ class Plan(C.Structure):
         ("tables", _vp),
         ("n_tables", C.c_int32),
         ("_pad", C.c_int32),
+        ("tiled", C.POINTER(Tiled)),
     ]
 
 

@@ -29,6 +29,7 @@ import numpy as np
 import torch
 
 from . import _native as N
+from . import tiling as TL
 
 LONG_CHUNK = 8192        # edges per workgroup for venues above the stream capacity
 MAX_ROWS_PER_BLOCK = 2048
@@ -39,11 +40,12 @@ class HostEdgeSet:
     name: str
     n_venues: int
     n_edges: int
-    v_rowptr: np.ndarray   # int32 [V+1]
-    v_agent: np.ndarray    # int32 [E]
-    v_pcontact: np.ndarray  # float32 [V]
-    a_rowptr: np.ndarray   # int32 [A+1]
-    a_venue: np.ndarray    # int32 [E]
+    v_rowptr: Optional[np.ndarray]   # int32 [V+1]   (None in a tiled-only plan)
+    v_agent: Optional[np.ndarray]    # int32 [E]
+    v_pcontact: np.ndarray           # float32 [V]
+    a_rowptr: Optional[np.ndarray]   # int32 [A+1]
+    a_venue: Optional[np.ndarray]    # int32 [E]
+    tiled: Optional[TL.TiledEdgeSet] = None
 
 
 def p_contact(people) -> np.ndarray:
@@ -64,7 +66,7 @@ def _csr(rows: np.ndarray, cols: np.ndarray, n_rows: int):
 
 
 def compile_edge_set(name: str, agent_index, venue_index, people, n_agents: int,
-                     n_ext_agents: Optional[int] = None) -> HostEdgeSet:
+                     n_ext_agents: Optional[int] = None, csr: bool = True) -> HostEdgeSet:
     """COO -> two CSR views.  ``agent_index`` may reference halo agents in [n_agents, n_ext)."""
     agent_index = np.asarray(agent_index).astype(np.int64, copy=False).ravel()
     venue_index = np.asarray(venue_index).astype(np.int64, copy=False).ravel()
@@ -78,6 +80,8 @@ def compile_edge_set(name: str, agent_index, venue_index, people, n_agents: int,
             raise ValueError(f"{name}: agent index out of range")
         if venue_index.min() < 0 or venue_index.max() >= n_venues:
             raise ValueError(f"{name}: venue index out of range")
+    if not csr:
+        return HostEdgeSet(name, n_venues, E, None, None, p_contact(people), None, None)
     v_rowptr, v_agent = _csr(venue_index, agent_index, n_venues)
     owned = agent_index < n_agents
     a_rowptr, a_venue = _csr(agent_index[owned], venue_index[owned], n_agents)
@@ -151,6 +155,10 @@ class HostPlan:
     long_rows: np.ndarray                # int32 [nl, 4]
     n_partial_slots: int
     set_index: Dict[str, int] = field(default_factory=dict)
+    layout: str = "csr"
+    n_slices: int = 0
+    slice_agents: int = 0
+    work: Optional[np.ndarray] = None    # int32 [n_work, 2] (set, block), heaviest first (tiled)
 
     @property
     def n_edges(self) -> int:
@@ -166,16 +174,37 @@ def agent_class_of(age, sex) -> np.ndarray:
 
 
 def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
-                 n_ext_agents: Optional[int] = None, block_order: str = "interleave") -> HostPlan:
-    """edge_sets: {name: {"agent": i64[E], "venue": i64[E], "people": [V]}} (insertion order = set ids)."""
+                 n_ext_agents: Optional[int] = None, block_order: str = "interleave",
+                 layout: str = "csr", leisure_sets: Sequence[str] = ("leisure",),
+                 sv_max: int = TL.SV_MAX, eb_target: int = TL.EB_TARGET, slices=None) -> HostPlan:
+    """edge_sets: {name: {"agent": i64[E], "venue": i64[E], "people": [V]}} (insertion order = set ids).
+
+    layout: "csr" (deterministic CSR kernels), "tiled" (LDS-tiled fast path) or "both".
+    """
     if len(edge_sets) > N.GJ_MAX_SETS:
         raise ValueError(f"at most {N.GJ_MAX_SETS} edge sets")
+    if layout not in ("csr", "tiled", "both"):
+        raise ValueError(layout)
     n_ext = n_agents if n_ext_agents is None else n_ext_agents
-    sets, all_blocks, all_long = [], [], []
+    want_csr, want_tiled = layout in ("csr", "both"), layout in ("tiled", "both")
+    if want_tiled and n_ext != n_agents:
+        raise ValueError("the tiled layout has no halo agents")
+    cls_all = None if age is None else agent_class_of(age, sex)
+    S, SA = slices if slices is not None else TL.choose_slices(n_agents)
+    sets, all_blocks, all_long, work = [], [], [], []
     slot = 0
     for sid, (name, es) in enumerate(edge_sets.items()):
-        hs = compile_edge_set(name, es["agent"], es["venue"], es["people"], n_agents, n_ext)
+        hs = compile_edge_set(name, es["agent"], es["venue"], es["people"], n_agents, n_ext, csr=want_csr)
         sets.append(hs)
+        if want_tiled:
+            hs.tiled = TL.build_tiled(name, es["agent"], es["venue"], hs.n_venues, hs.v_pcontact, S, SA,
+                                      agent_class=cls_all if (name in leisure_sets and cls_all is not None) else None,
+                                      sv_max=sv_max, eb_target=eb_target)
+            t = hs.tiled
+            for j in range(t.n_blocks):
+                work.append((int(t.blk_e0[j + 1] - t.blk_e0[j]) + int(t.blk_v0[j + 1] - t.blk_v0[j]), sid, j))
+        if not want_csr:
+            continue
         b, lr, ns = build_schedule(hs.v_rowptr, sid, slot)
         slot += ns
         all_blocks.append(b)
@@ -189,11 +218,15 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
     if age is None:
         cls = np.zeros(n_ext, dtype=np.uint8)
     else:
-        cls = agent_class_of(age, sex)
+        cls = cls_all
         if len(cls) != n_ext:
             raise ValueError("age/sex must cover owned + halo agents")
+    work.sort(key=lambda w: -w[0])
+    work_arr = np.array([(w[1], w[2]) for w in work], dtype=np.int32).reshape(-1, 2)
     return HostPlan(n_agents, n_ext, sets, cls, np.ascontiguousarray(blocks), long_rows, slot,
-                    {s.name: i for i, s in enumerate(sets)})
+                    {s.name: i for i, s in enumerate(sets)}, layout=layout,
+                    n_slices=S if want_tiled else 0, slice_agents=SA if want_tiled else 0,
+                    work=work_arr if want_tiled else None)
 
 
 class DevicePlan:
@@ -229,6 +262,7 @@ class DevicePlan:
             per_set_nets[n.edge_set] = per_set_nets.get(n.edge_set, 0) + 1
         self.keep = []
         self.cum: List[torch.Tensor] = []
+        self.tiled_c = None
         plan = N.Plan()
         plan.n_agents = host.n_agents
         plan.n_ext_agents = host.n_ext_agents
@@ -237,16 +271,37 @@ class DevicePlan:
             stride = max(1, per_set_nets.get(s.name, 1))
             if stride > N.GJ_MAX_NETS_PER_SET:
                 raise ValueError(f"edge set {s.name}: more than {N.GJ_MAX_NETS_PER_SET} networks")
-            t = dict(v_rowptr=up(s.v_rowptr), v_agent=up(s.v_agent), v_pc=up(s.v_pcontact),
-                     a_rowptr=up(s.a_rowptr), a_venue=up(s.a_venue))
+            t = dict(v_pc=up(s.v_pcontact))
+            if s.v_rowptr is not None:
+                t.update(v_rowptr=up(s.v_rowptr), v_agent=up(s.v_agent), a_rowptr=up(s.a_rowptr), a_venue=up(s.a_venue))
             cum = torch.zeros(max(1, s.n_venues) * stride, dtype=torch.float32, device=dev)
-            self.keep.append(t)
-            self.cum.append(cum)
             e = plan.sets[i]
             e.n_venues, e.n_edges = s.n_venues, s.n_edges
-            e.v_rowptr, e.v_agent, e.v_pcontact = t["v_rowptr"].data_ptr(), t["v_agent"].data_ptr(), t["v_pc"].data_ptr()
-            e.a_rowptr, e.a_venue = t["a_rowptr"].data_ptr(), t["a_venue"].data_ptr()
+            e.v_pcontact = t["v_pc"].data_ptr()
+            if s.v_rowptr is not None:
+                e.v_rowptr, e.v_agent = t["v_rowptr"].data_ptr(), t["v_agent"].data_ptr()
+                e.a_rowptr, e.a_venue = t["a_rowptr"].data_ptr(), t["a_venue"].data_ptr()
             e.cum, e.cum_stride = cum.data_ptr(), stride
+            if s.tiled is not None:
+                ts = s.tiled
+                if self.tiled_c is None:
+                    self.tiled_c = N.Tiled()
+                    self.tiled_c.n_slices, self.tiled_c.slice_agents = host.n_slices, host.slice_agents
+                u16 = lambda a: up(a.view(np.int16))
+                t.update(blk_v0=up(ts.blk_v0), blk_e0=up(ts.blk_e0), e_lv=u16(ts.e_lv), a_la=u16(ts.a_la),
+                         tile_sptr=up(ts.tile_sptr), tile_jpos=up(ts.tile_jpos),
+                         val=torch.zeros(max(1, ts.n_edges), dtype=torch.float32, device=dev))
+                if ts.e_cls is not None:
+                    t["e_cls"] = up(ts.e_cls)
+                c = self.tiled_c.sets[i]
+                c.n_blocks = ts.n_blocks
+                c.max_block_venues = int(np.diff(ts.blk_v0).max()) if ts.n_blocks else 0
+                c.blk_v0, c.blk_e0 = t["blk_v0"].data_ptr(), t["blk_e0"].data_ptr()
+                c.e_lv, c.a_la = t["e_lv"].data_ptr(), t["a_la"].data_ptr()
+                c.e_cls = N.ptr(t.get("e_cls"))
+                c.tile_sptr, c.tile_jpos, c.val = t["tile_sptr"].data_ptr(), t["tile_jpos"].data_ptr(), t["val"].data_ptr()
+            self.keep.append(t)
+            self.cum.append(cum)
         self.blocks = up(host.blocks.reshape(-1)) if len(host.blocks) else None
         self.long_rows = up(host.long_rows.reshape(-1)) if len(host.long_rows) else None
         self.partial = (torch.zeros(host.n_partial_slots * N.GJ_MAX_NETS_PER_SET, dtype=torch.float32, device=dev)
@@ -261,6 +316,11 @@ class DevicePlan:
         plan.agent_class = N.ptr(self.agent_class)
         plan.tables = N.ptr(self.tables)
         plan.n_tables = len(tabs)
+        if self.tiled_c is not None:
+            self.work = up(host.work.reshape(-1)) if len(host.work) else None
+            self.tiled_c.n_work = len(host.work)
+            self.tiled_c.work = N.ptr(self.work)
+            plan.tiled = C.pointer(self.tiled_c)
         self.c = plan
 
     def cum_of(self, set_name: str) -> torch.Tensor:

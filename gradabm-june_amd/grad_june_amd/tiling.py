@@ -1,0 +1,187 @@
+"""Tiled ("propagation-blocked") layout of an edge set - the fast path of the two passes.
+
+Why: in CSR form every edge costs a random 4-byte gather (``transmission[agent]`` in pass 1,
+``cum[venue]`` in pass 2).  On MI355X such a gather pulls a whole 128-byte line from the Infinity
+Cache or L2 - measured 60 G gathers/s from a 40 MB table, 175 G/s when the table is L2-resident -
+which bounds the CSR kernels at 6-12 % of the HBM roofline.  LDS serves random 4-byte reads two
+orders of magnitude faster, so the tiled layout arranges for every random access to hit LDS:
+
+* agents are cut into ``S`` *slices* of ``SA`` consecutive agents (a slice's values fit in LDS),
+* the venues of a set are cut into *blocks* of consecutive venues (a block's sums fit in LDS),
+* edge (a, v) belongs to *tile* (slice(a), block(v)).  Edges are stored twice, as 16-bit local
+  indices: ``a_la`` in slice-major tile order (s, j) and ``e_lv`` in block-major tile order (j, s);
+  a tile is contiguous in both, and inside a tile both use the same order (by venue, then agent).
+
+Per step and set, four streaming phases move 24 bytes per edge through HBM, all coalesced:
+  A  (one workgroup per slice)   x[slice] -> LDS;  val[blockmajor pos] = x[a_la]
+  B  (one workgroup per block)   sums[e_lv] += val   (LDS float atomics), cum = beta*p_contact*sums
+  C  (same workgroup)            val[i] = cum[e_lv[i]]                (in place)
+  D  (one workgroup per slice)   acc[a_la] += val[blockmajor pos]     (LDS float atomics), epilogue
+This module builds the static arrays (numpy, host) and is exercised on the CPU by an emulation of
+the four phases (tests/test_tiling_host.py).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional
+
+import numpy as np
+
+SA_MAX = 40448        # agents per slice: 158 KiB of LDS as fp32 (one 1024-thread workgroup per CU)
+SV_MAX = 32768        # venues per block (LDS fp32 sums; local venue index is 16-bit)
+EB_TARGET = 131072    # edges per block aimed for (work per workgroup of phases B/C)
+N_CU = 256
+
+
+def choose_slices(n_agents: int, sa_max: int = SA_MAX, n_cu: int = N_CU):
+    """(S, SA): S a multiple of the CU count once the world is large, SA <= sa_max."""
+    if n_agents <= 0:
+        return 1, 64
+    if n_agents <= n_cu * 1024:
+        sa = 1024 if n_agents > 1024 * 8 else max(64, -(-n_agents // 8))
+        s = -(-n_agents // sa)
+        return s, sa
+    m = -(-n_agents // (n_cu * sa_max))
+    s = n_cu * m
+    sa = -(-n_agents // s)
+    sa = -(-sa // 64) * 64
+    s = -(-n_agents // sa)
+    return s, sa
+
+
+def venue_blocks(degree: np.ndarray, sv_max: int = SV_MAX, eb_target: int = EB_TARGET) -> np.ndarray:
+    """Block boundaries ``blk_v0`` [J+1] over consecutive venues: <= sv_max venues, about eb_target
+    edges (a venue above eb_target is a block of its own)."""
+    V = len(degree)
+    if V == 0:
+        return np.zeros(1, dtype=np.int64)
+    rp = np.zeros(V + 1, dtype=np.int64)
+    np.cumsum(degree, out=rp[1:])
+    bounds = [0]
+    v = 0
+    while v < V:
+        end = int(np.searchsorted(rp, rp[v] + eb_target, side="right")) - 1
+        end = max(end, v + 1)
+        end = min(end, V, v + sv_max)
+        bounds.append(end)
+        v = end
+    return np.asarray(bounds, dtype=np.int64)
+
+
+@dataclass
+class TiledEdgeSet:
+    name: str
+    n_venues: int
+    n_edges: int
+    n_slices: int
+    n_blocks: int
+    blk_v0: np.ndarray      # int32 [J+1]  venue range of block j
+    blk_e0: np.ndarray      # int32 [J+1]  block-major edge range of block j
+    e_lv: np.ndarray        # uint16 [E]   local venue index, block-major tile order (j, s)
+    e_cls: Optional[np.ndarray]  # uint8 [E] agent class of the edge's agent, block-major (leisure sets)
+    a_la: np.ndarray        # uint16 [E]   local agent index, slice-major tile order (s, j)
+    tile_sptr: np.ndarray   # int32 [S*J+1] slice-major prefix: tile (s, j) = [sptr[s*J+j], sptr[s*J+j+1])
+    tile_jpos: np.ndarray   # int32 [S*J]   block-major start of tile (s, j)
+    v_pcontact: np.ndarray  # float32 [V]
+
+
+def build_tiled(name: str, agent_index, venue_index, n_venues: int, v_pcontact: np.ndarray,
+                n_slices: int, slice_agents: int, agent_class: Optional[np.ndarray] = None,
+                sv_max: int = SV_MAX, eb_target: int = EB_TARGET) -> TiledEdgeSet:
+    agent = np.asarray(agent_index, dtype=np.int64).ravel()
+    venue = np.asarray(venue_index, dtype=np.int64).ravel()
+    E = len(agent)
+    if slice_agents > 65536 or sv_max > 65536:
+        raise ValueError("local indices are 16-bit")
+    degree = np.bincount(venue, minlength=n_venues) if E else np.zeros(n_venues, dtype=np.int64)
+    blk_v0 = venue_blocks(degree, sv_max, eb_target)
+    J = len(blk_v0) - 1
+    S = n_slices
+    if J == 0:
+        z32 = np.zeros(1, dtype=np.int32)
+        return TiledEdgeSet(name, n_venues, 0, S, 0, z32, z32, np.zeros(0, np.uint16), None,
+                            np.zeros(0, np.uint16), np.zeros(1, np.int32), np.zeros(0, np.int32),
+                            np.asarray(v_pcontact, dtype=np.float32))
+    vblk = (np.searchsorted(blk_v0, np.arange(n_venues), side="right") - 1).astype(np.int64)
+    j = vblk[venue]
+    lv = venue - blk_v0[j]
+    s = agent // slice_agents
+    la = agent - s * slice_agents
+    if E and (s.max() >= S):
+        raise ValueError("agent index beyond the last slice")
+    # block-major tile order: (j, s, lv, la); ties (duplicate edges) keep COO order
+    key = ((j * S + s) * 65536 + lv) * 65536 + la
+    order = np.argsort(key, kind="stable")
+    tile_of = (j * S + s)[order]                       # block-major tile id per position
+    tile_len_js = np.bincount(tile_of, minlength=J * S).reshape(J, S)
+    jpos_js = np.zeros(J * S + 1, dtype=np.int64)
+    np.cumsum(tile_len_js.reshape(-1), out=jpos_js[1:])
+    tile_len_sj = tile_len_js.T.copy()                 # [S, J]
+    sptr = np.zeros(S * J + 1, dtype=np.int64)
+    np.cumsum(tile_len_sj.reshape(-1), out=sptr[1:])
+    jpos_sj = jpos_js[:-1].reshape(J, S).T.copy()      # block-major start of tile (s, j)
+    # slice-major position of every block-major position
+    tj = tile_of // S
+    ts = tile_of - tj * S
+    within = np.arange(E, dtype=np.int64) - jpos_js[tile_of]
+    pos_sm = sptr[ts * J + tj] + within
+    la_bm = la[order]
+    a_la = np.empty(E, dtype=np.uint16)
+    a_la[pos_sm] = la_bm.astype(np.uint16)
+    blk_e0 = jpos_js[:: S][: J + 1] if S > 0 else np.zeros(J + 1, dtype=np.int64)
+    blk_e0 = np.concatenate([jpos_js[0:J * S:S], [E]])
+    e_cls = None
+    if agent_class is not None:
+        e_cls = np.asarray(agent_class, dtype=np.uint8)[agent[order]]
+    return TiledEdgeSet(
+        name=name, n_venues=n_venues, n_edges=E, n_slices=S, n_blocks=J,
+        blk_v0=blk_v0.astype(np.int32), blk_e0=blk_e0.astype(np.int32),
+        e_lv=lv[order].astype(np.uint16), e_cls=e_cls, a_la=a_la,
+        tile_sptr=sptr.astype(np.int32), tile_jpos=jpos_sj.reshape(-1).astype(np.int32),
+        v_pcontact=np.asarray(v_pcontact, dtype=np.float32))
+
+
+# ------------------------------------------------------------------------------------------------
+# numpy emulation of the four phases (the specification the kernels are tested against on the CPU)
+# ------------------------------------------------------------------------------------------------
+def emulate_pass1(t: TiledEdgeSet, x: np.ndarray, slice_agents: int, beta: float,
+                  table: Optional[np.ndarray] = None):
+    """Phases A+B: returns (val [E] block-major, cum [V])."""
+    S, J = t.n_slices, t.n_blocks
+    val = np.zeros(t.n_edges, dtype=np.float32)
+    for s in range(S):
+        xs = x[s * slice_agents:(s + 1) * slice_agents]
+        for j in range(J):
+            a, b = t.tile_sptr[s * J + j], t.tile_sptr[s * J + j + 1]
+            p = t.tile_jpos[s * J + j]
+            val[p:p + (b - a)] = xs[t.a_la[a:b]]
+    cum = np.zeros(t.n_venues, dtype=np.float32)
+    for j in range(J):
+        e0, e1 = t.blk_e0[j], t.blk_e0[j + 1]
+        v0, v1 = t.blk_v0[j], t.blk_v0[j + 1]
+        xv = val[e0:e1].astype(np.float64)
+        if table is not None:
+            xv = table[t.e_cls[e0:e1]].astype(np.float64) * xv
+        sums = np.bincount(t.e_lv[e0:e1], weights=xv, minlength=v1 - v0)
+        cum[v0:v1] = (np.float32(beta) * t.v_pcontact[v0:v1]) * sums.astype(np.float32)
+    return val, cum
+
+
+def emulate_pass2(t: TiledEdgeSet, cum: np.ndarray, n_agents: int, slice_agents: int,
+                  weight_table: Optional[np.ndarray] = None):
+    """Phases C+D: returns acc [A] = sum over the agent's edges of cum[venue] (x table[cls])."""
+    S, J = t.n_slices, t.n_blocks
+    cval = np.zeros(t.n_edges, dtype=np.float32)
+    for j in range(J):
+        e0, e1 = t.blk_e0[j], t.blk_e0[j + 1]
+        c = cum[t.blk_v0[j] + t.e_lv[e0:e1].astype(np.int64)]
+        if weight_table is not None:
+            c = weight_table[t.e_cls[e0:e1]] * c
+        cval[e0:e1] = c
+    acc = np.zeros(S * slice_agents, dtype=np.float64)
+    for s in range(S):
+        for j in range(J):
+            a, b = t.tile_sptr[s * J + j], t.tile_sptr[s * J + j + 1]
+            p = t.tile_jpos[s * J + j]
+            np.add.at(acc, s * slice_agents + t.a_la[a:b].astype(np.int64), cval[p:p + (b - a)])
+    return acc[:n_agents].astype(np.float32)

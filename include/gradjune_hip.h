@@ -97,6 +97,41 @@ typedef struct gj_long_row {
 
 #define GJ_STREAM_EDGES 2048 /* max edges of a STREAM block (256 threads x 8)               */
 
+/* ---- tiled ("propagation-blocked") layout: the fast path of both passes -------------------
+ * Agents are cut into n_slices slices of slice_agents consecutive agents; the venues of a set
+ * into blocks of consecutive venues; edge (a, v) belongs to tile (slice(a), block(v)).  Every
+ * random access of the two passes then hits LDS (a slice of transmissions / a block of venue
+ * sums) and HBM only sees four coalesced streams per step (24 B per edge):
+ *   A  one workgroup per slice :  val[block-major pos] = x_slice[a_la]
+ *   B  one workgroup per block :  sums[e_lv] += val   (LDS float atomics); cum = beta*p_contact*sums
+ *   C  same workgroup (fused)  :  val[i] = cum[e_lv[i]]          (in place)
+ *   D  one workgroup per slice :  acc[a_la] += val[block-major pos]; epilogue a7-a9
+ * A tile is contiguous in both the slice-major (s, j) and the block-major (j, s) edge order.
+ * Sums are taken with LDS float atomics: results agree with the CSR path to fp32 rounding but
+ * are not bitwise reproducible from run to run (the CSR path is).                            */
+typedef struct gj_tiled_set {
+  int32_t n_blocks;          /* J: venue blocks of this set                                  */
+  int32_t max_block_venues;  /* largest block of this set (sizes the LDS of phases B/C)      */
+  const int32_t* blk_v0;     /* device [J+1]   venue range of block j                        */
+  const int32_t* blk_e0;     /* device [J+1]   block-major edge range of block j             */
+  const uint16_t* e_lv;      /* device [E]     venue index local to its block, block-major   */
+  const uint8_t* e_cls;      /* device [E]     agent_class of the edge's agent, block-major
+                                               (sets that carry leisure tables; else NULL)    */
+  const uint16_t* a_la;      /* device [E]     agent index local to its slice, slice-major   */
+  const int32_t* tile_sptr;  /* device [S*J+1] slice-major prefix: tile (s,j) = [sptr[s*J+j], sptr[s*J+j+1]) */
+  const int32_t* tile_jpos;  /* device [S*J]   block-major start of tile (s,j)               */
+  float* val;                /* device [E]     workspace: per-edge value (phase A->B, C->D)  */
+} gj_tiled_set;
+
+typedef struct gj_tiled {
+  int32_t n_slices;          /* S                                                            */
+  int32_t slice_agents;      /* SA (multiple of 64, <= 40448: one slice of fp32 fits LDS)    */
+  int32_t _pad;
+  int32_t n_work;            /* entries of `work`                                            */
+  const int32_t* work;       /* device [2*n_work] (set, block) pairs, heaviest first         */
+  gj_tiled_set sets[GJ_MAX_SETS];
+} gj_tiled;
+
 /* The compiled, immutable contact graph ("plan").  Host struct; arrays it points to are device
  * memory owned by the caller.                                                              */
 typedef struct gj_plan {
@@ -116,6 +151,9 @@ typedef struct gj_plan {
   const float* tables;        /* device [n_tables * GJ_TABLE_SIZE] leisure tables           */
   int32_t n_tables;
   int32_t _pad;
+  const gj_tiled* tiled;      /* HOST pointer or NULL.  Non-NULL: the passes run on the tiled
+                                 layout and the CSR arrays of `sets` (v_rowptr, v_agent, a_rowptr,
+                                 a_venue, blocks, long_rows) may be NULL                      */
 } gj_plan;
 
 /* One infection network active in this step

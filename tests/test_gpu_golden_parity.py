@@ -20,6 +20,20 @@ pytestmark = pytest.mark.gpu
 
 RTOL = 2e-5
 
+# every parity case runs on both device layouts: "csr" (deterministic CSR kernels) and "tiled"
+# (LDS-tiled fast path; small tiles/blocks forced so that multi-slice / multi-block paths run)
+LAYOUTS = [("csr", {}), ("tiled", {}), ("tiled", dict(sv_max=64, eb_target=512, slices="small"))]
+LAYOUT_IDS = ["csr", "tiled", "tiled-small-tiles"]
+
+
+def engine_for(world, tables, device, layout):
+    name, kw = layout
+    kw = dict(kw)
+    if kw.get("slices") == "small":
+        sa = 64
+        kw["slices"] = (-(-world["n_agents"] // sa), sa)
+    return L.make_engine(world, tables, device, layout=name, **kw)
+
 
 def _close(a, b, rtol=RTOL, atol=1e-9, what=""):
     a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
@@ -111,13 +125,14 @@ def run_case(npz, prefix, engine, device, tables):
     return int(bad.sum())
 
 
-def test_kat6(device):
+@pytest.mark.parametrize("layout", LAYOUTS, ids=LAYOUT_IDS)
+def test_kat6(device, layout):
     """The reference's exact known-answer test (test_base.py:39-44) through the HIP path."""
     from grad_june_amd.engine import AgentBuffers
 
     npz = L.load_npz("kat6.npz")
     world = L.world_from(npz)
-    eng = L.make_engine(world, None, device)
+    eng = engine_for(world, None, device, layout)
     A = 6
     z = lambda: torch.zeros(A, device=device)
     trans = torch.from_numpy(npz["transmission"]).to(device)
@@ -133,31 +148,34 @@ def test_kat6(device):
     assert np.abs(probs.cpu().numpy() - npz["not_infected_probs"]).max() <= 1e-6
 
 
-def test_c100_policy_variants(device):
+@pytest.mark.parametrize("layout", LAYOUTS, ids=LAYOUT_IDS)
+def test_c100_policy_variants(device, layout):
     npz = L.load_npz("c100.npz")
     world = L.world_from(npz)
-    eng = L.make_engine(world, None, device)
+    eng = engine_for(world, None, device, layout)
     flips = 0
     for v in str(npz["variants"]).split(","):
         flips += run_case(npz, v + "/", eng, device, None)
     assert flips == 0
 
 
+@pytest.mark.parametrize("layout", LAYOUTS, ids=LAYOUT_IDS)
 @pytest.mark.parametrize("name", ["june769.npz", "june769_hot.npz", "synth10k.npz"])
-def test_trajectory_teacher_forced(device, name):
+def test_trajectory_teacher_forced(device, name, layout):
     """Every recorded step of the reference trajectories, each from its recorded pre-state."""
     npz = L.load_npz(name)
     world = L.world_from(npz)
     tables = L.tables_from(npz)
-    eng = L.make_engine(world, tables, device)
+    eng = engine_for(world, tables, device, layout)
     flips = 0
     for i in range(int(npz["n_steps"])):
         flips += run_case(npz, f"step{i}/", eng, device, tables)
     assert flips == 0
 
 
+@pytest.mark.parametrize("layout", LAYOUTS, ids=LAYOUT_IDS)
 @pytest.mark.parametrize("name", ["june769.npz", "june769_hot.npz"])
-def test_trajectory_chained_counts(device, name):
+def test_trajectory_chained_counts(device, name, layout):
     """15 chained hot-path steps on the GPU (own state carried forward; the recorded symptom
     stage supplies the quarantine mask, symptoms being outside the path): infection counts per
     timestep must equal the reference's cases_per_timestep under the same injected noise."""
@@ -166,7 +184,7 @@ def test_trajectory_chained_counts(device, name):
     npz = L.load_npz(name)
     world = L.world_from(npz)
     tables = L.tables_from(npz)
-    eng = L.make_engine(world, tables, device)
+    eng = engine_for(world, tables, device, layout)
     A = world["n_agents"]
     rec0 = L.step_record(npz, "step0/")
     st = L.device_state(L.pre_state(rec0), device)

@@ -1,0 +1,64 @@
+"""CPU: the tiled (propagation-blocked) layout - structure invariants and a numpy emulation of the
+four streaming phases against plain bincount sums."""
+import numpy as np
+import pytest
+
+from grad_june_amd.tiling import (build_tiled, choose_slices, emulate_pass1, emulate_pass2, venue_blocks)
+
+
+def random_set(rng, A, V, E, big=None):
+    venue = rng.integers(0, V, E)
+    if big:
+        venue[: big] = min(3, V - 1)           # one huge venue
+    agent = rng.integers(0, A, E)
+    return agent, venue
+
+
+@pytest.mark.parametrize("A,V,E,sa,svmax,eb", [(5000, 700, 20000, 512, 128, 3000), (300, 5, 4000, 64, 65536, 1 << 30),
+                                               (10000, 9000, 15000, 1024, 4096, 2000), (64, 1, 10, 64, 16, 16)])
+def test_layout_and_emulation(A, V, E, sa, svmax, eb):
+    rng = np.random.default_rng(A + V)
+    agent, venue = random_set(rng, A, V, E, big=E // 3)
+    S = -(-A // sa)
+    pc = rng.random(V).astype(np.float32)
+    cls = rng.integers(0, 200, A).astype(np.uint8)
+    t = build_tiled("x", agent, venue, V, pc, S, sa, agent_class=cls, sv_max=svmax, eb_target=eb)
+    J = t.n_blocks
+    assert t.blk_v0[0] == 0 and t.blk_v0[-1] == V and t.blk_e0[-1] == E and t.tile_sptr[-1] == E
+    assert (np.diff(t.blk_v0) <= svmax).all() and (np.diff(t.blk_v0) > 0).all()
+    deg = np.bincount(venue, minlength=V)
+    assert np.array_equal(np.diff(t.blk_e0), np.add.reduceat(deg, t.blk_v0[:-1]))
+    # every tile is contiguous in both orders and holds the same multiset of edges
+    lens = np.diff(t.tile_sptr).reshape(S, J)
+    assert lens.sum() == E
+    x = rng.random(S * sa).astype(np.float32)
+    val, cum = emulate_pass1(t, x, sa, beta=0.7)
+    ref = np.float32(0.7) * pc * np.bincount(venue, weights=x[agent].astype(np.float64), minlength=V).astype(np.float32)
+    assert np.allclose(cum, ref, rtol=1e-5, atol=1e-7)
+    # val in block-major order is x[agent] of the edge stored there
+    order_key = np.sort(val)
+    assert np.allclose(order_key, np.sort(x[agent]))
+    acc = emulate_pass2(t, cum, A, sa)
+    ref2 = np.bincount(agent, weights=cum[venue].astype(np.float64), minlength=A)
+    assert np.allclose(acc, ref2, rtol=1e-5, atol=1e-6)
+    # leisure-style tables ride on the per-edge class
+    tab = rng.random(200).astype(np.float32)
+    _, cum_l = emulate_pass1(t, x, sa, beta=1.0, table=tab)
+    ref_l = pc * np.bincount(venue, weights=(tab[cls[agent]] * x[agent]).astype(np.float64), minlength=V).astype(np.float32)
+    assert np.allclose(cum_l, ref_l, rtol=1e-5, atol=1e-7)
+    acc_l = emulate_pass2(t, cum_l, A, sa, weight_table=tab)
+    ref_l2 = np.bincount(agent, weights=(tab[cls[agent]] * cum_l[venue]).astype(np.float64), minlength=A)
+    assert np.allclose(acc_l, ref_l2, rtol=1e-5, atol=1e-6)
+
+
+def test_empty_set_and_slice_choice():
+    t = build_tiled("e", np.zeros(0, np.int64), np.zeros(0, np.int64), 0, np.zeros(0, np.float32), 4, 64)
+    assert t.n_blocks == 0 and t.n_edges == 0
+    t = build_tiled("e", np.zeros(0, np.int64), np.zeros(0, np.int64), 10, np.ones(10, np.float32), 4, 64)
+    assert t.n_blocks == 1 and t.n_edges == 0 and t.blk_v0.tolist() == [0, 10]
+    for n in (1, 100, 769, 10_000, 1_000_000, 10_000_000, 25_000_000):
+        S, SA = choose_slices(n)
+        assert S * SA >= n and (S - 1) * SA < n and SA <= 40448
+    assert choose_slices(10_000_000)[0] == 256
+    b = venue_blocks(np.array([5, 5, 100000, 5, 5]), sv_max=2, eb_target=50)
+    assert b.tolist() == [0, 2, 3, 5]
