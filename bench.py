@@ -38,6 +38,10 @@ def parse():
     ap.add_argument("--agents", type=int, default=None)
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--infected", type=float, default=0.01)
+    ap.add_argument("--layout", default="tiled", choices=["tiled", "csr"],
+                    help="tiled: LDS propagation-blocked kernels (default); csr: deterministic CSR kernels")
+    ap.add_argument("--sv-max", type=int, default=None)
+    ap.add_argument("--eb-target", type=int, default=None)
     ap.add_argument("--edge-mult", type=float, default=1.0, help="experiments: memberships per agent x this")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
@@ -85,10 +89,16 @@ def kernel_bytes(world, networks):
     e_nets = sum(E[edge_set_of(n)] for n in networks)
     v_nets = sum(V[edge_set_of(n)] for n in networks)
     N = len(networks)
+    p1 = 4 * e_sets + 4 * e_nets + 12 * v_nets                  # pass 1
+    p2 = 4 * e_sets + 4 * e_nets + 8 * N * A + 32 * A           # pass 2 + probs + sample + infect
     return {
         "transmission": 32 * A,                                   # 6 reads + 1 write + quarantine mask
-        "venue_reduce": 4 * e_sets + 4 * e_nets + 12 * v_nets,    # pass 1
-        "agent_gather": 4 * e_sets + 4 * e_nets + 8 * N * A + 32 * A,  # pass 2 + probs + sample + infect
+        "venue_reduce": p1, "agent_gather": p2,                   # CSR layout: one launch per pass
+        # tiled layout: pass 1 = scatter (A) + first half of the venue launch (B); pass 2 = second half (C)
+        # + agents (D).  The venue launch is priced at half of each pass's edge terms + the venue terms.
+        "tile_scatter": (4 * e_sets + 4 * e_nets) // 2,
+        "tile_venues": (4 * e_sets + 4 * e_nets) // 2 + 12 * v_nets + (4 * e_sets + 4 * e_nets) // 2,
+        "tile_agents": (4 * e_sets + 4 * e_nets) // 2 + 8 * N * A + 32 * A,
     }
 
 
@@ -179,7 +189,13 @@ def main():
     else:
         from grad_june_amd.benchrun import SingleGpuHotPath
 
-        runner = SingleGpuHotPath(world, specs, betas, dev, seed=args.seed)
+        kw = {}
+        if args.layout == "tiled":
+            if args.sv_max:
+                kw["sv_max"] = args.sv_max
+            if args.eb_target:
+                kw["eb_target"] = args.eb_target
+        runner = SingleGpuHotPath(world, specs, betas, dev, seed=args.seed, layout=args.layout, **kw)
     t_setup = time.time() - t0
 
     def sync():
@@ -228,6 +244,7 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
+        "layout": args.layout,
         "config": {"workload": f"{args.preset}: {world['n_agents']} agents, {len(networks)} infection networks on "
                                f"{len(world['edge_sets'])} edge sets, {n_edges} network-edges, seed {args.seed}, "
                                f"{args.infected:.0%} infected, Philox noise",

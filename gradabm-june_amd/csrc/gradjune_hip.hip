@@ -874,6 +874,27 @@ int gj_step(const gj_plan* plan, const gj_agent_state* state, const gj_step_para
   return gj::do_agent_gather(plan, state, params, G, io, 1, (hipStream_t)stream);
 }
 
+int gj_step_phase(const gj_plan* plan, const gj_agent_state* state, const gj_step_params* params,
+                  const gj_step_io* io, int phase, void* stream) {
+  int rc = gj::check_plan(plan);
+  if (rc) return rc;
+  gj::Groups G;
+  rc = gj::group_networks(plan, params, &G);
+  if (rc) return rc;
+  rc = gj::check_state(plan, state, params);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  switch (phase) {
+    case 0: return gj::do_transmission(plan, state, params, st);
+    case 1: return plan->tiled ? gj::tiled_scatter(plan, state, params, G, st)
+                               : gj::do_venue_reduce(plan, state, params, G, st);
+    case 2: return plan->tiled ? gj::tiled_venues(plan, params, G, 0, st) : GJ_OK;
+    case 3: return plan->tiled ? gj::tiled_agents(plan, state, params, G, io, 1, st)
+                               : gj::do_agent_gather(plan, state, params, G, io, 1, st);
+    default: return GJ_E_RANGE;
+  }
+}
+
 int gj_pack_f32(int64_t n, const int32_t* index, const float* src, float* out, void* stream) {
   if (n < 0) return GJ_E_RANGE;
   if (n == 0) return GJ_OK;

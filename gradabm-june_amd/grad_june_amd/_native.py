@@ -150,6 +150,10 @@ SYMBOLS = {
         [C.c_int64, _vp, _vp, C.c_uint64, C.c_uint64, C.c_int64, C.c_float, _vp, _vp, _vp, _vp, _vp],
     ),
     "gj_step": (C.c_int, [C.POINTER(Plan), C.POINTER(AgentState), C.POINTER(StepParams), C.POINTER(StepIO), _vp]),
+    "gj_step_phase": (
+        C.c_int,
+        [C.POINTER(Plan), C.POINTER(AgentState), C.POINTER(StepParams), C.POINTER(StepIO), C.c_int, _vp],
+    ),
     "gj_pack_f32": (C.c_int, [C.c_int64, _vp, _vp, _vp, _vp]),
     "gj_unpack_f32": (C.c_int, [C.c_int64, _vp, _vp, _vp, _vp]),
     "gj_event_create": (C.c_int, [C.POINTER(_vp)]),

@@ -44,10 +44,15 @@ class EventLog:
 
 
 class SingleGpuHotPath:
+    PHASES = {"csr": ((0, "transmission"), (1, "venue_reduce"), (3, "agent_gather")),
+              "tiled": ((0, "transmission"), (1, "tile_scatter"), (2, "tile_venues"), (3, "tile_agents"))}
+
     def __init__(self, world: dict, specs: Sequence[NetworkSpec], betas: Dict[str, float], device,
-                 seed: int = 0, quarantine_threshold=None, exp_noise=None):
+                 seed: int = 0, quarantine_threshold=None, exp_noise=None, layout: str = "tiled", **plan_kw):
         self.device = torch.device(device)
-        host = compile_plan(world["n_agents"], world["edge_sets"], age=world["age"], sex=world["sex"])
+        self.layout = layout
+        host = compile_plan(world["n_agents"], world["edge_sets"], age=world["age"], sex=world["sex"],
+                            layout=layout, **plan_kw)
         self.engine = InfectionEngine(DevicePlan(host, specs, self.device))
         self.networks = list(world["networks"])
         self.betas = betas
@@ -81,12 +86,9 @@ class SingleGpuHotPath:
             e.step(self.bufs, p, self.io)
         else:
             self.log.mark("begin")
-            e.transmission_update(self.bufs, p)
-            self.log.mark("transmission")
-            e.venue_reduce(self.bufs, p)
-            self.log.mark("venue_reduce")
-            e.agent_gather(self.bufs, p, self.io, sample=True)
-            self.log.mark("agent_gather")
+            for phase, label in self.PHASES[self.layout]:
+                e.step_phase(self.bufs, p, self.io, phase)
+                self.log.mark(label)
         self.t += 1
 
     def reset_timers(self):

@@ -116,6 +116,11 @@ class InfectionEngine:
         N.check(self.lib.gj_step(C.byref(self.plan.c), C.byref(bufs.c), C.byref(p), C.byref(io),
                                  N.current_stream()), "gj_step")
 
+    def step_phase(self, bufs: AgentBuffers, p: N.StepParams, io: N.StepIO, phase: int):
+        self._prep(bufs, p)
+        N.check(self.lib.gj_step_phase(C.byref(self.plan.c), C.byref(bufs.c), C.byref(p), C.byref(io), int(phase),
+                                       N.current_stream()), "gj_step_phase")
+
     def sample_infect(self, not_infected_probs, *, now: float, susceptibility, is_infected, infection_time,
                       exp_noise=None, new_infected=None, seed: int = 0, step: int = 0, agent_offset: int = 0):
         n = not_infected_probs.numel()

@@ -39,6 +39,7 @@ def choose_slices(n_agents: int, sa_max: int = SA_MAX, n_cu: int = N_CU):
         return 1, 64
     if n_agents <= n_cu * 1024:
         sa = 1024 if n_agents > 1024 * 8 else max(64, -(-n_agents // 8))
+        sa = -(-sa // 64) * 64
         s = -(-n_agents // sa)
         return s, sa
     m = -(-n_agents // (n_cu * sa_max))

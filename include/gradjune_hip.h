@@ -249,6 +249,13 @@ int gj_sample_infect(int64_t n_agents, const float* not_infected_probs, const fl
 int gj_step(const gj_plan* plan, const gj_agent_state* state, const gj_step_params* params,
             const gj_step_io* io, void* stream);
 
+/* One launch group of gj_step at a time, for per-kernel timing (bench.py brackets each with HIP
+ * events): phase 0 = transmission; 1 = pass-1 front (tiled: phase A scatter; CSR: venue reduce);
+ * 2 = tiled phases B+C (CSR: nothing); 3 = pass-2 + epilogue + decision + state update.
+ * Calling phases 0,1,2,3 in order is exactly gj_step.                                        */
+int gj_step_phase(const gj_plan* plan, const gj_agent_state* state, const gj_step_params* params,
+                  const gj_step_io* io, int phase, void* stream);
+
 /* Multi-GPU halo exchange helpers (one process per GPU; the all-to-all itself is issued by
  * the host through torch.distributed/RCCL between the two calls).
  * pack:   out[i] = src[index[i]]            for i < n      (send buffer of owned agents)
