@@ -1,5 +1,9 @@
 // Tiled ("propagation-blocked") kernels: phases A-D of include/gradjune_hip.h, struct gj_tiled.
 // Every random access hits LDS; HBM sees only coalesced streams.  Included by gradjune_hip.hip.
+//
+// All three kernels are pure streaming + LDS, so what matters is bytes in flight per CU: one
+// workgroup of 16 waves owns up to 158 KiB of LDS (one per CU), and every lane keeps kUnroll
+// independent loads in flight before it touches LDS.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -11,11 +15,14 @@ namespace gj {
 
 constexpr int kTileThreads = 1024;  // 16 waves: one workgroup per CU when the slice fills LDS
 constexpr int kTileWaves = kTileThreads / kWave;
+constexpr int kUnroll = 8;          // 64-edge chunks a wave keeps in flight (phases A and D)
 
 struct TSetA {            // what phases A and D need of one set
   const uint16_t* a_la;
   const int32_t* tile_sptr;
   const int32_t* tile_jpos;
+  const int32_t* chunk_ptr;
+  const uint16_t* chunk_tile;
   float* val;
   int32_t J;
   int32_t active;         // networks active on the set in this step (0: skip)
@@ -32,7 +39,6 @@ struct TileAArgs {
   const float* qtrans;    // == trans when no quarantine collection
 };
 
-// ---- phase A: scatter the slice's transmissions to every edge, in block-major tile order -------
 __device__ __forceinline__ void load_slice(float* lds, const float* __restrict__ src, int64_t base, int n_local,
                                            int tid) {
   const int n4 = n_local >> 2;   // base is a multiple of 64 floats: 16-byte aligned
@@ -42,6 +48,18 @@ __device__ __forceinline__ void load_slice(float* lds, const float* __restrict__
   for (int i = (n4 << 2) + tid; i < n_local; i += kTileThreads) lds[i] = src[base + i];
 }
 
+// Block-major slot of slice-major edge i of slice row `row`: the chunk table names the tile of the
+// chunk's first edge; a lane walks forward over the (few) tile boundaries inside the chunk.
+__device__ __forceinline__ int slot_of(const TSetA& T, int row, int j, int i) {
+  int hi = T.tile_sptr[row + j + 1];
+  while (i >= hi) {
+    ++j;
+    hi = T.tile_sptr[row + j + 1];
+  }
+  return T.tile_jpos[row + j] + (i - T.tile_sptr[row + j]);
+}
+
+// ---- phase A: scatter the slice's transmissions to every edge, in block-major tile order -------
 __global__ __launch_bounds__(kTileThreads) void k_tile_scatter(const TileAArgs A) {
   extern __shared__ __align__(16) float lds_x[];
   const int tid = threadIdx.x;
@@ -64,10 +82,26 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_scatter(const TileAArgs A
       const TSetA& T = A.sets[t];
       if (!T.active || (two_sources && T.raw != pass)) continue;
       const int row = s * T.J;
-      for (int j = wave; j < T.J; j += kTileWaves) {
-        const int a = T.tile_sptr[row + j], b = T.tile_sptr[row + j + 1];
-        const int p = T.tile_jpos[row + j] - a;
-        for (int i = a + lane; i < b; i += kWave) T.val[p + i] = lds_x[T.a_la[i]];
+      const int seg0 = T.tile_sptr[row], seg1 = T.tile_sptr[row + T.J];
+      const int c_base = T.chunk_ptr[s];
+      const int n_chunks = T.chunk_ptr[s + 1] - c_base;
+      for (int c0 = wave * kUnroll; c0 < n_chunks; c0 += kTileWaves * kUnroll) {
+        int la[kUnroll], slot[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+          const int i = seg0 + (c0 + u) * kWave + lane;
+          la[u] = (c0 + u < n_chunks && i < seg1) ? (int)T.a_la[i] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+          if (la[u] >= 0) {
+            const int i = seg0 + (c0 + u) * kWave + lane;
+            slot[u] = slot_of(T, row, T.chunk_tile[c_base + c0 + u], i);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u)
+          if (la[u] >= 0) T.val[slot[u]] = lds_x[la[u]];
       }
     }
   }
@@ -99,32 +133,20 @@ struct TileBArgs {
   int32_t mode;            // 0: B then C (fused);  1: B only (cum written);  2: C only (cum read)
 };
 
-// segmented (by run of equal keys) inclusive sum across the wave; returns true on the last lane of a run
-__device__ __forceinline__ bool run_sum(int key, float& x, int lane) {
-  const int prev = __shfl_up(key, 1, kWave);
-  int head = (lane == 0) || (prev != key);
-#pragma unroll
-  for (int off = 1; off < kWave; off <<= 1) {
-    const float y = __shfl_up(x, off, kWave);
-    const int hy = __shfl_up(head, off, kWave);
-    if (lane >= off && !head) {
-      x += y;
-      head |= hy;
-    }
-  }
-  const int next = __shfl_down(key, 1, kWave);
-  return (lane == kWave - 1) || (next != key);
-}
+struct Slots8 {           // 8 consecutive block-major slots: 16 bytes of local venue indices
+  uint32_t w[4];
+  __device__ __forceinline__ int lv(int q) const { return (w[q >> 1] >> ((q & 1) * 16)) & 0xFFFF; }
+};
 
 __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B) {
   extern __shared__ __align__(16) float lds_s[];
-  const int tid = threadIdx.x, lane = tid % kWave;
+  const int tid = threadIdx.x;
   const int set = B.work[2 * blockIdx.x], j = B.work[2 * blockIdx.x + 1];
   const TSetB& T = B.sets[set];
   const int nk = T.nk;
   if (nk == 0) return;
   const int v0 = T.blk_v0[j], nv = T.blk_v0[j + 1] - v0;
-  const int e0 = T.blk_e0[j], e1 = T.blk_e0[j + 1];
+  const int g0 = T.blk_e0[j] >> 3, g1 = T.blk_e0[j + 1] >> 3;   // groups of 8 slots
   float* sums = lds_s;                       // [nk][nv]
   float* tabs = lds_s + (size_t)nk * nv;     // [nk][200] pass-1 tables, then [nk][200] pass-2 weights
   if (T.leisure) {
@@ -135,51 +157,98 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
       tabs[nk * 200 + i] = T.age75[k] ? l * (((c % 100) > 75) ? 1.0f : 0.0f) : l;
     }
   }
+  const uint4* lv8 = reinterpret_cast<const uint4*>(T.e_lv);
+  const uint2* cls8 = reinterpret_cast<const uint2*>(T.e_cls);
+  float4* val4 = reinterpret_cast<float4*>(T.val);
   if (B.mode != 2) {
     for (int i = tid; i < nk * nv; i += kTileThreads) sums[i] = 0.0f;
     __syncthreads();
-    // B: stream the block's edges; whole waves stay converged (uniform trip count) for the shuffles
-    const int n_iter = (e1 - e0 + kTileThreads - 1) / kTileThreads;
-    for (int it = 0; it < n_iter; ++it) {
-      const int i = e0 + it * kTileThreads + tid;
-      const bool ok = i < e1;
-      const int lv = ok ? (int)T.e_lv[i] : -1 - lane;
-      float x = ok ? T.val[i] : 0.0f;
+    // B: each lane takes 8 consecutive slots (48 bytes in flight), merges runs of one venue in
+    // registers and adds each run to the block's LDS sums
+    for (int g = g0 + tid; g < g1; g += kTileThreads) {
+      const uint4 raw = lv8[g];
+      const float4 xa = val4[2 * g], xb = val4[2 * g + 1];
+      const Slots8 L{{raw.x, raw.y, raw.z, raw.w}};
+      const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
       if (!T.leisure) {
-        const bool tail = run_sum(lv, x, lane);
-        if (ok && tail) atomicAdd(&sums[lv], x);
-      } else if (ok) {
-        const int c = T.e_cls[i];
-        for (int k = 0; k < nk; ++k) atomicAdd(&sums[k * nv + lv], tabs[k * 200 + c] * x);
+        int cur = L.lv(0);
+        float acc = x[0];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) {
+          const int lv = L.lv(q);
+          if (lv == cur) {
+            acc += x[q];
+          } else {
+            if (cur != 0xFFFF) atomicAdd(&sums[cur], acc);
+            cur = lv;
+            acc = x[q];
+          }
+        }
+        if (cur != 0xFFFF) atomicAdd(&sums[cur], acc);
+      } else {
+        const uint2 craw = cls8[g];
+        const uint32_t cw[2] = {craw.x, craw.y};
+        for (int k = 0; k < nk; ++k) {
+          const float* tk = tabs + k * 200;
+          int cur = L.lv(0);
+          float acc = tk[cw[0] & 0xFF] * x[0];
+#pragma unroll
+          for (int q = 1; q < 8; ++q) {
+            const int lv = L.lv(q);
+            const float xl = tk[(cw[q >> 2] >> ((q & 3) * 8)) & 0xFF] * x[q];
+            if (lv == cur) {
+              acc += xl;
+            } else {
+              if (cur != 0xFFFF) atomicAdd(&sums[k * nv + cur], acc);
+              cur = lv;
+              acc = xl;
+            }
+          }
+          if (cur != 0xFFFF) atomicAdd(&sums[k * nv + cur], acc);
+        }
       }
     }
     __syncthreads();
-    for (int i = tid; i < nk * nv; i += kTileThreads) {
-      const int k = i / nv, lv = i - k * nv;
-      const float c = (T.beta[k] * T.v_pc[v0 + lv]) * sums[i];
-      T.cum[(int64_t)(v0 + lv) * T.stride + k] = c;
-      sums[i] = c;
+    for (int k = 0; k < nk; ++k) {
+      const float beta = T.beta[k];
+      for (int lv = tid; lv < nv; lv += kTileThreads) {
+        const float c = (beta * T.v_pc[v0 + lv]) * sums[k * nv + lv];
+        T.cum[(int64_t)(v0 + lv) * T.stride + k] = c;
+        sums[k * nv + lv] = c;
+      }
     }
     if (B.mode == 1) return;
   } else {
-    for (int i = tid; i < nk * nv; i += kTileThreads) {
-      const int k = i / nv, lv = i - k * nv;
-      sums[i] = T.cum[(int64_t)(v0 + lv) * T.stride + k];
-    }
+    for (int k = 0; k < nk; ++k)
+      for (int lv = tid; lv < nv; lv += kTileThreads) sums[k * nv + lv] = T.cum[(int64_t)(v0 + lv) * T.stride + k];
   }
   __syncthreads();
-  // C: per edge, the venue's cum (leisure: weighted over the set's networks by the agent's class)
-  for (int i = e0 + tid; i < e1; i += kTileThreads) {
-    const int lv = T.e_lv[i];
-    float r;
+  // C: per slot, the venue's cum (leisure: weighted over the set's networks by the agent's class)
+  for (int g = g0 + tid; g < g1; g += kTileThreads) {
+    const uint4 raw = lv8[g];
+    const Slots8 L{{raw.x, raw.y, raw.z, raw.w}};
+    float r[8];
     if (!T.leisure) {
-      r = sums[lv];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int lv = L.lv(q);
+        r[q] = (lv != 0xFFFF) ? sums[lv] : 0.0f;
+      }
     } else {
-      const int c = T.e_cls[i];
-      r = 0.0f;
-      for (int k = 0; k < nk; ++k) r += tabs[nk * 200 + k * 200 + c] * sums[k * nv + lv];
+      const uint2 craw = cls8[g];
+      const uint32_t cw[2] = {craw.x, craw.y};
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int lv = L.lv(q);
+        const int c = (cw[q >> 2] >> ((q & 3) * 8)) & 0xFF;
+        float a = 0.0f;
+        if (lv != 0xFFFF)
+          for (int k = 0; k < nk; ++k) a += tabs[nk * 200 + k * 200 + c] * sums[k * nv + lv];
+        r[q] = a;
+      }
     }
-    T.val[i] = r;
+    val4[2 * g] = make_float4(r[0], r[1], r[2], r[3]);
+    val4[2 * g + 1] = make_float4(r[4], r[5], r[6], r[7]);
   }
 }
 
@@ -218,10 +287,27 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
       const TSetA& T = D.sets[t];
       if (!T.active || T.raw != pass) continue;
       const int row = s * T.J;
-      for (int j = wave; j < T.J; j += kTileWaves) {
-        const int a = T.tile_sptr[row + j], b = T.tile_sptr[row + j + 1];
-        const int p = T.tile_jpos[row + j] - a;
-        for (int i = a + lane; i < b; i += kWave) atomicAdd(&lds_acc[T.a_la[i]], T.val[p + i]);
+      const int seg0 = T.tile_sptr[row], seg1 = T.tile_sptr[row + T.J];
+      const int c_base = T.chunk_ptr[s];
+      const int n_chunks = T.chunk_ptr[s + 1] - c_base;
+      for (int c0 = wave * kUnroll; c0 < n_chunks; c0 += kTileWaves * kUnroll) {
+        int la[kUnroll];
+        float v[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+          const int i = seg0 + (c0 + u) * kWave + lane;
+          la[u] = (c0 + u < n_chunks && i < seg1) ? (int)T.a_la[i] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+          if (la[u] >= 0) {
+            const int i = seg0 + (c0 + u) * kWave + lane;
+            v[u] = T.val[slot_of(T, row, T.chunk_tile[c_base + c0 + u], i)];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u)
+          if (la[u] >= 0) atomicAdd(&lds_acc[la[u]], v[u]);
       }
     }
     __syncthreads();

@@ -622,8 +622,8 @@ static int check_tiled(const gj_plan* plan) {
     const gj_tiled_set& S = T->sets[s];
     if (S.n_blocks < 0) return GJ_E_PLAN;
     if (S.n_blocks == 0) continue;
-    if (!S.blk_v0 || !S.blk_e0 || !S.tile_sptr || !S.tile_jpos) return GJ_E_NULL;
-    if (plan->sets[s].n_edges > 0 && (!S.e_lv || !S.a_la || !S.val)) return GJ_E_NULL;
+    if (!S.blk_v0 || !S.blk_e0 || !S.tile_sptr || !S.tile_jpos || !S.chunk_ptr) return GJ_E_NULL;
+    if (plan->sets[s].n_edges > 0 && (!S.e_lv || !S.a_la || !S.val || !S.chunk_tile)) return GJ_E_NULL;
     if (S.max_block_venues < 1 || S.max_block_venues > 65536) return GJ_E_PLAN;
   }
   return GJ_OK;
@@ -649,6 +649,8 @@ static void fill_set_a(const gj_plan* plan, const gj_step_params* p, const Group
     sets[s].a_la = S.a_la;
     sets[s].tile_sptr = S.tile_sptr;
     sets[s].tile_jpos = S.tile_jpos;
+    sets[s].chunk_ptr = S.chunk_ptr;
+    sets[s].chunk_tile = S.chunk_tile;
     sets[s].val = S.val;
     sets[s].J = S.n_blocks;
     sets[s].active = (S.n_blocks > 0 && plan->sets[s].n_edges > 0) ? G.nk[g] : 0;

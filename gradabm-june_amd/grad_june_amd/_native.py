@@ -51,6 +51,8 @@ class TiledSet(C.Structure):
         ("a_la", _vp),
         ("tile_sptr", _vp),
         ("tile_jpos", _vp),
+        ("chunk_ptr", _vp),
+        ("chunk_tile", _vp),
         ("val", _vp),
     ]
 

@@ -290,7 +290,8 @@ class DevicePlan:
                 u16 = lambda a: up(a.view(np.int16))
                 t.update(blk_v0=up(ts.blk_v0), blk_e0=up(ts.blk_e0), e_lv=u16(ts.e_lv), a_la=u16(ts.a_la),
                          tile_sptr=up(ts.tile_sptr), tile_jpos=up(ts.tile_jpos),
-                         val=torch.zeros(max(1, ts.n_edges), dtype=torch.float32, device=dev))
+                         chunk_ptr=up(ts.chunk_ptr), chunk_tile=u16(ts.chunk_tile) if len(ts.chunk_tile) else None,
+                         val=torch.zeros(max(8, ts.n_slots), dtype=torch.float32, device=dev))
                 if ts.e_cls is not None:
                     t["e_cls"] = up(ts.e_cls)
                 c = self.tiled_c.sets[i]
@@ -300,6 +301,7 @@ class DevicePlan:
                 c.e_lv, c.a_la = t["e_lv"].data_ptr(), t["a_la"].data_ptr()
                 c.e_cls = N.ptr(t.get("e_cls"))
                 c.tile_sptr, c.tile_jpos, c.val = t["tile_sptr"].data_ptr(), t["tile_jpos"].data_ptr(), t["val"].data_ptr()
+                c.chunk_ptr, c.chunk_tile = t["chunk_ptr"].data_ptr(), N.ptr(t["chunk_tile"])
             self.keep.append(t)
             self.cum.append(cum)
         self.blocks = up(host.blocks.reshape(-1)) if len(host.blocks) else None
@@ -331,7 +333,7 @@ class DevicePlan:
     def bytes_resident(self) -> int:
         n = 0
         for t in self.keep:
-            n += sum(x.numel() * x.element_size() for x in t.values())
+            n += sum(x.numel() * x.element_size() for x in t.values() if x is not None)
         n += sum(c.numel() * 4 for c in self.cum)
         for x in (self.blocks, self.long_rows, self.partial, self.agent_class, self.tables):
             if x is not None:

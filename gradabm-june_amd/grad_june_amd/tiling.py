@@ -31,6 +31,8 @@ SA_MAX = 40448        # agents per slice: 158 KiB of LDS as fp32 (one 1024-threa
 SV_MAX = 32768        # venues per block (LDS fp32 sums; local venue index is 16-bit)
 EB_TARGET = 131072    # edges per block aimed for (work per workgroup of phases B/C)
 N_CU = 256
+PAD = 8               # block-major arrays: every block starts on a multiple of PAD slots
+CHUNK = 64            # slice-major traversal granule (one wave-instruction)
 
 
 def choose_slices(n_agents: int, sa_max: int = SA_MAX, n_cu: int = N_CU):
@@ -84,6 +86,9 @@ class TiledEdgeSet:
     tile_sptr: np.ndarray   # int32 [S*J+1] slice-major prefix: tile (s, j) = [sptr[s*J+j], sptr[s*J+j+1])
     tile_jpos: np.ndarray   # int32 [S*J]   block-major start of tile (s, j)
     v_pcontact: np.ndarray  # float32 [V]
+    n_slots: int = 0        # length of the block-major arrays: every block padded to a multiple of 8
+    chunk_ptr: Optional[np.ndarray] = None   # int32 [S+1] first 64-edge chunk of slice s (slice-major)
+    chunk_tile: Optional[np.ndarray] = None  # uint16 [n_chunks] block j of the chunk's first edge
 
 
 def build_tiled(name: str, agent_index, venue_index, n_venues: int, v_pcontact: np.ndarray,
@@ -102,7 +107,8 @@ def build_tiled(name: str, agent_index, venue_index, n_venues: int, v_pcontact: 
         z32 = np.zeros(1, dtype=np.int32)
         return TiledEdgeSet(name, n_venues, 0, S, 0, z32, z32, np.zeros(0, np.uint16), None,
                             np.zeros(0, np.uint16), np.zeros(1, np.int32), np.zeros(0, np.int32),
-                            np.asarray(v_pcontact, dtype=np.float32))
+                            np.asarray(v_pcontact, dtype=np.float32), 0, np.zeros(S + 1, np.int32),
+                            np.zeros(0, np.uint16))
     vblk = (np.searchsorted(blk_v0, np.arange(n_venues), side="right") - 1).astype(np.int64)
     j = vblk[venue]
     lv = venue - blk_v0[j]
@@ -113,10 +119,20 @@ def build_tiled(name: str, agent_index, venue_index, n_venues: int, v_pcontact: 
     # block-major tile order: (j, s, lv, la); ties (duplicate edges) keep COO order
     key = ((j * S + s) * 65536 + lv) * 65536 + la
     order = np.argsort(key, kind="stable")
-    tile_of = (j * S + s)[order]                       # block-major tile id per position
+    tile_of = (j * S + s)[order]                       # block-major tile id per (unpadded) position
     tile_len_js = np.bincount(tile_of, minlength=J * S).reshape(J, S)
-    jpos_js = np.zeros(J * S + 1, dtype=np.int64)
-    np.cumsum(tile_len_js.reshape(-1), out=jpos_js[1:])
+    upos_js = np.zeros(J * S + 1, dtype=np.int64)      # unpadded block-major prefix
+    np.cumsum(tile_len_js.reshape(-1), out=upos_js[1:])
+    # every block occupies a multiple of PAD slots so that phases B/C can use 16-byte accesses;
+    # the pad slots at a block's end carry the sentinel local venue 0xFFFF
+    blk_len = tile_len_js.sum(1)
+    blk_slots = -(-blk_len // PAD) * PAD
+    blk_start = np.zeros(J + 1, dtype=np.int64)
+    np.cumsum(blk_slots, out=blk_start[1:])
+    blk_ustart = np.concatenate([upos_js[0:J * S:S], [E]])
+    shift = np.repeat(blk_start[:-1] - blk_ustart[:-1], S)          # per tile (j, s): padded - unpadded
+    jpos_js = np.concatenate([upos_js[:-1] + shift, [blk_start[-1]]])
+    n_slots = int(blk_start[-1])
     tile_len_sj = tile_len_js.T.copy()                 # [S, J]
     sptr = np.zeros(S * J + 1, dtype=np.int64)
     np.cumsum(tile_len_sj.reshape(-1), out=sptr[1:])
@@ -124,22 +140,34 @@ def build_tiled(name: str, agent_index, venue_index, n_venues: int, v_pcontact: 
     # slice-major position of every block-major position
     tj = tile_of // S
     ts = tile_of - tj * S
-    within = np.arange(E, dtype=np.int64) - jpos_js[tile_of]
+    within = np.arange(E, dtype=np.int64) - upos_js[tile_of]
     pos_sm = sptr[ts * J + tj] + within
+    pos_bm = jpos_js[tile_of] + within                              # padded block-major slot
     la_bm = la[order]
     a_la = np.empty(E, dtype=np.uint16)
     a_la[pos_sm] = la_bm.astype(np.uint16)
-    blk_e0 = jpos_js[:: S][: J + 1] if S > 0 else np.zeros(J + 1, dtype=np.int64)
-    blk_e0 = np.concatenate([jpos_js[0:J * S:S], [E]])
+    e_lv = np.full(n_slots, 0xFFFF, dtype=np.uint16)
+    e_lv[pos_bm] = lv[order].astype(np.uint16)
     e_cls = None
     if agent_class is not None:
-        e_cls = np.asarray(agent_class, dtype=np.uint8)[agent[order]]
+        e_cls = np.zeros(n_slots, dtype=np.uint8)
+        e_cls[pos_bm] = np.asarray(agent_class, dtype=np.uint8)[agent[order]]
+    # 64-edge chunks of each slice's slice-major segment, and the block of each chunk's first edge
+    seg = sptr[0:S * J + 1:J]                                        # [S+1] slice segment bounds
+    n_chunks = -(-(np.diff(seg)) // CHUNK)
+    chunk_ptr = np.zeros(S + 1, dtype=np.int64)
+    np.cumsum(n_chunks, out=chunk_ptr[1:])
+    first_edge = np.repeat(seg[:-1], n_chunks) + CHUNK * (np.arange(chunk_ptr[-1]) - np.repeat(chunk_ptr[:-1], n_chunks))
+    # tile (slice-major index) containing an edge position: last tile whose start <= position, skipping empties
+    chunk_tile_sm = np.searchsorted(sptr, first_edge, side="right") - 1
+    chunk_tile = (chunk_tile_sm - np.repeat(np.arange(S) * J, n_chunks)).astype(np.uint16)
     return TiledEdgeSet(
         name=name, n_venues=n_venues, n_edges=E, n_slices=S, n_blocks=J,
-        blk_v0=blk_v0.astype(np.int32), blk_e0=blk_e0.astype(np.int32),
-        e_lv=lv[order].astype(np.uint16), e_cls=e_cls, a_la=a_la,
+        blk_v0=blk_v0.astype(np.int32), blk_e0=blk_start.astype(np.int32),
+        e_lv=e_lv, e_cls=e_cls, a_la=a_la,
         tile_sptr=sptr.astype(np.int32), tile_jpos=jpos_sj.reshape(-1).astype(np.int32),
-        v_pcontact=np.asarray(v_pcontact, dtype=np.float32))
+        v_pcontact=np.asarray(v_pcontact, dtype=np.float32), n_slots=n_slots,
+        chunk_ptr=chunk_ptr.astype(np.int32), chunk_tile=chunk_tile)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -149,7 +177,7 @@ def emulate_pass1(t: TiledEdgeSet, x: np.ndarray, slice_agents: int, beta: float
                   table: Optional[np.ndarray] = None):
     """Phases A+B: returns (val [E] block-major, cum [V])."""
     S, J = t.n_slices, t.n_blocks
-    val = np.zeros(t.n_edges, dtype=np.float32)
+    val = np.zeros(t.n_slots, dtype=np.float32)
     for s in range(S):
         xs = x[s * slice_agents:(s + 1) * slice_agents]
         for j in range(J):
@@ -160,10 +188,11 @@ def emulate_pass1(t: TiledEdgeSet, x: np.ndarray, slice_agents: int, beta: float
     for j in range(J):
         e0, e1 = t.blk_e0[j], t.blk_e0[j + 1]
         v0, v1 = t.blk_v0[j], t.blk_v0[j + 1]
-        xv = val[e0:e1].astype(np.float64)
+        real = t.e_lv[e0:e1] != 0xFFFF
+        xv = val[e0:e1][real].astype(np.float64)
         if table is not None:
-            xv = table[t.e_cls[e0:e1]].astype(np.float64) * xv
-        sums = np.bincount(t.e_lv[e0:e1], weights=xv, minlength=v1 - v0)
+            xv = table[t.e_cls[e0:e1][real]].astype(np.float64) * xv
+        sums = np.bincount(t.e_lv[e0:e1][real], weights=xv, minlength=v1 - v0)
         cum[v0:v1] = (np.float32(beta) * t.v_pcontact[v0:v1]) * sums.astype(np.float32)
     return val, cum
 
@@ -172,10 +201,12 @@ def emulate_pass2(t: TiledEdgeSet, cum: np.ndarray, n_agents: int, slice_agents:
                   weight_table: Optional[np.ndarray] = None):
     """Phases C+D: returns acc [A] = sum over the agent's edges of cum[venue] (x table[cls])."""
     S, J = t.n_slices, t.n_blocks
-    cval = np.zeros(t.n_edges, dtype=np.float32)
+    cval = np.zeros(t.n_slots, dtype=np.float32)
     for j in range(J):
         e0, e1 = t.blk_e0[j], t.blk_e0[j + 1]
-        c = cum[t.blk_v0[j] + t.e_lv[e0:e1].astype(np.int64)]
+        real = t.e_lv[e0:e1] != 0xFFFF
+        c = np.zeros(e1 - e0, dtype=np.float32)
+        c[real] = cum[t.blk_v0[j] + t.e_lv[e0:e1][real].astype(np.int64)]
         if weight_table is not None:
             c = weight_table[t.e_cls[e0:e1]] * c
         cval[e0:e1] = c

@@ -113,14 +113,18 @@ typedef struct gj_tiled_set {
   int32_t n_blocks;          /* J: venue blocks of this set                                  */
   int32_t max_block_venues;  /* largest block of this set (sizes the LDS of phases B/C)      */
   const int32_t* blk_v0;     /* device [J+1]   venue range of block j                        */
-  const int32_t* blk_e0;     /* device [J+1]   block-major edge range of block j             */
-  const uint16_t* e_lv;      /* device [E]     venue index local to its block, block-major   */
-  const uint8_t* e_cls;      /* device [E]     agent_class of the edge's agent, block-major
+  const int32_t* blk_e0;     /* device [J+1]   block-major SLOT range of block j; every block is
+                                               padded to a multiple of 8 slots (16-byte accesses) */
+  const uint16_t* e_lv;      /* device [slots] venue index local to its block, block-major;
+                                               0xFFFF marks a pad slot                        */
+  const uint8_t* e_cls;      /* device [slots] agent_class of the edge's agent, block-major
                                                (sets that carry leisure tables; else NULL)    */
   const uint16_t* a_la;      /* device [E]     agent index local to its slice, slice-major   */
   const int32_t* tile_sptr;  /* device [S*J+1] slice-major prefix: tile (s,j) = [sptr[s*J+j], sptr[s*J+j+1]) */
-  const int32_t* tile_jpos;  /* device [S*J]   block-major start of tile (s,j)               */
-  float* val;                /* device [E]     workspace: per-edge value (phase A->B, C->D)  */
+  const int32_t* tile_jpos;  /* device [S*J]   block-major start slot of tile (s,j)          */
+  const int32_t* chunk_ptr;  /* device [S+1]   first 64-edge chunk of slice s's slice-major segment */
+  const uint16_t* chunk_tile;/* device [chunks] block j holding the first edge of each chunk */
+  float* val;                /* device [slots] workspace: per-edge value (phase A->B, C->D)  */
 } gj_tiled_set;
 
 typedef struct gj_tiled {

@@ -24,10 +24,19 @@ def test_layout_and_emulation(A, V, E, sa, svmax, eb):
     cls = rng.integers(0, 200, A).astype(np.uint8)
     t = build_tiled("x", agent, venue, V, pc, S, sa, agent_class=cls, sv_max=svmax, eb_target=eb)
     J = t.n_blocks
-    assert t.blk_v0[0] == 0 and t.blk_v0[-1] == V and t.blk_e0[-1] == E and t.tile_sptr[-1] == E
+    assert t.blk_v0[0] == 0 and t.blk_v0[-1] == V and t.blk_e0[-1] == t.n_slots and t.tile_sptr[-1] == E
     assert (np.diff(t.blk_v0) <= svmax).all() and (np.diff(t.blk_v0) > 0).all()
     deg = np.bincount(venue, minlength=V)
-    assert np.array_equal(np.diff(t.blk_e0), np.add.reduceat(deg, t.blk_v0[:-1]))
+    blk_edges = np.add.reduceat(deg, t.blk_v0[:-1])
+    assert (t.blk_e0 % 8 == 0).all() and np.array_equal(np.diff(t.blk_e0), -(-blk_edges // 8) * 8)
+    assert (t.e_lv != 0xFFFF).sum() == E
+    # chunk table: the block of the first edge of every 64-edge chunk of every slice segment
+    seg = t.tile_sptr[0:S * J + 1:J]
+    for sl in range(S):
+        for c in range(t.chunk_ptr[sl], t.chunk_ptr[sl + 1]):
+            i = seg[sl] + 64 * (c - t.chunk_ptr[sl])
+            jj = int(t.chunk_tile[c])
+            assert t.tile_sptr[sl * J + jj] <= i < t.tile_sptr[sl * J + jj + 1]
     # every tile is contiguous in both orders and holds the same multiset of edges
     lens = np.diff(t.tile_sptr).reshape(S, J)
     assert lens.sum() == E
@@ -36,8 +45,7 @@ def test_layout_and_emulation(A, V, E, sa, svmax, eb):
     ref = np.float32(0.7) * pc * np.bincount(venue, weights=x[agent].astype(np.float64), minlength=V).astype(np.float32)
     assert np.allclose(cum, ref, rtol=1e-5, atol=1e-7)
     # val in block-major order is x[agent] of the edge stored there
-    order_key = np.sort(val)
-    assert np.allclose(order_key, np.sort(x[agent]))
+    assert np.allclose(np.sort(val[t.e_lv != 0xFFFF]), np.sort(x[agent]))
     acc = emulate_pass2(t, cum, A, sa)
     ref2 = np.bincount(agent, weights=cum[venue].astype(np.float64), minlength=A)
     assert np.allclose(acc, ref2, rtol=1e-5, atol=1e-6)
