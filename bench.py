@@ -42,6 +42,7 @@ def parse():
                     help="tiled: LDS propagation-blocked kernels (default); csr: deterministic CSR kernels")
     ap.add_argument("--sv-max", type=int, default=None)
     ap.add_argument("--eb-target", type=int, default=None)
+    ap.add_argument("--slice-agents", type=int, default=None, help="tiled: agents per slice (multiple of 64)")
     ap.add_argument("--edge-mult", type=float, default=1.0, help="experiments: memberships per agent x this")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
@@ -195,6 +196,9 @@ def main():
                 kw["sv_max"] = args.sv_max
             if args.eb_target:
                 kw["eb_target"] = args.eb_target
+            if args.slice_agents:
+                sa = args.slice_agents
+                kw["slices"] = (-(-world["n_agents"] // sa), sa)
         runner = SingleGpuHotPath(world, specs, betas, dev, seed=args.seed, layout=args.layout, **kw)
     t_setup = time.time() - t0
 

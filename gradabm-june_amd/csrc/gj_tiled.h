@@ -34,6 +34,8 @@ struct TileAArgs {
   TSetA sets[GJ_MAX_SETS];
   int32_t n_sets;
   int32_t slice_agents;
+  int32_t j_max;          // largest J over the sets: sizes the LDS tile-table rows
+  int32_t _pad;
   int64_t n_agents;
   const float* trans;
   const float* qtrans;    // == trans when no quarantine collection
@@ -48,15 +50,21 @@ __device__ __forceinline__ void load_slice(float* lds, const float* __restrict__
   for (int i = (n4 << 2) + tid; i < n_local; i += kTileThreads) lds[i] = src[base + i];
 }
 
-// Block-major slot of slice-major edge i of slice row `row`: the chunk table names the tile of the
-// chunk's first edge; a lane walks forward over the (few) tile boundaries inside the chunk.
-__device__ __forceinline__ int slot_of(const TSetA& T, int row, int j, int i) {
-  int hi = T.tile_sptr[row + j + 1];
-  while (i >= hi) {
-    ++j;
-    hi = T.tile_sptr[row + j + 1];
+// Block-major slot of slice-major edge i.  tb_s / tb_j are this slice's rows of the set's tile
+// tables, staged in LDS; the chunk table names the tile of the chunk's first edge and a lane walks
+// forward over the (few) tile boundaries inside its chunk.
+__device__ __forceinline__ int slot_of(const int* tb_s, const int* tb_j, int j, int i) {
+  while (i >= tb_s[j + 1]) ++j;
+  return tb_j[j] + (i - tb_s[j]);
+}
+
+__device__ __forceinline__ void stage_tile_rows(const TSetA& T, int row, int* tb_s, int* tb_j, int tid) {
+  __syncthreads();   // the previous set's lookups are done
+  for (int i = tid; i <= T.J; i += kTileThreads) {
+    tb_s[i] = T.tile_sptr[row + i];
+    if (i < T.J) tb_j[i] = T.tile_jpos[row + i];
   }
-  return T.tile_jpos[row + j] + (i - T.tile_sptr[row + j]);
+  __syncthreads();
 }
 
 // ---- phase A: scatter the slice's transmissions to every edge, in block-major tile order -------
@@ -67,6 +75,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_scatter(const TileAArgs A
   const int s = blockIdx.x;
   const int64_t base = (int64_t)s * A.slice_agents;
   const int n_local = (int)min((int64_t)A.slice_agents, A.n_agents - base);
+  int* tb_s = reinterpret_cast<int*>(lds_x + A.slice_agents);
+  int* tb_j = tb_s + A.j_max + 1;
   const bool two_sources = A.qtrans != A.trans;
   for (int pass = 0; pass < 2; ++pass) {
     // pass 0: sets that read q*transmission (or everything when there is one source); pass 1: raw sets
@@ -82,7 +92,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_scatter(const TileAArgs A
       const TSetA& T = A.sets[t];
       if (!T.active || (two_sources && T.raw != pass)) continue;
       const int row = s * T.J;
-      const int seg0 = T.tile_sptr[row], seg1 = T.tile_sptr[row + T.J];
+      stage_tile_rows(T, row, tb_s, tb_j, tid);
+      const int seg0 = tb_s[0], seg1 = tb_s[T.J];
       const int c_base = T.chunk_ptr[s];
       const int n_chunks = T.chunk_ptr[s + 1] - c_base;
       for (int c0 = wave * kUnroll; c0 < n_chunks; c0 += kTileWaves * kUnroll) {
@@ -96,7 +107,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_scatter(const TileAArgs A
         for (int u = 0; u < kUnroll; ++u) {
           if (la[u] >= 0) {
             const int i = seg0 + (c0 + u) * kWave + lane;
-            slot[u] = slot_of(T, row, T.chunk_tile[c_base + c0 + u], i);
+            slot[u] = slot_of(tb_s, tb_j, T.chunk_tile[c_base + c0 + u], i);
           }
         }
 #pragma unroll
@@ -257,6 +268,8 @@ struct TileDArgs {
   TSetA sets[GJ_MAX_SETS];
   int32_t n_sets;
   int32_t slice_agents;
+  int32_t j_max;
+  int32_t _pad;
   int64_t n_agents;
   const float* stage;
   float* susceptibility;
@@ -279,6 +292,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
   const int s = blockIdx.x;
   const int64_t base = (int64_t)s * D.slice_agents;
   const int n_local = (int)min((int64_t)D.slice_agents, D.n_agents - base);
+  int* tb_s = reinterpret_cast<int*>(lds_acc + D.slice_agents);
+  int* tb_j = tb_s + D.j_max + 1;
   for (int i = tid; i < n_local; i += kTileThreads) lds_acc[i] = 0.0f;
   __syncthreads();
   // ts = susc * (q * sum over masked sets + sum over raw sets): masked sets first, scale by q, raw sets last
@@ -287,7 +302,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
       const TSetA& T = D.sets[t];
       if (!T.active || T.raw != pass) continue;
       const int row = s * T.J;
-      const int seg0 = T.tile_sptr[row], seg1 = T.tile_sptr[row + T.J];
+      stage_tile_rows(T, row, tb_s, tb_j, tid);
+      const int seg0 = tb_s[0], seg1 = tb_s[T.J];
       const int c_base = T.chunk_ptr[s];
       const int n_chunks = T.chunk_ptr[s + 1] - c_base;
       for (int c0 = wave * kUnroll; c0 < n_chunks; c0 += kTileWaves * kUnroll) {
@@ -302,7 +318,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
         for (int u = 0; u < kUnroll; ++u) {
           if (la[u] >= 0) {
             const int i = seg0 + (c0 + u) * kWave + lane;
-            v[u] = T.val[slot_of(T, row, T.chunk_tile[c_base + c0 + u], i)];
+            v[u] = T.val[slot_of(tb_s, tb_j, T.chunk_tile[c_base + c0 + u], i)];
           }
         }
 #pragma unroll

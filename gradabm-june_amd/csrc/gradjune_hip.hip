@@ -640,8 +640,9 @@ static int allow_lds(K kernel, size_t bytes) {
   return GJ_OK;
 }
 
-static void fill_set_a(const gj_plan* plan, const gj_step_params* p, const Groups& G, TSetA* sets) {
+static int fill_set_a(const gj_plan* plan, const gj_step_params* p, const Groups& G, TSetA* sets) {
   const gj_tiled* T = plan->tiled;
+  int j_max = 1;
   for (int s = 0; s < GJ_MAX_SETS; ++s) sets[s] = TSetA{};
   for (int g = 0; g < G.n; ++g) {
     const int s = G.set[g];
@@ -655,7 +656,14 @@ static void fill_set_a(const gj_plan* plan, const gj_step_params* p, const Group
     sets[s].J = S.n_blocks;
     sets[s].active = (S.n_blocks > 0 && plan->sets[s].n_edges > 0) ? G.nk[g] : 0;
     sets[s].raw = p->nets[G.first[g]].mask_kind == GJ_MASK_RAW;
+    if (S.n_blocks > j_max) j_max = S.n_blocks;
   }
+  return j_max;
+}
+
+// LDS of phases A and D: one slice of fp32 + this slice's rows of the widest set's tile tables
+static size_t slice_lds(const gj_tiled* T, int j_max) {
+  return (size_t)T->slice_agents * sizeof(float) + (size_t)(2 * j_max + 2) * sizeof(int32_t);
 }
 
 static int tiled_scatter(const gj_plan* plan, const gj_agent_state* st, const gj_step_params* p, const Groups& G,
@@ -663,13 +671,13 @@ static int tiled_scatter(const gj_plan* plan, const gj_agent_state* st, const gj
   const gj_tiled* T = plan->tiled;
   if (plan->n_agents == 0 || G.n == 0) return GJ_OK;
   TileAArgs A;
-  fill_set_a(plan, p, G, A.sets);
+  A.j_max = fill_set_a(plan, p, G, A.sets);
   A.n_sets = plan->n_sets;
   A.slice_agents = T->slice_agents;
   A.n_agents = plan->n_agents;
   A.trans = st->transmission;
   A.qtrans = p->has_quarantine ? st->q_transmission : st->transmission;
-  const size_t lds = (size_t)T->slice_agents * sizeof(float);
+  const size_t lds = slice_lds(T, A.j_max);
   int rc = allow_lds(k_tile_scatter, lds);
   if (rc) return rc;
   hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)T->n_slices), dim3(kTileThreads), lds, stream, A);
@@ -729,7 +737,7 @@ static int tiled_agents(const gj_plan* plan, const gj_agent_state* st, const gj_
   const gj_tiled* T = plan->tiled;
   if (plan->n_agents == 0) return GJ_OK;
   TileDArgs D;
-  fill_set_a(plan, p, G, D.sets);
+  D.j_max = fill_set_a(plan, p, G, D.sets);
   D.n_sets = plan->n_sets;
   D.slice_agents = T->slice_agents;
   D.n_agents = plan->n_agents;
@@ -749,7 +757,7 @@ static int tiled_agents(const gj_plan* plan, const gj_agent_state* st, const gj_
   D.seed = p->seed;
   D.step = p->step;
   D.agent_offset = p->agent_offset;
-  const size_t lds = (size_t)T->slice_agents * sizeof(float);
+  const size_t lds = slice_lds(T, D.j_max);
   int rc = allow_lds(k_tile_agents, lds);
   if (rc) return rc;
   hipLaunchKernelGGL(k_tile_agents, dim3((unsigned)T->n_slices), dim3(kTileThreads), lds, stream, D);

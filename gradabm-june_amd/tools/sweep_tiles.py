@@ -1,0 +1,57 @@
+"""Experiment driver (GPU): time the tiled kernels of one world under several tile geometries.
+
+    python tools/sweep_tiles.py [preset] [agents]
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "gradabm-june_amd"))
+sys.path.insert(0, ROOT)
+
+import torch
+
+import bench as B
+import __graft_entry__ as entry
+from grad_june_amd.benchrun import SingleGpuHotPath
+from grad_june_amd.synthetic import make_world
+
+
+def main():
+    preset = sys.argv[1] if len(sys.argv) > 1 else "c3"
+    agents = int(sys.argv[2]) if len(sys.argv) > 2 else None
+    entry.build()
+    world = make_world(preset, n_agents=agents)
+    specs, betas = B.network_specs(world), B.betas_of(world)
+    dev = torch.device("cuda:0")
+    A = world["n_agents"]
+
+    def run(tag, layout="tiled", **kw):
+        r = SingleGpuHotPath(world, specs, betas, dev, seed=1, layout=layout, **kw)
+        for _ in range(3):
+            r.step()
+        torch.cuda.synchronize()
+        r.reset_timers()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            r.step(timed=True)
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / 20 * 1e3
+        print(tag, "ms/step %.3f" % el, {k: round(v, 3) for k, v in r.kernel_ms().items()}, flush=True)
+        del r
+        torch.cuda.empty_cache()
+
+    def sl(sa):
+        return (-(-A // sa), sa)
+
+    run("default")
+    run("sa19584", slices=sl(19584))
+    run("sv16k", sv_max=16384)
+    run("sa19584+sv16k", slices=sl(19584), sv_max=16384)
+    run("sa19584+sv16k+eb64k", slices=sl(19584), sv_max=16384, eb_target=65536)
+    run("sa9792+sv8k+eb64k", slices=sl(9792), sv_max=8192, eb_target=65536)
+
+
+if __name__ == "__main__":
+    main()
