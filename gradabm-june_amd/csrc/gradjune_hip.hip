@@ -901,6 +901,10 @@ int gj_step_phase(const gj_plan* plan, const gj_agent_state* state, const gj_ste
     case 2: return plan->tiled ? gj::tiled_venues(plan, params, G, 0, st) : GJ_OK;
     case 3: return plan->tiled ? gj::tiled_agents(plan, state, params, G, io, 1, st)
                                : gj::do_agent_gather(plan, state, params, G, io, 1, st);
+    case 4: return plan->tiled ? gj::tiled_agents(plan, state, params, G, io, 0, st)
+                               : gj::do_agent_gather(plan, state, params, G, io, 0, st);
+    case 5: return plan->tiled ? gj::tiled_venues(plan, params, G, 1, st) : GJ_OK;
+    case 6: return plan->tiled ? gj::tiled_venues(plan, params, G, 2, st) : GJ_OK;
     default: return GJ_E_RANGE;
   }
 }

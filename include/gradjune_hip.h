@@ -256,7 +256,9 @@ int gj_step(const gj_plan* plan, const gj_agent_state* state, const gj_step_para
 /* One launch group of gj_step at a time, for per-kernel timing (bench.py brackets each with HIP
  * events): phase 0 = transmission; 1 = pass-1 front (tiled: phase A scatter; CSR: venue reduce);
  * 2 = tiled phases B+C (CSR: nothing); 3 = pass-2 + epilogue + decision + state update.
- * Calling phases 0,1,2,3 in order is exactly gj_step.                                        */
+ * Calling phases 0,1,2,3 in order is exactly gj_step.  Diagnostic variants: 4 = phase 3 without
+ * the decision/state update (probabilities only); 5 / 6 = the tiled venue launch split into its
+ * B half (sums -> cum) and its C half (cum -> per-edge values).                                */
 int gj_step_phase(const gj_plan* plan, const gj_agent_state* state, const gj_step_params* params,
                   const gj_step_io* io, int phase, void* stream);
 

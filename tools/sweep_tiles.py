@@ -45,12 +45,29 @@ def main():
     def sl(sa):
         return (-(-A // sa), sa)
 
-    run("default")
-    run("sa19584", slices=sl(19584))
-    run("sv16k", sv_max=16384)
-    run("sa19584+sv16k", slices=sl(19584), sv_max=16384)
-    run("sa19584+sv16k+eb64k", slices=sl(19584), sv_max=16384, eb_target=65536)
-    run("sa9792+sv8k+eb64k", slices=sl(9792), sv_max=8192, eb_target=65536)
+    if os.environ.get("GJ_SWEEP", "geometry") == "geometry":
+        run("default")
+        run("sa19584", slices=sl(19584))
+        run("sa19584+sv16k+eb64k", slices=sl(19584), sv_max=16384, eb_target=65536)
+        return
+    # phase anatomy: diagnostic phases of gj_step_phase
+    r = SingleGpuHotPath(world, specs, betas, dev, seed=1, layout="tiled", slices=sl(19584), sv_max=16384, eb_target=65536)
+    for _ in range(3):
+        r.step()
+    from grad_june_amd.engine import HipTimer
+    t = HipTimer()
+    for label, phases in (("A scatter", [1]), ("B only", [5]), ("C only", [6]), ("B+C fused", [2]),
+                          ("D no sampling", [4]), ("D full", [3])):
+        p = r.params()
+        for ph in phases:
+            r.engine.step_phase(r.bufs, p, r.io, ph)
+        torch.cuda.synchronize()
+        t.start()
+        for _ in range(10):
+            for ph in phases:
+                r.engine.step_phase(r.bufs, p, r.io, ph)
+        t.stop()
+        print(label, "%.3f ms" % (t.elapsed_ms() / 10), flush=True)
 
 
 if __name__ == "__main__":
