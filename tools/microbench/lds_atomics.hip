@@ -10,8 +10,8 @@ constexpr int kIters = 256;
 
 template <int MODE>
 __global__ __launch_bounds__(1024) void k(const uint32_t* __restrict__ idx, float* out, int iters) {
-  __shared__ float lds[kN];
-  __shared__ unsigned long long lds64[MODE == 2 ? kN / 2 : 1];
+  __shared__ unsigned long long lds64[kN / 2];              // 128 KiB, viewed as fp32 or u64
+  float* lds = reinterpret_cast<float*>(lds64);
   for (int i = threadIdx.x; i < kN; i += 1024) lds[i] = 0.f;
   __syncthreads();
   float acc = 0.f;
