@@ -17,6 +17,20 @@ constexpr int kTileThreads = 1024;  // 16 waves: one workgroup per CU when the s
 constexpr int kTileWaves = kTileThreads / kWave;
 constexpr int kUnroll = 8;          // 64-edge chunks a wave keeps in flight (phases A and D)
 
+// LDS float atomics run at 0.33 lanes/clk/CU on gfx950 (measured, tools/microbench/lds_atomics.hip)
+// against 4.9 for ds_add_u64 and 7.3 for ds_add_u32, so the per-venue and per-agent sums are kept
+// in 64-bit fixed point (2^-36 resolution, range +-1.3e8): integer adds are order-independent, which
+// also makes both passes bitwise reproducible, and exact (no rounding inside a sum).
+typedef unsigned long long fx_t;
+constexpr float kFxScale = 68719476736.0f;            // 2^36
+constexpr double kFxInv = 1.0 / 68719476736.0;
+constexpr float kFxMax = 1.0e8f;
+__device__ __forceinline__ fx_t to_fx(float x) {
+  x = fminf(fmaxf(x, -kFxMax), kFxMax);               // also maps NaN to -kFxMax: finite, flagged by tests
+  return (fx_t)__float2ll_rn(x * kFxScale);
+}
+__device__ __forceinline__ float from_fx(fx_t v) { return (float)((double)(long long)v * kFxInv); }
+
 struct TSetA {            // what phases A and D need of one set
   const uint16_t* a_la;
   const int32_t* tile_sptr;
@@ -158,8 +172,9 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
   if (nk == 0) return;
   const int v0 = T.blk_v0[j], nv = T.blk_v0[j + 1] - v0;
   const int g0 = T.blk_e0[j] >> 3, g1 = T.blk_e0[j + 1] >> 3;   // groups of 8 slots
-  float* sums = lds_s;                       // [nk][nv]
-  float* tabs = lds_s + (size_t)nk * nv;     // [nk][200] pass-1 tables, then [nk][200] pass-2 weights
+  fx_t* sums = reinterpret_cast<fx_t*>(lds_s);                    // [nk][nv] fixed-point sums (phase B)
+  float* cumf = lds_s;                                            // cum of (k, lv) at float index 2*(k*nv+lv) (phase C)
+  float* tabs = lds_s + 2 * (size_t)nk * nv;  // [nk][200] pass-1 tables, then [nk][200] pass-2 weights
   if (T.leisure) {
     for (int i = tid; i < nk * 200; i += kTileThreads) {
       const int k = i / 200, c = i % 200;
@@ -172,7 +187,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
   const uint2* cls8 = reinterpret_cast<const uint2*>(T.e_cls);
   float4* val4 = reinterpret_cast<float4*>(T.val);
   if (B.mode != 2) {
-    for (int i = tid; i < nk * nv; i += kTileThreads) sums[i] = 0.0f;
+    for (int i = tid; i < nk * nv; i += kTileThreads) sums[i] = 0;
     __syncthreads();
     // B: each lane takes 8 consecutive slots (48 bytes in flight), merges runs of one venue in
     // registers and adds each run to the block's LDS sums
@@ -190,12 +205,12 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
           if (lv == cur) {
             acc += x[q];
           } else {
-            if (cur != 0xFFFF) atomicAdd(&sums[cur], acc);
+            if (cur != 0xFFFF) atomicAdd(&sums[cur], to_fx(acc));
             cur = lv;
             acc = x[q];
           }
         }
-        if (cur != 0xFFFF) atomicAdd(&sums[cur], acc);
+        if (cur != 0xFFFF) atomicAdd(&sums[cur], to_fx(acc));
       } else {
         const uint2 craw = cls8[g];
         const uint32_t cw[2] = {craw.x, craw.y};
@@ -210,12 +225,12 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
             if (lv == cur) {
               acc += xl;
             } else {
-              if (cur != 0xFFFF) atomicAdd(&sums[k * nv + cur], acc);
+              if (cur != 0xFFFF) atomicAdd(&sums[k * nv + cur], to_fx(acc));
               cur = lv;
               acc = xl;
             }
           }
-          if (cur != 0xFFFF) atomicAdd(&sums[k * nv + cur], acc);
+          if (cur != 0xFFFF) atomicAdd(&sums[k * nv + cur], to_fx(acc));
         }
       }
     }
@@ -223,15 +238,16 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
     for (int k = 0; k < nk; ++k) {
       const float beta = T.beta[k];
       for (int lv = tid; lv < nv; lv += kTileThreads) {
-        const float c = (beta * T.v_pc[v0 + lv]) * sums[k * nv + lv];
+        const float c = (beta * T.v_pc[v0 + lv]) * from_fx(sums[k * nv + lv]);
         T.cum[(int64_t)(v0 + lv) * T.stride + k] = c;
-        sums[k * nv + lv] = c;
+        cumf[2 * (k * nv + lv)] = c;      // low half of the lane's own 8-byte slot
       }
     }
     if (B.mode == 1) return;
   } else {
     for (int k = 0; k < nk; ++k)
-      for (int lv = tid; lv < nv; lv += kTileThreads) sums[k * nv + lv] = T.cum[(int64_t)(v0 + lv) * T.stride + k];
+      for (int lv = tid; lv < nv; lv += kTileThreads)
+        cumf[2 * (k * nv + lv)] = T.cum[(int64_t)(v0 + lv) * T.stride + k];
   }
   __syncthreads();
   // C: per slot, the venue's cum (leisure: weighted over the set's networks by the agent's class)
@@ -243,7 +259,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int lv = L.lv(q);
-        r[q] = (lv != 0xFFFF) ? sums[lv] : 0.0f;
+        r[q] = (lv != 0xFFFF) ? cumf[2 * lv] : 0.0f;
       }
     } else {
       const uint2 craw = cls8[g];
@@ -254,7 +270,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
         const int c = (cw[q >> 2] >> ((q & 3) * 8)) & 0xFF;
         float a = 0.0f;
         if (lv != 0xFFFF)
-          for (int k = 0; k < nk; ++k) a += tabs[nk * 200 + k * 200 + c] * sums[k * nv + lv];
+          for (int k = 0; k < nk; ++k) a += tabs[nk * 200 + k * 200 + c] * cumf[2 * (k * nv + lv)];
         r[q] = a;
       }
     }
@@ -286,7 +302,7 @@ struct TileDArgs {
 };
 
 __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D) {
-  extern __shared__ __align__(16) float lds_acc[];
+  extern __shared__ __align__(16) fx_t lds_acc[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid / kWave), lane = tid % kWave;
   const int s = blockIdx.x;
@@ -294,7 +310,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
   const int n_local = (int)min((int64_t)D.slice_agents, D.n_agents - base);
   int* tb_s = reinterpret_cast<int*>(lds_acc + D.slice_agents);
   int* tb_j = tb_s + D.j_max + 1;
-  for (int i = tid; i < n_local; i += kTileThreads) lds_acc[i] = 0.0f;
+  for (int i = tid; i < n_local; i += kTileThreads) lds_acc[i] = 0;
   __syncthreads();
   // ts = susc * (q * sum over masked sets + sum over raw sets): masked sets first, scale by q, raw sets last
   for (int pass = 0; pass < 2; ++pass) {
@@ -323,20 +339,20 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
         }
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u)
-          if (la[u] >= 0) atomicAdd(&lds_acc[la[u]], v[u]);
+          if (la[u] >= 0) atomicAdd(&lds_acc[la[u]], to_fx(v[u]));
       }
     }
     __syncthreads();
     if (pass == 0 && D.has_q) {
       for (int i = tid; i < n_local; i += kTileThreads)
-        lds_acc[i] = ((D.stage[base + i] < D.q_thr) ? 1.0f : 0.0f) * lds_acc[i];
+        if (!(D.stage[base + i] < D.q_thr)) lds_acc[i] = 0;
       __syncthreads();
     }
   }
   for (int i = tid; i < n_local; i += kTileThreads) {
     const int64_t a = base + i;
     float susc = D.susceptibility[a];
-    float ts = susc * lds_acc[i];
+    float ts = susc * from_fx(lds_acc[i]);
     if (D.trans_susc) D.trans_susc[a] = ts;
     ts = fminf(fmaxf(ts, 1e-6f), 100.0f);
     float p = expf(-ts * D.dt);

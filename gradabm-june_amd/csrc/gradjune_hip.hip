@@ -614,7 +614,7 @@ static int do_agent_gather(const gj_plan* plan, const gj_agent_state* st, const 
 // ------------------------------------------------------------------------------------------
 static int check_tiled(const gj_plan* plan) {
   const gj_tiled* T = plan->tiled;
-  if (T->n_slices < 1 || T->slice_agents < 64 || T->slice_agents % 64 || T->slice_agents > 40448) return GJ_E_PLAN;
+  if (T->n_slices < 1 || T->slice_agents < 64 || T->slice_agents % 64 || T->slice_agents > 19968) return GJ_E_PLAN;
   if ((int64_t)T->n_slices * T->slice_agents < plan->n_agents) return GJ_E_PLAN;
   if (plan->n_ext_agents != plan->n_agents) return GJ_E_PLAN;   // no halo agents in the tiled layout
   if (T->n_work < 0 || (T->n_work > 0 && !T->work)) return GJ_E_PLAN;
@@ -661,9 +661,10 @@ static int fill_set_a(const gj_plan* plan, const gj_step_params* p, const Groups
   return j_max;
 }
 
-// LDS of phases A and D: one slice of fp32 + this slice's rows of the widest set's tile tables
-static size_t slice_lds(const gj_tiled* T, int j_max) {
-  return (size_t)T->slice_agents * sizeof(float) + (size_t)(2 * j_max + 2) * sizeof(int32_t);
+// LDS of phases A and D: one slice (fp32 values in A, 64-bit fixed-point sums in D) + this slice's
+// rows of the widest set's tile tables
+static size_t slice_lds(const gj_tiled* T, int j_max, size_t elem) {
+  return (size_t)T->slice_agents * elem + (size_t)(2 * j_max + 2) * sizeof(int32_t);
 }
 
 static int tiled_scatter(const gj_plan* plan, const gj_agent_state* st, const gj_step_params* p, const Groups& G,
@@ -677,7 +678,7 @@ static int tiled_scatter(const gj_plan* plan, const gj_agent_state* st, const gj
   A.n_agents = plan->n_agents;
   A.trans = st->transmission;
   A.qtrans = p->has_quarantine ? st->q_transmission : st->transmission;
-  const size_t lds = slice_lds(T, A.j_max);
+  const size_t lds = slice_lds(T, A.j_max, sizeof(float));
   int rc = allow_lds(k_tile_scatter, lds);
   if (rc) return rc;
   hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)T->n_slices), dim3(kTileThreads), lds, stream, A);
@@ -719,7 +720,8 @@ static int tiled_venues(const gj_plan* plan, const gj_step_params* p, const Grou
     } else if (G.nk[g] != 1) {
       return GJ_E_PLAN;   // several networks on one set need per-network tables
     }
-    const size_t need = ((size_t)X.nk * S.max_block_venues + (X.leisure ? 2 * 200 * (size_t)X.nk : 0)) * sizeof(float);
+    const size_t need = (size_t)X.nk * S.max_block_venues * sizeof(fx_t) +
+                        (X.leisure ? 2 * 200 * (size_t)X.nk : 0) * sizeof(float);
     if (X.nk && need > lds) lds = need;
   }
   B.work = T->work;
@@ -757,7 +759,7 @@ static int tiled_agents(const gj_plan* plan, const gj_agent_state* st, const gj_
   D.seed = p->seed;
   D.step = p->step;
   D.agent_offset = p->agent_offset;
-  const size_t lds = slice_lds(T, D.j_max);
+  const size_t lds = slice_lds(T, D.j_max, sizeof(fx_t));
   int rc = allow_lds(k_tile_agents, lds);
   if (rc) return rc;
   hipLaunchKernelGGL(k_tile_agents, dim3((unsigned)T->n_slices), dim3(kTileThreads), lds, stream, D);

@@ -14,9 +14,9 @@ orders of magnitude faster, so the tiled layout arranges for every random access
 
 Per step and set, four streaming phases move 24 bytes per edge through HBM, all coalesced:
   A  (one workgroup per slice)   x[slice] -> LDS;  val[blockmajor pos] = x[a_la]
-  B  (one workgroup per block)   sums[e_lv] += val   (LDS float atomics), cum = beta*p_contact*sums
+  B  (one workgroup per block)   sums[e_lv] += val   (LDS 64-bit fixed-point atomics), cum = beta*p_contact*sums
   C  (same workgroup)            val[i] = cum[e_lv[i]]                (in place)
-  D  (one workgroup per slice)   acc[a_la] += val[blockmajor pos]     (LDS float atomics), epilogue
+  D  (one workgroup per slice)   acc[a_la] += val[blockmajor pos]     (LDS fixed-point atomics), epilogue
 This module builds the static arrays (numpy, host) and is exercised on the CPU by an emulation of
 the four phases (tests/test_tiling_host.py).
 """
@@ -27,8 +27,8 @@ from typing import List, Optional
 
 import numpy as np
 
-SA_MAX = 40448        # agents per slice: 158 KiB of LDS as fp32 (one 1024-thread workgroup per CU)
-SV_MAX = 32768        # venues per block (LDS fp32 sums; local venue index is 16-bit)
+SA_MAX = 19968        # agents per slice: 156 KiB of LDS as 64-bit fixed-point sums (phase D)
+SV_MAX = 16384        # venues per block (128 KiB of 64-bit sums in phase B; local venue index is 16-bit)
 EB_TARGET = 131072    # edges per block aimed for (work per workgroup of phases B/C)
 N_CU = 256
 PAD = 8               # block-major arrays: every block starts on a multiple of PAD slots

@@ -103,12 +103,13 @@ typedef struct gj_long_row {
  * random access of the two passes then hits LDS (a slice of transmissions / a block of venue
  * sums) and HBM only sees four coalesced streams per step (24 B per edge):
  *   A  one workgroup per slice :  val[block-major pos] = x_slice[a_la]
- *   B  one workgroup per block :  sums[e_lv] += val   (LDS float atomics); cum = beta*p_contact*sums
+ *   B  one workgroup per block :  sums[e_lv] += val   (LDS integer atomics); cum = beta*p_contact*sums
  *   C  same workgroup (fused)  :  val[i] = cum[e_lv[i]]          (in place)
  *   D  one workgroup per slice :  acc[a_la] += val[block-major pos]; epilogue a7-a9
  * A tile is contiguous in both the slice-major (s, j) and the block-major (j, s) edge order.
- * Sums are taken with LDS float atomics: results agree with the CSR path to fp32 rounding but
- * are not bitwise reproducible from run to run (the CSR path is).                            */
+ * Sums are accumulated with 64-bit fixed-point LDS atomics (resolution 2^-36, |value| < 1e8):
+ * integer adds are order-independent, so results are bitwise reproducible from run to run, and
+ * agree with the CSR path to fp32 rounding.                                                  */
 typedef struct gj_tiled_set {
   int32_t n_blocks;          /* J: venue blocks of this set                                  */
   int32_t max_block_venues;  /* largest block of this set (sizes the LDS of phases B/C)      */
@@ -129,7 +130,7 @@ typedef struct gj_tiled_set {
 
 typedef struct gj_tiled {
   int32_t n_slices;          /* S                                                            */
-  int32_t slice_agents;      /* SA (multiple of 64, <= 40448: one slice of fp32 fits LDS)    */
+  int32_t slice_agents;      /* SA (multiple of 64, <= 19968: one slice of 8-byte sums fits LDS) */
   int32_t _pad;
   int32_t n_work;            /* entries of `work`                                            */
   const int32_t* work;       /* device [2*n_work] (set, block) pairs, heaviest first         */
