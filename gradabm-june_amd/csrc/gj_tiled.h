@@ -15,7 +15,7 @@ namespace gj {
 
 constexpr int kTileThreads = 1024;  // 16 waves: one workgroup per CU when the slice fills LDS
 constexpr int kTileWaves = kTileThreads / kWave;
-constexpr int kUnroll = 8;          // 64-edge chunks a wave keeps in flight (phases A and D)
+constexpr int kUnroll = 16;         // 64-edge chunks a wave keeps in flight (phases A and D)
 
 // LDS float atomics run at 0.33 lanes/clk/CU on gfx950 (measured, tools/microbench/lds_atomics.hip)
 // against 4.9 for ds_add_u64 and 7.3 for ds_add_u32, so the per-venue and per-agent sums are kept
@@ -41,14 +41,14 @@ struct TSetA {            // what phases A and D need of one set
   int32_t J;
   int32_t active;         // networks active on the set in this step (0: skip)
   int32_t raw;            // 1: reads raw transmission / susceptibility weight (household)
-  int32_t _pad;
+  int32_t row_off;        // offset (ints) of this set's tile-table rows in the LDS row area
 };
 
 struct TileAArgs {
   TSetA sets[GJ_MAX_SETS];
   int32_t n_sets;
   int32_t slice_agents;
-  int32_t j_max;          // largest J over the sets: sizes the LDS tile-table rows
+  int32_t row_ints;       // LDS ints holding the active sets' tile-table rows
   int32_t _pad;
   int64_t n_agents;
   const float* trans;
@@ -72,13 +72,20 @@ __device__ __forceinline__ int slot_of(const int* tb_s, const int* tb_j, int j, 
   return tb_j[j] + (i - tb_s[j]);
 }
 
-__device__ __forceinline__ void stage_tile_rows(const TSetA& T, int row, int* tb_s, int* tb_j, int tid) {
-  __syncthreads();   // the previous set's lookups are done
-  for (int i = tid; i <= T.J; i += kTileThreads) {
-    tb_s[i] = T.tile_sptr[row + i];
-    if (i < T.J) tb_j[i] = T.tile_jpos[row + i];
+// This slice's rows of every active set's tile tables -> LDS (set t at offset T.row_off: J+1 prefix
+// entries, then J block-major starts).  Caller synchronises.
+__device__ __forceinline__ void stage_tile_rows(const TSetA* sets, int n_sets, int s, int* tb, int tid) {
+  for (int t = 0; t < n_sets; ++t) {
+    const TSetA& T = sets[t];
+    if (!T.active) continue;
+    const int row = s * T.J;
+    int* tb_s = tb + T.row_off;
+    int* tb_j = tb_s + T.J + 1;
+    for (int i = tid; i <= T.J; i += kTileThreads) {
+      tb_s[i] = T.tile_sptr[row + i];
+      if (i < T.J) tb_j[i] = T.tile_jpos[row + i];
+    }
   }
-  __syncthreads();
 }
 
 // ---- phase A: scatter the slice's transmissions to every edge, in block-major tile order -------
@@ -89,8 +96,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_scatter(const TileAArgs A
   const int s = blockIdx.x;
   const int64_t base = (int64_t)s * A.slice_agents;
   const int n_local = (int)min((int64_t)A.slice_agents, A.n_agents - base);
-  int* tb_s = reinterpret_cast<int*>(lds_x + A.slice_agents);
-  int* tb_j = tb_s + A.j_max + 1;
+  int* tb = reinterpret_cast<int*>(lds_x + A.slice_agents);
+  stage_tile_rows(A.sets, A.n_sets, s, tb, tid);
   const bool two_sources = A.qtrans != A.trans;
   for (int pass = 0; pass < 2; ++pass) {
     // pass 0: sets that read q*transmission (or everything when there is one source); pass 1: raw sets
@@ -105,8 +112,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_scatter(const TileAArgs A
     for (int t = 0; t < A.n_sets; ++t) {
       const TSetA& T = A.sets[t];
       if (!T.active || (two_sources && T.raw != pass)) continue;
-      const int row = s * T.J;
-      stage_tile_rows(T, row, tb_s, tb_j, tid);
+      const int* tb_s = tb + T.row_off;
+      const int* tb_j = tb_s + T.J + 1;
       const int seg0 = tb_s[0], seg1 = tb_s[T.J];
       const int c_base = T.chunk_ptr[s];
       const int n_chunks = T.chunk_ptr[s + 1] - c_base;
@@ -191,6 +198,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
     __syncthreads();
     // B: each lane takes 8 consecutive slots (48 bytes in flight), merges runs of one venue in
     // registers and adds each run to the block's LDS sums
+#pragma unroll 2
     for (int g = g0 + tid; g < g1; g += kTileThreads) {
       const uint4 raw = lv8[g];
       const float4 xa = val4[2 * g], xb = val4[2 * g + 1];
@@ -251,6 +259,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
   }
   __syncthreads();
   // C: per slot, the venue's cum (leisure: weighted over the set's networks by the agent's class)
+#pragma unroll 2
   for (int g = g0 + tid; g < g1; g += kTileThreads) {
     const uint4 raw = lv8[g];
     const Slots8 L{{raw.x, raw.y, raw.z, raw.w}};
@@ -284,7 +293,7 @@ struct TileDArgs {
   TSetA sets[GJ_MAX_SETS];
   int32_t n_sets;
   int32_t slice_agents;
-  int32_t j_max;
+  int32_t row_ints;
   int32_t _pad;
   int64_t n_agents;
   const float* stage;
@@ -308,8 +317,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
   const int s = blockIdx.x;
   const int64_t base = (int64_t)s * D.slice_agents;
   const int n_local = (int)min((int64_t)D.slice_agents, D.n_agents - base);
-  int* tb_s = reinterpret_cast<int*>(lds_acc + D.slice_agents);
-  int* tb_j = tb_s + D.j_max + 1;
+  int* tb = reinterpret_cast<int*>(lds_acc + D.slice_agents);
+  stage_tile_rows(D.sets, D.n_sets, s, tb, tid);
   for (int i = tid; i < n_local; i += kTileThreads) lds_acc[i] = 0;
   __syncthreads();
   // ts = susc * (q * sum over masked sets + sum over raw sets): masked sets first, scale by q, raw sets last
@@ -317,8 +326,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
     for (int t = 0; t < D.n_sets; ++t) {
       const TSetA& T = D.sets[t];
       if (!T.active || T.raw != pass) continue;
-      const int row = s * T.J;
-      stage_tile_rows(T, row, tb_s, tb_j, tid);
+      const int* tb_s = tb + T.row_off;
+      const int* tb_j = tb_s + T.J + 1;
       const int seg0 = tb_s[0], seg1 = tb_s[T.J];
       const int c_base = T.chunk_ptr[s];
       const int n_chunks = T.chunk_ptr[s + 1] - c_base;
