@@ -15,7 +15,7 @@ namespace gj {
 
 constexpr int kTileThreads = 1024;  // 16 waves: one workgroup per CU when the slice fills LDS
 constexpr int kTileWaves = kTileThreads / kWave;
-constexpr int kUnroll = 16;         // 64-edge chunks a wave keeps in flight (phases A and D)
+constexpr int kUnroll = 8;          // 64-edge chunks a wave keeps in flight (phases A and D)
 
 // LDS float atomics run at 0.33 lanes/clk/CU on gfx950 (measured, tools/microbench/lds_atomics.hip)
 // against 4.9 for ds_add_u64 and 7.3 for ds_add_u32, so the per-venue and per-agent sums are kept
@@ -41,14 +41,14 @@ struct TSetA {            // what phases A and D need of one set
   int32_t J;
   int32_t active;         // networks active on the set in this step (0: skip)
   int32_t raw;            // 1: reads raw transmission / susceptibility weight (household)
-  int32_t row_off;        // offset (ints) of this set's tile-table rows in the LDS row area
+  int32_t _pad;
 };
 
 struct TileAArgs {
   TSetA sets[GJ_MAX_SETS];
   int32_t n_sets;
   int32_t slice_agents;
-  int32_t row_ints;       // LDS ints holding the active sets' tile-table rows
+  int32_t j_max;          // largest J over the sets: sizes the LDS tile-table rows
   int32_t _pad;
   int64_t n_agents;
   const float* trans;
@@ -72,20 +72,13 @@ __device__ __forceinline__ int slot_of(const int* tb_s, const int* tb_j, int j, 
   return tb_j[j] + (i - tb_s[j]);
 }
 
-// This slice's rows of every active set's tile tables -> LDS (set t at offset T.row_off: J+1 prefix
-// entries, then J block-major starts).  Caller synchronises.
-__device__ __forceinline__ void stage_tile_rows(const TSetA* sets, int n_sets, int s, int* tb, int tid) {
-  for (int t = 0; t < n_sets; ++t) {
-    const TSetA& T = sets[t];
-    if (!T.active) continue;
-    const int row = s * T.J;
-    int* tb_s = tb + T.row_off;
-    int* tb_j = tb_s + T.J + 1;
-    for (int i = tid; i <= T.J; i += kTileThreads) {
-      tb_s[i] = T.tile_sptr[row + i];
-      if (i < T.J) tb_j[i] = T.tile_jpos[row + i];
-    }
+__device__ __forceinline__ void stage_tile_rows(const TSetA& T, int row, int* tb_s, int* tb_j, int tid) {
+  __syncthreads();   // the previous set's lookups are done
+  for (int i = tid; i <= T.J; i += kTileThreads) {
+    tb_s[i] = T.tile_sptr[row + i];
+    if (i < T.J) tb_j[i] = T.tile_jpos[row + i];
   }
+  __syncthreads();
 }
 
 // ---- phase A: scatter the slice's transmissions to every edge, in block-major tile order -------
@@ -96,8 +89,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_scatter(const TileAArgs A
   const int s = blockIdx.x;
   const int64_t base = (int64_t)s * A.slice_agents;
   const int n_local = (int)min((int64_t)A.slice_agents, A.n_agents - base);
-  int* tb = reinterpret_cast<int*>(lds_x + A.slice_agents);
-  stage_tile_rows(A.sets, A.n_sets, s, tb, tid);
+  int* tb_s = reinterpret_cast<int*>(lds_x + A.slice_agents);
+  int* tb_j = tb_s + A.j_max + 1;
   const bool two_sources = A.qtrans != A.trans;
   for (int pass = 0; pass < 2; ++pass) {
     // pass 0: sets that read q*transmission (or everything when there is one source); pass 1: raw sets
@@ -112,28 +105,28 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_scatter(const TileAArgs A
     for (int t = 0; t < A.n_sets; ++t) {
       const TSetA& T = A.sets[t];
       if (!T.active || (two_sources && T.raw != pass)) continue;
-      const int* tb_s = tb + T.row_off;
-      const int* tb_j = tb_s + T.J + 1;
+      const int row = s * T.J;
+      stage_tile_rows(T, row, tb_s, tb_j, tid);
       const int seg0 = tb_s[0], seg1 = tb_s[T.J];
       const int c_base = T.chunk_ptr[s];
       const int n_chunks = T.chunk_ptr[s + 1] - c_base;
       for (int c0 = wave * kUnroll; c0 < n_chunks; c0 += kTileWaves * kUnroll) {
         int la[kUnroll], slot[kUnroll];
+        bool ok[kUnroll];
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
           const int i = seg0 + (c0 + u) * kWave + lane;
-          la[u] = (c0 + u < n_chunks && i < seg1) ? (int)T.a_la[i] : -1;
+          ok[u] = (c0 + u < n_chunks) && (i < seg1);
+          la[u] = ok[u] ? (int)T.a_la[i] : 0;
         }
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-          if (la[u] >= 0) {
-            const int i = seg0 + (c0 + u) * kWave + lane;
-            slot[u] = slot_of(tb_s, tb_j, T.chunk_tile[c_base + c0 + u], i);
-          }
+        for (int u = 0; u < kUnroll; ++u) {   // slots depend on the position only: overlaps the loads above
+          const int i = seg0 + (c0 + u) * kWave + lane;
+          slot[u] = ok[u] ? slot_of(tb_s, tb_j, T.chunk_tile[c_base + c0 + u], i) : 0;
         }
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u)
-          if (la[u] >= 0) T.val[slot[u]] = lds_x[la[u]];
+          if (ok[u]) T.val[slot[u]] = lds_x[la[u]];
       }
     }
   }
@@ -198,7 +191,6 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
     __syncthreads();
     // B: each lane takes 8 consecutive slots (48 bytes in flight), merges runs of one venue in
     // registers and adds each run to the block's LDS sums
-#pragma unroll 2
     for (int g = g0 + tid; g < g1; g += kTileThreads) {
       const uint4 raw = lv8[g];
       const float4 xa = val4[2 * g], xb = val4[2 * g + 1];
@@ -259,7 +251,6 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
   }
   __syncthreads();
   // C: per slot, the venue's cum (leisure: weighted over the set's networks by the agent's class)
-#pragma unroll 2
   for (int g = g0 + tid; g < g1; g += kTileThreads) {
     const uint4 raw = lv8[g];
     const Slots8 L{{raw.x, raw.y, raw.z, raw.w}};
@@ -293,7 +284,7 @@ struct TileDArgs {
   TSetA sets[GJ_MAX_SETS];
   int32_t n_sets;
   int32_t slice_agents;
-  int32_t row_ints;
+  int32_t j_max;
   int32_t _pad;
   int64_t n_agents;
   const float* stage;
@@ -317,8 +308,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
   const int s = blockIdx.x;
   const int64_t base = (int64_t)s * D.slice_agents;
   const int n_local = (int)min((int64_t)D.slice_agents, D.n_agents - base);
-  int* tb = reinterpret_cast<int*>(lds_acc + D.slice_agents);
-  stage_tile_rows(D.sets, D.n_sets, s, tb, tid);
+  int* tb_s = reinterpret_cast<int*>(lds_acc + D.slice_agents);
+  int* tb_j = tb_s + D.j_max + 1;
   for (int i = tid; i < n_local; i += kTileThreads) lds_acc[i] = 0;
   __syncthreads();
   // ts = susc * (q * sum over masked sets + sum over raw sets): masked sets first, scale by q, raw sets last
@@ -326,29 +317,29 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
     for (int t = 0; t < D.n_sets; ++t) {
       const TSetA& T = D.sets[t];
       if (!T.active || T.raw != pass) continue;
-      const int* tb_s = tb + T.row_off;
-      const int* tb_j = tb_s + T.J + 1;
+      const int row = s * T.J;
+      stage_tile_rows(T, row, tb_s, tb_j, tid);
       const int seg0 = tb_s[0], seg1 = tb_s[T.J];
       const int c_base = T.chunk_ptr[s];
       const int n_chunks = T.chunk_ptr[s + 1] - c_base;
       for (int c0 = wave * kUnroll; c0 < n_chunks; c0 += kTileWaves * kUnroll) {
         int la[kUnroll];
         float v[kUnroll];
+        bool ok[kUnroll];
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
           const int i = seg0 + (c0 + u) * kWave + lane;
-          la[u] = (c0 + u < n_chunks && i < seg1) ? (int)T.a_la[i] : -1;
+          ok[u] = (c0 + u < n_chunks) && (i < seg1);
+          la[u] = ok[u] ? (int)T.a_la[i] : 0;
         }
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-          if (la[u] >= 0) {
-            const int i = seg0 + (c0 + u) * kWave + lane;
-            v[u] = T.val[slot_of(tb_s, tb_j, T.chunk_tile[c_base + c0 + u], i)];
-          }
+        for (int u = 0; u < kUnroll; ++u) {   // the slot depends on the position only: both loads overlap
+          const int i = seg0 + (c0 + u) * kWave + lane;
+          v[u] = ok[u] ? T.val[slot_of(tb_s, tb_j, T.chunk_tile[c_base + c0 + u], i)] : 0.0f;
         }
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u)
-          if (la[u] >= 0) atomicAdd(&lds_acc[la[u]], to_fx(v[u]));
+          if (ok[u]) atomicAdd(&lds_acc[la[u]], to_fx(v[u]));
       }
     }
     __syncthreads();
@@ -358,9 +349,23 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
       __syncthreads();
     }
   }
-  for (int i = tid; i < n_local; i += kTileThreads) {
+  constexpr int kEp = 4;   // agents per lane whose loads are issued together
+  for (int i0 = tid; i0 < n_local; i0 += kEp * kTileThreads) {
+    float susc_b[kEp], e0_b[kEp], e1_b[kEp];
+#pragma unroll
+    for (int u = 0; u < kEp; ++u) {
+      const int i = i0 + u * kTileThreads;
+      const bool ok = i < n_local;
+      susc_b[u] = ok ? D.susceptibility[base + i] : 0.0f;
+      e0_b[u] = (ok && D.sample && D.exp_noise) ? D.exp_noise[base + i] : 1.0f;
+      e1_b[u] = (ok && D.sample && D.exp_noise) ? D.exp_noise[D.n_agents + base + i] : 1.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < kEp; ++u) {
+    const int i = i0 + u * kTileThreads;
+    if (i >= n_local) continue;
     const int64_t a = base + i;
-    float susc = D.susceptibility[a];
+    float susc = susc_b[u];
     float ts = susc * from_fx(lds_acc[i]);
     if (D.trans_susc) D.trans_susc[a] = ts;
     ts = fminf(fmaxf(ts, 1e-6f), 100.0f);
@@ -368,13 +373,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
     p = fminf(fmaxf(p, 0.0f), 1.0f);
     if (D.not_infected_probs) D.not_infected_probs[a] = p;
     if (!D.sample) continue;
-    float e0, e1;
-    if (D.exp_noise) {
-      e0 = D.exp_noise[a];
-      e1 = D.exp_noise[D.n_agents + a];
-    } else {
-      exp_pair(D.seed, D.step, D.agent_offset + a, e0, e1);
-    }
+    float e0 = e0_b[u], e1 = e1_b[u];
+    if (!D.exp_noise) exp_pair(D.seed, D.step, D.agent_offset + a, e0, e1);
     const float nw = gumbel_new_infected(p, e0, e1);
     if (D.new_infected) D.new_infected[a] = nw;
     if (nw != 0.0f) {
@@ -383,6 +383,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
       D.susceptibility[a] = susc;
       D.is_infected[a] = inf;
       D.infection_time[a] = t_inf;
+    }
     }
   }
 }

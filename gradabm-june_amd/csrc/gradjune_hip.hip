@@ -640,10 +640,9 @@ static int allow_lds(K kernel, size_t bytes) {
   return GJ_OK;
 }
 
-// returns the LDS ints needed for the active sets' tile-table rows
 static int fill_set_a(const gj_plan* plan, const gj_step_params* p, const Groups& G, TSetA* sets) {
   const gj_tiled* T = plan->tiled;
-  int row_ints = 0;
+  int j_max = 1;
   for (int s = 0; s < GJ_MAX_SETS; ++s) sets[s] = TSetA{};
   for (int g = 0; g < G.n; ++g) {
     const int s = G.set[g];
@@ -657,18 +656,15 @@ static int fill_set_a(const gj_plan* plan, const gj_step_params* p, const Groups
     sets[s].J = S.n_blocks;
     sets[s].active = (S.n_blocks > 0 && plan->sets[s].n_edges > 0) ? G.nk[g] : 0;
     sets[s].raw = p->nets[G.first[g]].mask_kind == GJ_MASK_RAW;
-    if (sets[s].active) {
-      sets[s].row_off = row_ints;
-      row_ints += 2 * S.n_blocks + 1;
-    }
+    if (S.n_blocks > j_max) j_max = S.n_blocks;
   }
-  return row_ints;
+  return j_max;
 }
 
 // LDS of phases A and D: one slice (fp32 values in A, 64-bit fixed-point sums in D) + this slice's
 // rows of the widest set's tile tables
-static size_t slice_lds(const gj_tiled* T, int row_ints, size_t elem) {
-  return (size_t)T->slice_agents * elem + (size_t)(row_ints + 2) * sizeof(int32_t);
+static size_t slice_lds(const gj_tiled* T, int j_max, size_t elem) {
+  return (size_t)T->slice_agents * elem + (size_t)(2 * j_max + 2) * sizeof(int32_t);
 }
 
 static int tiled_scatter(const gj_plan* plan, const gj_agent_state* st, const gj_step_params* p, const Groups& G,
@@ -676,13 +672,13 @@ static int tiled_scatter(const gj_plan* plan, const gj_agent_state* st, const gj
   const gj_tiled* T = plan->tiled;
   if (plan->n_agents == 0 || G.n == 0) return GJ_OK;
   TileAArgs A;
-  A.row_ints = fill_set_a(plan, p, G, A.sets);
+  A.j_max = fill_set_a(plan, p, G, A.sets);
   A.n_sets = plan->n_sets;
   A.slice_agents = T->slice_agents;
   A.n_agents = plan->n_agents;
   A.trans = st->transmission;
   A.qtrans = p->has_quarantine ? st->q_transmission : st->transmission;
-  const size_t lds = slice_lds(T, A.row_ints, sizeof(float));
+  const size_t lds = slice_lds(T, A.j_max, sizeof(float));
   int rc = allow_lds(k_tile_scatter, lds);
   if (rc) return rc;
   hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)T->n_slices), dim3(kTileThreads), lds, stream, A);
@@ -743,7 +739,7 @@ static int tiled_agents(const gj_plan* plan, const gj_agent_state* st, const gj_
   const gj_tiled* T = plan->tiled;
   if (plan->n_agents == 0) return GJ_OK;
   TileDArgs D;
-  D.row_ints = fill_set_a(plan, p, G, D.sets);
+  D.j_max = fill_set_a(plan, p, G, D.sets);
   D.n_sets = plan->n_sets;
   D.slice_agents = T->slice_agents;
   D.n_agents = plan->n_agents;
@@ -763,7 +759,7 @@ static int tiled_agents(const gj_plan* plan, const gj_agent_state* st, const gj_
   D.seed = p->seed;
   D.step = p->step;
   D.agent_offset = p->agent_offset;
-  const size_t lds = slice_lds(T, D.row_ints, sizeof(fx_t));
+  const size_t lds = slice_lds(T, D.j_max, sizeof(fx_t));
   int rc = allow_lds(k_tile_agents, lds);
   if (rc) return rc;
   hipLaunchKernelGGL(k_tile_agents, dim3((unsigned)T->n_slices), dim3(kTileThreads), lds, stream, D);

@@ -27,7 +27,7 @@ from typing import List, Optional
 
 import numpy as np
 
-SA_MAX = 18432        # agents per slice: 144 KiB of LDS as 64-bit fixed-point sums (phase D) + tile rows
+SA_MAX = 19968        # agents per slice: 156 KiB of LDS as 64-bit fixed-point sums (phase D)
 SV_MAX = 16384        # venues per block (128 KiB of 64-bit sums in phase B; local venue index is 16-bit)
 EB_TARGET = 131072    # edges per block aimed for (work per workgroup of phases B/C)
 N_CU = 256

@@ -66,7 +66,7 @@ def test_empty_set_and_slice_choice():
     assert t.n_blocks == 1 and t.n_edges == 0 and t.blk_v0.tolist() == [0, 10]
     for n in (1, 100, 769, 10_000, 1_000_000, 10_000_000, 25_000_000):
         S, SA = choose_slices(n)
-        assert S * SA >= n and (S - 1) * SA < n and SA <= 18432
-    assert choose_slices(10_000_000)[0] in (767, 768)
+        assert S * SA >= n and (S - 1) * SA < n and SA <= 19968
+    assert choose_slices(10_000_000)[0] in (511, 512)
     b = venue_blocks(np.array([5, 5, 100000, 5, 5]), sv_max=2, eb_target=50)
     assert b.tolist() == [0, 2, 3, 5]
