@@ -36,7 +36,7 @@ struct TSetA {            // what phases A and D need of one set
   const int32_t* tile_sptr;
   const int32_t* tile_jpos;
   const int32_t* chunk_ptr;
-  const uint16_t* chunk_tile;
+  const int4* chunk_desc;
   float* val;
   int32_t J;
   int32_t active;         // networks active on the set in this step (0: skip)
@@ -48,8 +48,6 @@ struct TileAArgs {
   TSetA sets[GJ_MAX_SETS];
   int32_t n_sets;
   int32_t slice_agents;
-  int32_t j_max;          // largest J over the sets: sizes the LDS tile-table rows
-  int32_t _pad;
   int64_t n_agents;
   const float* trans;
   const float* qtrans;    // == trans when no quarantine collection
@@ -64,21 +62,16 @@ __device__ __forceinline__ void load_slice(float* lds, const float* __restrict__
   for (int i = (n4 << 2) + tid; i < n_local; i += kTileThreads) lds[i] = src[base + i];
 }
 
-// Block-major slot of slice-major edge i.  tb_s / tb_j are this slice's rows of the set's tile
-// tables, staged in LDS; the chunk table names the tile of the chunk's first edge and a lane walks
-// forward over the (few) tile boundaries inside its chunk.
-__device__ __forceinline__ int slot_of(const int* tb_s, const int* tb_j, int j, int i) {
-  while (i >= tb_s[j + 1]) ++j;
-  return tb_j[j] + (i - tb_s[j]);
-}
-
-__device__ __forceinline__ void stage_tile_rows(const TSetA& T, int row, int* tb_s, int* tb_j, int tid) {
-  __syncthreads();   // the previous set's lookups are done
-  for (int i = tid; i <= T.J; i += kTileThreads) {
-    tb_s[i] = T.tile_sptr[row + i];
-    if (i < T.J) tb_j[i] = T.tile_jpos[row + i];
-  }
-  __syncthreads();
+// Block-major slot of lane `lane` of a 64-edge chunk (descriptor d: slot0, slot1, split | multi<<16, j0;
+// see tiling.py).  The common case is pure register arithmetic on a wave-uniform descriptor; a chunk
+// that spans more than two (tiny) tiles walks the tile tables.
+__device__ __forceinline__ int chunk_slot(const TSetA& T, const int4 d, int row, int i, int lane) {
+  const int split = d.z & 0xFFFF;
+  if (lane < split) return d.x + lane;
+  if (!(d.z >> 16)) return d.y + (lane - split);
+  int j = d.w;
+  while (i >= T.tile_sptr[row + j + 1]) ++j;
+  return T.tile_jpos[row + j] + (i - T.tile_sptr[row + j]);
 }
 
 // ---- phase A: scatter the slice's transmissions to every edge, in block-major tile order -------
@@ -89,8 +82,6 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_scatter(const TileAArgs A
   const int s = blockIdx.x;
   const int64_t base = (int64_t)s * A.slice_agents;
   const int n_local = (int)min((int64_t)A.slice_agents, A.n_agents - base);
-  int* tb_s = reinterpret_cast<int*>(lds_x + A.slice_agents);
-  int* tb_j = tb_s + A.j_max + 1;
   const bool two_sources = A.qtrans != A.trans;
   for (int pass = 0; pass < 2; ++pass) {
     // pass 0: sets that read q*transmission (or everything when there is one source); pass 1: raw sets
@@ -106,27 +97,24 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_scatter(const TileAArgs A
       const TSetA& T = A.sets[t];
       if (!T.active || (two_sources && T.raw != pass)) continue;
       const int row = s * T.J;
-      stage_tile_rows(T, row, tb_s, tb_j, tid);
-      const int seg0 = tb_s[0], seg1 = tb_s[T.J];
+      const int seg0 = T.tile_sptr[row], seg1 = T.tile_sptr[row + T.J];
       const int c_base = T.chunk_ptr[s];
       const int n_chunks = T.chunk_ptr[s + 1] - c_base;
       for (int c0 = wave * kUnroll; c0 < n_chunks; c0 += kTileWaves * kUnroll) {
-        int la[kUnroll], slot[kUnroll];
-        bool ok[kUnroll];
+        int la[kUnroll];
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
           const int i = seg0 + (c0 + u) * kWave + lane;
-          ok[u] = (c0 + u < n_chunks) && (i < seg1);
-          la[u] = ok[u] ? (int)T.a_la[i] : 0;
+          la[u] = (c0 + u < n_chunks && i < seg1) ? (int)T.a_la[i] : -1;
         }
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {   // slots depend on the position only: overlaps the loads above
-          const int i = seg0 + (c0 + u) * kWave + lane;
-          slot[u] = ok[u] ? slot_of(tb_s, tb_j, T.chunk_tile[c_base + c0 + u], i) : 0;
+        for (int u = 0; u < kUnroll; ++u) {
+          if (c0 + u < n_chunks) {
+            const int4 d = T.chunk_desc[c_base + c0 + u];
+            const int i = seg0 + (c0 + u) * kWave + lane;
+            if (la[u] >= 0) T.val[chunk_slot(T, d, row, i, lane)] = lds_x[la[u]];
+          }
         }
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u)
-          if (ok[u]) T.val[slot[u]] = lds_x[la[u]];
       }
     }
   }
@@ -284,8 +272,6 @@ struct TileDArgs {
   TSetA sets[GJ_MAX_SETS];
   int32_t n_sets;
   int32_t slice_agents;
-  int32_t j_max;
-  int32_t _pad;
   int64_t n_agents;
   const float* stage;
   float* susceptibility;
@@ -308,8 +294,6 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
   const int s = blockIdx.x;
   const int64_t base = (int64_t)s * D.slice_agents;
   const int n_local = (int)min((int64_t)D.slice_agents, D.n_agents - base);
-  int* tb_s = reinterpret_cast<int*>(lds_acc + D.slice_agents);
-  int* tb_j = tb_s + D.j_max + 1;
   for (int i = tid; i < n_local; i += kTileThreads) lds_acc[i] = 0;
   __syncthreads();
   // ts = susc * (q * sum over masked sets + sum over raw sets): masked sets first, scale by q, raw sets last
@@ -318,28 +302,26 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
       const TSetA& T = D.sets[t];
       if (!T.active || T.raw != pass) continue;
       const int row = s * T.J;
-      stage_tile_rows(T, row, tb_s, tb_j, tid);
-      const int seg0 = tb_s[0], seg1 = tb_s[T.J];
+      const int seg0 = T.tile_sptr[row], seg1 = T.tile_sptr[row + T.J];
       const int c_base = T.chunk_ptr[s];
       const int n_chunks = T.chunk_ptr[s + 1] - c_base;
       for (int c0 = wave * kUnroll; c0 < n_chunks; c0 += kTileWaves * kUnroll) {
         int la[kUnroll];
         float v[kUnroll];
-        bool ok[kUnroll];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
+        for (int u = 0; u < kUnroll; ++u) {   // both loads of an edge depend on its position only
           const int i = seg0 + (c0 + u) * kWave + lane;
-          ok[u] = (c0 + u < n_chunks) && (i < seg1);
-          la[u] = ok[u] ? (int)T.a_la[i] : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {   // the slot depends on the position only: both loads overlap
-          const int i = seg0 + (c0 + u) * kWave + lane;
-          v[u] = ok[u] ? T.val[slot_of(tb_s, tb_j, T.chunk_tile[c_base + c0 + u], i)] : 0.0f;
+          const bool ok = (c0 + u < n_chunks) && (i < seg1);
+          la[u] = ok ? (int)T.a_la[i] : -1;
+          v[u] = 0.0f;
+          if (c0 + u < n_chunks) {
+            const int4 d = T.chunk_desc[c_base + c0 + u];
+            if (ok) v[u] = T.val[chunk_slot(T, d, row, i, lane)];
+          }
         }
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u)
-          if (ok[u]) atomicAdd(&lds_acc[la[u]], to_fx(v[u]));
+          if (la[u] >= 0) atomicAdd(&lds_acc[la[u]], to_fx(v[u]));
       }
     }
     __syncthreads();
@@ -362,28 +344,28 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
     }
 #pragma unroll
     for (int u = 0; u < kEp; ++u) {
-    const int i = i0 + u * kTileThreads;
-    if (i >= n_local) continue;
-    const int64_t a = base + i;
-    float susc = susc_b[u];
-    float ts = susc * from_fx(lds_acc[i]);
-    if (D.trans_susc) D.trans_susc[a] = ts;
-    ts = fminf(fmaxf(ts, 1e-6f), 100.0f);
-    float p = expf(-ts * D.dt);
-    p = fminf(fmaxf(p, 0.0f), 1.0f);
-    if (D.not_infected_probs) D.not_infected_probs[a] = p;
-    if (!D.sample) continue;
-    float e0 = e0_b[u], e1 = e1_b[u];
-    if (!D.exp_noise) exp_pair(D.seed, D.step, D.agent_offset + a, e0, e1);
-    const float nw = gumbel_new_infected(p, e0, e1);
-    if (D.new_infected) D.new_infected[a] = nw;
-    if (nw != 0.0f) {
-      float inf = D.is_infected[a], t_inf = D.infection_time[a];
-      infect(nw, D.now, susc, inf, t_inf);
-      D.susceptibility[a] = susc;
-      D.is_infected[a] = inf;
-      D.infection_time[a] = t_inf;
-    }
+      const int i = i0 + u * kTileThreads;
+      if (i >= n_local) continue;
+      const int64_t a = base + i;
+      float susc = susc_b[u];
+      float ts = susc * from_fx(lds_acc[i]);
+      if (D.trans_susc) D.trans_susc[a] = ts;
+      ts = fminf(fmaxf(ts, 1e-6f), 100.0f);
+      float p = expf(-ts * D.dt);
+      p = fminf(fmaxf(p, 0.0f), 1.0f);
+      if (D.not_infected_probs) D.not_infected_probs[a] = p;
+      if (!D.sample) continue;
+      float e0 = e0_b[u], e1 = e1_b[u];
+      if (!D.exp_noise) exp_pair(D.seed, D.step, D.agent_offset + a, e0, e1);
+      const float nw = gumbel_new_infected(p, e0, e1);
+      if (D.new_infected) D.new_infected[a] = nw;
+      if (nw != 0.0f) {
+        float inf = D.is_infected[a], t_inf = D.infection_time[a];
+        infect(nw, D.now, susc, inf, t_inf);
+        D.susceptibility[a] = susc;
+        D.is_infected[a] = inf;
+        D.infection_time[a] = t_inf;
+      }
     }
   }
 }

@@ -614,7 +614,7 @@ static int do_agent_gather(const gj_plan* plan, const gj_agent_state* st, const 
 // ------------------------------------------------------------------------------------------
 static int check_tiled(const gj_plan* plan) {
   const gj_tiled* T = plan->tiled;
-  if (T->n_slices < 1 || T->slice_agents < 64 || T->slice_agents % 64 || T->slice_agents > 19968) return GJ_E_PLAN;
+  if (T->n_slices < 1 || T->slice_agents < 64 || T->slice_agents % 64 || T->slice_agents > 20480) return GJ_E_PLAN;
   if ((int64_t)T->n_slices * T->slice_agents < plan->n_agents) return GJ_E_PLAN;
   if (plan->n_ext_agents != plan->n_agents) return GJ_E_PLAN;   // no halo agents in the tiled layout
   if (T->n_work < 0 || (T->n_work > 0 && !T->work)) return GJ_E_PLAN;
@@ -623,7 +623,7 @@ static int check_tiled(const gj_plan* plan) {
     if (S.n_blocks < 0) return GJ_E_PLAN;
     if (S.n_blocks == 0) continue;
     if (!S.blk_v0 || !S.blk_e0 || !S.tile_sptr || !S.tile_jpos || !S.chunk_ptr) return GJ_E_NULL;
-    if (plan->sets[s].n_edges > 0 && (!S.e_lv || !S.a_la || !S.val || !S.chunk_tile)) return GJ_E_NULL;
+    if (plan->sets[s].n_edges > 0 && (!S.e_lv || !S.a_la || !S.val || !S.chunk_desc)) return GJ_E_NULL;
     if (S.max_block_venues < 1 || S.max_block_venues > 65536) return GJ_E_PLAN;
   }
   return GJ_OK;
@@ -640,9 +640,8 @@ static int allow_lds(K kernel, size_t bytes) {
   return GJ_OK;
 }
 
-static int fill_set_a(const gj_plan* plan, const gj_step_params* p, const Groups& G, TSetA* sets) {
+static void fill_set_a(const gj_plan* plan, const gj_step_params* p, const Groups& G, TSetA* sets) {
   const gj_tiled* T = plan->tiled;
-  int j_max = 1;
   for (int s = 0; s < GJ_MAX_SETS; ++s) sets[s] = TSetA{};
   for (int g = 0; g < G.n; ++g) {
     const int s = G.set[g];
@@ -651,34 +650,29 @@ static int fill_set_a(const gj_plan* plan, const gj_step_params* p, const Groups
     sets[s].tile_sptr = S.tile_sptr;
     sets[s].tile_jpos = S.tile_jpos;
     sets[s].chunk_ptr = S.chunk_ptr;
-    sets[s].chunk_tile = S.chunk_tile;
+    sets[s].chunk_desc = reinterpret_cast<const int4*>(S.chunk_desc);
     sets[s].val = S.val;
     sets[s].J = S.n_blocks;
     sets[s].active = (S.n_blocks > 0 && plan->sets[s].n_edges > 0) ? G.nk[g] : 0;
     sets[s].raw = p->nets[G.first[g]].mask_kind == GJ_MASK_RAW;
-    if (S.n_blocks > j_max) j_max = S.n_blocks;
   }
-  return j_max;
 }
 
-// LDS of phases A and D: one slice (fp32 values in A, 64-bit fixed-point sums in D) + this slice's
-// rows of the widest set's tile tables
-static size_t slice_lds(const gj_tiled* T, int j_max, size_t elem) {
-  return (size_t)T->slice_agents * elem + (size_t)(2 * j_max + 2) * sizeof(int32_t);
-}
+// LDS of phases A and D: one slice (fp32 values in A, 64-bit fixed-point sums in D)
+static size_t slice_lds(const gj_tiled* T, size_t elem) { return (size_t)T->slice_agents * elem; }
 
 static int tiled_scatter(const gj_plan* plan, const gj_agent_state* st, const gj_step_params* p, const Groups& G,
                          hipStream_t stream) {
   const gj_tiled* T = plan->tiled;
   if (plan->n_agents == 0 || G.n == 0) return GJ_OK;
   TileAArgs A;
-  A.j_max = fill_set_a(plan, p, G, A.sets);
+  fill_set_a(plan, p, G, A.sets);
   A.n_sets = plan->n_sets;
   A.slice_agents = T->slice_agents;
   A.n_agents = plan->n_agents;
   A.trans = st->transmission;
   A.qtrans = p->has_quarantine ? st->q_transmission : st->transmission;
-  const size_t lds = slice_lds(T, A.j_max, sizeof(float));
+  const size_t lds = slice_lds(T, sizeof(float));
   int rc = allow_lds(k_tile_scatter, lds);
   if (rc) return rc;
   hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)T->n_slices), dim3(kTileThreads), lds, stream, A);
@@ -739,7 +733,7 @@ static int tiled_agents(const gj_plan* plan, const gj_agent_state* st, const gj_
   const gj_tiled* T = plan->tiled;
   if (plan->n_agents == 0) return GJ_OK;
   TileDArgs D;
-  D.j_max = fill_set_a(plan, p, G, D.sets);
+  fill_set_a(plan, p, G, D.sets);
   D.n_sets = plan->n_sets;
   D.slice_agents = T->slice_agents;
   D.n_agents = plan->n_agents;
@@ -759,7 +753,7 @@ static int tiled_agents(const gj_plan* plan, const gj_agent_state* st, const gj_
   D.seed = p->seed;
   D.step = p->step;
   D.agent_offset = p->agent_offset;
-  const size_t lds = slice_lds(T, D.j_max, sizeof(fx_t));
+  const size_t lds = slice_lds(T, sizeof(fx_t));
   int rc = allow_lds(k_tile_agents, lds);
   if (rc) return rc;
   hipLaunchKernelGGL(k_tile_agents, dim3((unsigned)T->n_slices), dim3(kTileThreads), lds, stream, D);

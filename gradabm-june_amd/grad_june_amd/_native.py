@@ -52,7 +52,7 @@ class TiledSet(C.Structure):
         ("tile_sptr", _vp),
         ("tile_jpos", _vp),
         ("chunk_ptr", _vp),
-        ("chunk_tile", _vp),
+        ("chunk_desc", _vp),
         ("val", _vp),
     ]
 

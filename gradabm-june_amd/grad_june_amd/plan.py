@@ -290,7 +290,7 @@ class DevicePlan:
                 u16 = lambda a: up(a.view(np.int16))
                 t.update(blk_v0=up(ts.blk_v0), blk_e0=up(ts.blk_e0), e_lv=u16(ts.e_lv), a_la=u16(ts.a_la),
                          tile_sptr=up(ts.tile_sptr), tile_jpos=up(ts.tile_jpos),
-                         chunk_ptr=up(ts.chunk_ptr), chunk_tile=u16(ts.chunk_tile) if len(ts.chunk_tile) else None,
+                         chunk_ptr=up(ts.chunk_ptr), chunk_desc=up(ts.chunk_desc.reshape(-1)) if len(ts.chunk_desc) else None,
                          val=torch.zeros(max(8, ts.n_slots), dtype=torch.float32, device=dev))
                 if ts.e_cls is not None:
                     t["e_cls"] = up(ts.e_cls)
@@ -301,7 +301,7 @@ class DevicePlan:
                 c.e_lv, c.a_la = t["e_lv"].data_ptr(), t["a_la"].data_ptr()
                 c.e_cls = N.ptr(t.get("e_cls"))
                 c.tile_sptr, c.tile_jpos, c.val = t["tile_sptr"].data_ptr(), t["tile_jpos"].data_ptr(), t["val"].data_ptr()
-                c.chunk_ptr, c.chunk_tile = t["chunk_ptr"].data_ptr(), N.ptr(t["chunk_tile"])
+                c.chunk_ptr, c.chunk_desc = t["chunk_ptr"].data_ptr(), N.ptr(t["chunk_desc"])
             self.keep.append(t)
             self.cum.append(cum)
         self.blocks = up(host.blocks.reshape(-1)) if len(host.blocks) else None

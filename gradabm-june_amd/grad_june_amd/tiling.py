@@ -27,7 +27,7 @@ from typing import List, Optional
 
 import numpy as np
 
-SA_MAX = 19968        # agents per slice: 156 KiB of LDS as 64-bit fixed-point sums (phase D)
+SA_MAX = 20480        # agents per slice: 160 KiB of LDS as 64-bit fixed-point sums (phase D)
 SV_MAX = 16384        # venues per block (128 KiB of 64-bit sums in phase B; local venue index is 16-bit)
 EB_TARGET = 131072    # edges per block aimed for (work per workgroup of phases B/C)
 N_CU = 256
@@ -88,7 +88,11 @@ class TiledEdgeSet:
     v_pcontact: np.ndarray  # float32 [V]
     n_slots: int = 0        # length of the block-major arrays: every block padded to a multiple of 8
     chunk_ptr: Optional[np.ndarray] = None   # int32 [S+1] first 64-edge chunk of slice s (slice-major)
-    chunk_tile: Optional[np.ndarray] = None  # uint16 [n_chunks] block j of the chunk's first edge
+    chunk_desc: Optional[np.ndarray] = None  # int32 [n_chunks, 4]: slot0, slot1, split | multi << 16, j0
+    # A chunk = 64 consecutive slice-major edges.  Its first `split` edges lie in one tile and map to
+    # block-major slots slot0, slot0+1, ...; the rest lie in the next non-empty tile and map to slot1,
+    # slot1+1, ...  `multi` flags the rare chunk that spans more than two tiles (tiny tiles): its
+    # lanes resolve their slot from the tile tables, starting at block j0.
 
 
 def build_tiled(name: str, agent_index, venue_index, n_venues: int, v_pcontact: np.ndarray,
@@ -108,7 +112,7 @@ def build_tiled(name: str, agent_index, venue_index, n_venues: int, v_pcontact: 
         return TiledEdgeSet(name, n_venues, 0, S, 0, z32, z32, np.zeros(0, np.uint16), None,
                             np.zeros(0, np.uint16), np.zeros(1, np.int32), np.zeros(0, np.int32),
                             np.asarray(v_pcontact, dtype=np.float32), 0, np.zeros(S + 1, np.int32),
-                            np.zeros(0, np.uint16))
+                            np.zeros((0, 4), np.int32))
     vblk = (np.searchsorted(blk_v0, np.arange(n_venues), side="right") - 1).astype(np.int64)
     j = vblk[venue]
     lv = venue - blk_v0[j]
@@ -159,15 +163,25 @@ def build_tiled(name: str, agent_index, venue_index, n_venues: int, v_pcontact: 
     np.cumsum(n_chunks, out=chunk_ptr[1:])
     first_edge = np.repeat(seg[:-1], n_chunks) + CHUNK * (np.arange(chunk_ptr[-1]) - np.repeat(chunk_ptr[:-1], n_chunks))
     # tile (slice-major index) containing an edge position: last tile whose start <= position, skipping empties
-    chunk_tile_sm = np.searchsorted(sptr, first_edge, side="right") - 1
-    chunk_tile = (chunk_tile_sm - np.repeat(np.arange(S) * J, n_chunks)).astype(np.uint16)
+    seg_end = np.repeat(seg[1:], n_chunks)
+    chunk_end = np.minimum(first_edge + CHUNK, seg_end)
+    t0 = np.searchsorted(sptr, first_edge, side="right") - 1
+    end0 = sptr[t0 + 1]
+    split = np.minimum(end0, chunk_end) - first_edge
+    slot0 = jpos_sj.reshape(-1)[t0] + (first_edge - sptr[t0])
+    two = end0 < chunk_end                                             # chunk continues in another tile
+    t1 = np.where(two, np.searchsorted(sptr, np.minimum(end0, E - 1), side="right") - 1, t0)
+    slot1 = np.where(two, jpos_sj.reshape(-1)[t1] + (end0 - sptr[t1]), 0)
+    multi = two & (sptr[t1 + 1] < chunk_end)
+    chunk_desc = np.stack([slot0, slot1, split + (multi.astype(np.int64) << 16),
+                           t0 - np.repeat(np.arange(S) * J, n_chunks)], axis=1).astype(np.int32)
     return TiledEdgeSet(
         name=name, n_venues=n_venues, n_edges=E, n_slices=S, n_blocks=J,
         blk_v0=blk_v0.astype(np.int32), blk_e0=blk_start.astype(np.int32),
         e_lv=e_lv, e_cls=e_cls, a_la=a_la,
         tile_sptr=sptr.astype(np.int32), tile_jpos=jpos_sj.reshape(-1).astype(np.int32),
         v_pcontact=np.asarray(v_pcontact, dtype=np.float32), n_slots=n_slots,
-        chunk_ptr=chunk_ptr.astype(np.int32), chunk_tile=chunk_tile)
+        chunk_ptr=chunk_ptr.astype(np.int32), chunk_desc=np.ascontiguousarray(chunk_desc))
 
 
 # ------------------------------------------------------------------------------------------------

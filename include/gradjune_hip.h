@@ -124,13 +124,16 @@ typedef struct gj_tiled_set {
   const int32_t* tile_sptr;  /* device [S*J+1] slice-major prefix: tile (s,j) = [sptr[s*J+j], sptr[s*J+j+1]) */
   const int32_t* tile_jpos;  /* device [S*J]   block-major start slot of tile (s,j)          */
   const int32_t* chunk_ptr;  /* device [S+1]   first 64-edge chunk of slice s's slice-major segment */
-  const uint16_t* chunk_tile;/* device [chunks] block j holding the first edge of each chunk */
+  const int32_t* chunk_desc; /* device [4*chunks] per 64-edge chunk: slot0, slot1, split|multi<<16, j0:
+                                the first `split` edges map to block-major slots slot0.., the rest
+                                (next non-empty tile) to slot1..; multi: spans > 2 tiles, lanes
+                                resolve through tile_sptr/tile_jpos starting at block j0        */
   float* val;                /* device [slots] workspace: per-edge value (phase A->B, C->D)  */
 } gj_tiled_set;
 
 typedef struct gj_tiled {
   int32_t n_slices;          /* S                                                            */
-  int32_t slice_agents;      /* SA (multiple of 64, <= 19968: one slice of 8-byte sums fits LDS) */
+  int32_t slice_agents;      /* SA (multiple of 64, <= 20480: one slice of 8-byte sums fits LDS) */
   int32_t _pad;
   int32_t n_work;            /* entries of `work`                                            */
   const int32_t* work;       /* device [2*n_work] (set, block) pairs, heaviest first         */

@@ -30,13 +30,23 @@ def test_layout_and_emulation(A, V, E, sa, svmax, eb):
     blk_edges = np.add.reduceat(deg, t.blk_v0[:-1])
     assert (t.blk_e0 % 8 == 0).all() and np.array_equal(np.diff(t.blk_e0), -(-blk_edges // 8) * 8)
     assert (t.e_lv != 0xFFFF).sum() == E
-    # chunk table: the block of the first edge of every 64-edge chunk of every slice segment
+    # chunk descriptors: every slice-major edge resolves to the block-major slot the tile tables give
     seg = t.tile_sptr[0:S * J + 1:J]
+    tile_of_pos = np.searchsorted(t.tile_sptr, np.arange(E), side="right") - 1
+    slot_ref = t.tile_jpos[tile_of_pos] + (np.arange(E) - t.tile_sptr[tile_of_pos])
+    n_multi = 0
     for sl in range(S):
         for c in range(t.chunk_ptr[sl], t.chunk_ptr[sl + 1]):
-            i = seg[sl] + 64 * (c - t.chunk_ptr[sl])
-            jj = int(t.chunk_tile[c])
-            assert t.tile_sptr[sl * J + jj] <= i < t.tile_sptr[sl * J + jj + 1]
+            i0 = seg[sl] + 64 * (c - t.chunk_ptr[sl])
+            n = min(64, seg[sl + 1] - i0)
+            slot0, slot1, sm, j0 = (int(x) for x in t.chunk_desc[c])
+            split, multi = sm & 0xFFFF, sm >> 16
+            assert t.tile_sptr[sl * J + j0] <= i0 < t.tile_sptr[sl * J + j0 + 1] and 1 <= split <= n
+            assert np.array_equal(slot_ref[i0:i0 + split], slot0 + np.arange(split))
+            if multi:
+                n_multi += 1
+            else:
+                assert np.array_equal(slot_ref[i0 + split:i0 + n], slot1 + np.arange(n - split))
     # every tile is contiguous in both orders and holds the same multiset of edges
     lens = np.diff(t.tile_sptr).reshape(S, J)
     assert lens.sum() == E
@@ -66,7 +76,7 @@ def test_empty_set_and_slice_choice():
     assert t.n_blocks == 1 and t.n_edges == 0 and t.blk_v0.tolist() == [0, 10]
     for n in (1, 100, 769, 10_000, 1_000_000, 10_000_000, 25_000_000):
         S, SA = choose_slices(n)
-        assert S * SA >= n and (S - 1) * SA < n and SA <= 19968
+        assert S * SA >= n and (S - 1) * SA < n and SA <= 20480
     assert choose_slices(10_000_000)[0] in (511, 512)
     b = venue_blocks(np.array([5, 5, 100000, 5, 5]), sv_max=2, eb_target=50)
     assert b.tolist() == [0, 2, 3, 5]
