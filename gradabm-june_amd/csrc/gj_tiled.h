@@ -102,6 +102,10 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_scatter(const TileAArgs A
       const int n_chunks = T.chunk_ptr[s + 1] - c_base;
       for (int c0 = wave * kUnroll; c0 < n_chunks; c0 += kTileWaves * kUnroll) {
         int la[kUnroll];
+        int4 d[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u)   // wave-uniform descriptors: scalar loads, all in flight together
+          d[u] = T.chunk_desc[c_base + min(c0 + u, n_chunks - 1)];
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
           const int i = seg0 + (c0 + u) * kWave + lane;
@@ -109,11 +113,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_scatter(const TileAArgs A
         }
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
-          if (c0 + u < n_chunks) {
-            const int4 d = T.chunk_desc[c_base + c0 + u];
-            const int i = seg0 + (c0 + u) * kWave + lane;
-            if (la[u] >= 0) T.val[chunk_slot(T, d, row, i, lane)] = lds_x[la[u]];
-          }
+          const int i = seg0 + (c0 + u) * kWave + lane;
+          if (la[u] >= 0) T.val[chunk_slot(T, d[u], row, i, lane)] = lds_x[la[u]];
         }
       }
     }
@@ -308,16 +309,16 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
       for (int c0 = wave * kUnroll; c0 < n_chunks; c0 += kTileWaves * kUnroll) {
         int la[kUnroll];
         float v[kUnroll];
+        int4 d[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u)   // wave-uniform descriptors: scalar loads, all in flight together
+          d[u] = T.chunk_desc[c_base + min(c0 + u, n_chunks - 1)];
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {   // both loads of an edge depend on its position only
           const int i = seg0 + (c0 + u) * kWave + lane;
           const bool ok = (c0 + u < n_chunks) && (i < seg1);
           la[u] = ok ? (int)T.a_la[i] : -1;
-          v[u] = 0.0f;
-          if (c0 + u < n_chunks) {
-            const int4 d = T.chunk_desc[c_base + c0 + u];
-            if (ok) v[u] = T.val[chunk_slot(T, d, row, i, lane)];
-          }
+          v[u] = ok ? T.val[chunk_slot(T, d[u], row, i, lane)] : 0.0f;
         }
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u)
