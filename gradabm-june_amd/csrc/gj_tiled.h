@@ -63,12 +63,16 @@ __device__ __forceinline__ void load_slice(float* lds, const float* __restrict__
 }
 
 // Block-major slot of lane `lane` of a 64-edge chunk (descriptor d: slot0, slot1, split | multi<<16, j0;
-// see tiling.py).  The common case is pure register arithmetic on a wave-uniform descriptor; a chunk
-// that spans more than two (tiny) tiles walks the tile tables.
-__device__ __forceinline__ int chunk_slot(const TSetA& T, const int4 d, int row, int i, int lane) {
+// see tiling.py).  Fast form: pure register arithmetic on a wave-uniform descriptor (straight-line
+// code, so that a batch of chunks keeps all its loads in flight).
+__device__ __forceinline__ int chunk_slot_fast(const int4 d, int lane) {
+  const int split = d.z & 0xFFFF;
+  return (lane < split) ? d.x + lane : d.y + (lane - split);
+}
+// General form for the rare chunk that spans more than two (tiny) tiles: walk the tile tables.
+__device__ __noinline__ int chunk_slot_slow(const TSetA& T, const int4 d, int row, int i, int lane) {
   const int split = d.z & 0xFFFF;
   if (lane < split) return d.x + lane;
-  if (!(d.z >> 16)) return d.y + (lane - split);
   int j = d.w;
   while (i >= T.tile_sptr[row + j + 1]) ++j;
   return T.tile_jpos[row + j] + (i - T.tile_sptr[row + j]);
@@ -103,18 +107,29 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_scatter(const TileAArgs A
       for (int c0 = wave * kUnroll; c0 < n_chunks; c0 += kTileWaves * kUnroll) {
         int la[kUnroll];
         int4 d[kUnroll];
+        int multi = 0;
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u)   // wave-uniform descriptors: scalar loads, all in flight together
+        for (int u = 0; u < kUnroll; ++u) {  // wave-uniform descriptors, all loads in flight together
           d[u] = T.chunk_desc[c_base + min(c0 + u, n_chunks - 1)];
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-          const int i = seg0 + (c0 + u) * kWave + lane;
-          la[u] = (c0 + u < n_chunks && i < seg1) ? (int)T.a_la[i] : -1;
+          multi |= d[u].z;
         }
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-          const int i = seg0 + (c0 + u) * kWave + lane;
-          if (la[u] >= 0) T.val[chunk_slot(T, d[u], row, i, lane)] = lds_x[la[u]];
+        for (int u = 0; u < kUnroll; ++u)    // unconditional (clamped) loads: straight-line, all in flight
+          la[u] = T.a_la[min(seg0 + (c0 + u) * kWave + lane, seg1 - 1)];
+        if (__builtin_amdgcn_readfirstlane(multi >> 16) == 0) {
+#pragma unroll
+          for (int u = 0; u < kUnroll; ++u) {
+            const int i = seg0 + (c0 + u) * kWave + lane;
+            if ((c0 + u < n_chunks) && (i < seg1)) T.val[chunk_slot_fast(d[u], lane)] = lds_x[la[u]];
+          }
+        } else {
+          for (int u = 0; u < kUnroll; ++u) {
+            const int i = seg0 + (c0 + u) * kWave + lane;
+            if ((c0 + u < n_chunks) && (i < seg1)) {
+              const int slot = (d[u].z >> 16) ? chunk_slot_slow(T, d[u], row, i, lane) : chunk_slot_fast(d[u], lane);
+              T.val[slot] = lds_x[la[u]];
+            }
+          }
         }
       }
     }
@@ -310,19 +325,36 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
         int la[kUnroll];
         float v[kUnroll];
         int4 d[kUnroll];
+        int multi = 0;
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u)   // wave-uniform descriptors: scalar loads, all in flight together
+        for (int u = 0; u < kUnroll; ++u) {  // wave-uniform descriptors, all loads in flight together
           d[u] = T.chunk_desc[c_base + min(c0 + u, n_chunks - 1)];
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {   // both loads of an edge depend on its position only
-          const int i = seg0 + (c0 + u) * kWave + lane;
-          const bool ok = (c0 + u < n_chunks) && (i < seg1);
-          la[u] = ok ? (int)T.a_la[i] : -1;
-          v[u] = ok ? T.val[chunk_slot(T, d[u], row, i, lane)] : 0.0f;
+          multi |= d[u].z;
         }
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u)
-          if (la[u] >= 0) atomicAdd(&lds_acc[la[u]], to_fx(v[u]));
+        for (int u = 0; u < kUnroll; ++u)    // unconditional (clamped) loads: straight-line, all in flight
+          la[u] = T.a_la[min(seg0 + (c0 + u) * kWave + lane, seg1 - 1)];
+        if (__builtin_amdgcn_readfirstlane(multi >> 16) == 0) {
+#pragma unroll
+          for (int u = 0; u < kUnroll; ++u) {  // the slot depends on the position only: loads overlap the ones above
+            const int i = seg0 + (c0 + u) * kWave + lane;
+            const bool ok = (c0 + u < n_chunks) && (i < seg1);
+            v[u] = T.val[ok ? chunk_slot_fast(d[u], lane) : 0];
+          }
+        } else {
+          for (int u = 0; u < kUnroll; ++u) {
+            const int i = seg0 + (c0 + u) * kWave + lane;
+            const bool ok = (c0 + u < n_chunks) && (i < seg1);
+            int slot = 0;
+            if (ok) slot = (d[u].z >> 16) ? chunk_slot_slow(T, d[u], row, i, lane) : chunk_slot_fast(d[u], lane);
+            v[u] = T.val[slot];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+          const int i = seg0 + (c0 + u) * kWave + lane;
+          if ((c0 + u < n_chunks) && (i < seg1)) atomicAdd(&lds_acc[la[u]], to_fx(v[u]));
+        }
       }
     }
     __syncthreads();
