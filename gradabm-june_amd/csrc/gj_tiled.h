@@ -104,28 +104,28 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_scatter(const TileAArgs A
       const int seg0 = T.tile_sptr[row], seg1 = T.tile_sptr[row + T.J];
       const int c_base = T.chunk_ptr[s];
       const int n_chunks = T.chunk_ptr[s + 1] - c_base;
-      for (int c0 = wave; c0 < n_chunks; c0 += kTileWaves * kUnroll) {   // chunk (c0 + u * kTileWaves): waves interleave
+      for (int c0 = wave * kUnroll; c0 < n_chunks; c0 += kTileWaves * kUnroll) {
         int la[kUnroll];
         int4 d[kUnroll];
         int multi = 0;
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {  // wave-uniform descriptors, all loads in flight together
-          d[u] = T.chunk_desc[c_base + min(c0 + u * kTileWaves, n_chunks - 1)];
+          d[u] = T.chunk_desc[c_base + min(c0 + u, n_chunks - 1)];
           multi |= d[u].z;
         }
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u)    // unconditional (clamped) loads: straight-line, all in flight
-          la[u] = T.a_la[min(seg0 + (c0 + u * kTileWaves) * kWave + lane, seg1 - 1)];
+          la[u] = T.a_la[min(seg0 + (c0 + u) * kWave + lane, seg1 - 1)];
         if (__builtin_amdgcn_readfirstlane(multi >> 16) == 0) {
 #pragma unroll
           for (int u = 0; u < kUnroll; ++u) {
-            const int i = seg0 + (c0 + u * kTileWaves) * kWave + lane;
-            if ((c0 + u * kTileWaves < n_chunks) && (i < seg1)) T.val[chunk_slot_fast(d[u], lane)] = lds_x[la[u]];
+            const int i = seg0 + (c0 + u) * kWave + lane;
+            if ((c0 + u < n_chunks) && (i < seg1)) T.val[chunk_slot_fast(d[u], lane)] = lds_x[la[u]];
           }
         } else {
           for (int u = 0; u < kUnroll; ++u) {
-            const int i = seg0 + (c0 + u * kTileWaves) * kWave + lane;
-            if ((c0 + u * kTileWaves < n_chunks) && (i < seg1)) {
+            const int i = seg0 + (c0 + u) * kWave + lane;
+            if ((c0 + u < n_chunks) && (i < seg1)) {
               const int slot = (d[u].z >> 16) ? chunk_slot_slow(T, d[u], row, i, lane) : chunk_slot_fast(d[u], lane);
               T.val[slot] = lds_x[la[u]];
             }
@@ -321,30 +321,30 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
       const int seg0 = T.tile_sptr[row], seg1 = T.tile_sptr[row + T.J];
       const int c_base = T.chunk_ptr[s];
       const int n_chunks = T.chunk_ptr[s + 1] - c_base;
-      for (int c0 = wave; c0 < n_chunks; c0 += kTileWaves * kUnroll) {   // chunk (c0 + u * kTileWaves): waves interleave
+      for (int c0 = wave * kUnroll; c0 < n_chunks; c0 += kTileWaves * kUnroll) {
         int la[kUnroll];
         float v[kUnroll];
         int4 d[kUnroll];
         int multi = 0;
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {  // wave-uniform descriptors, all loads in flight together
-          d[u] = T.chunk_desc[c_base + min(c0 + u * kTileWaves, n_chunks - 1)];
+          d[u] = T.chunk_desc[c_base + min(c0 + u, n_chunks - 1)];
           multi |= d[u].z;
         }
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u)    // unconditional (clamped) loads: straight-line, all in flight
-          la[u] = T.a_la[min(seg0 + (c0 + u * kTileWaves) * kWave + lane, seg1 - 1)];
+          la[u] = T.a_la[min(seg0 + (c0 + u) * kWave + lane, seg1 - 1)];
         if (__builtin_amdgcn_readfirstlane(multi >> 16) == 0) {
 #pragma unroll
           for (int u = 0; u < kUnroll; ++u) {  // the slot depends on the position only: loads overlap the ones above
-            const int i = seg0 + (c0 + u * kTileWaves) * kWave + lane;
-            const bool ok = (c0 + u * kTileWaves < n_chunks) && (i < seg1);
+            const int i = seg0 + (c0 + u) * kWave + lane;
+            const bool ok = (c0 + u < n_chunks) && (i < seg1);
             v[u] = T.val[ok ? chunk_slot_fast(d[u], lane) : 0];
           }
         } else {
           for (int u = 0; u < kUnroll; ++u) {
-            const int i = seg0 + (c0 + u * kTileWaves) * kWave + lane;
-            const bool ok = (c0 + u * kTileWaves < n_chunks) && (i < seg1);
+            const int i = seg0 + (c0 + u) * kWave + lane;
+            const bool ok = (c0 + u < n_chunks) && (i < seg1);
             int slot = 0;
             if (ok) slot = (d[u].z >> 16) ? chunk_slot_slow(T, d[u], row, i, lane) : chunk_slot_fast(d[u], lane);
             v[u] = T.val[slot];
@@ -352,8 +352,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
         }
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
-          const int i = seg0 + (c0 + u * kTileWaves) * kWave + lane;
-          if ((c0 + u * kTileWaves < n_chunks) && (i < seg1)) atomicAdd(&lds_acc[la[u]], to_fx(v[u]));
+          const int i = seg0 + (c0 + u) * kWave + lane;
+          if ((c0 + u < n_chunks) && (i < seg1)) atomicAdd(&lds_acc[la[u]], to_fx(v[u]));
         }
       }
     }
