@@ -615,8 +615,9 @@ static int do_agent_gather(const gj_plan* plan, const gj_agent_state* st, const 
 static int check_tiled(const gj_plan* plan) {
   const gj_tiled* T = plan->tiled;
   if (T->n_slices < 1 || T->slice_agents < 64 || T->slice_agents % 64 || T->slice_agents > 20480) return GJ_E_PLAN;
-  if ((int64_t)T->n_slices * T->slice_agents < plan->n_agents) return GJ_E_PLAN;
-  if (plan->n_ext_agents != plan->n_agents) return GJ_E_PLAN;   // no halo agents in the tiled layout
+  // slices cover owned + halo agents; halo agents start on a slice boundary (phase D runs on the
+  // slices of owned agents only)
+  if ((int64_t)T->n_slices * T->slice_agents < plan->n_ext_agents) return GJ_E_PLAN;
   if (T->n_work < 0 || (T->n_work > 0 && !T->work)) return GJ_E_PLAN;
   for (int s = 0; s < plan->n_sets; ++s) {
     const gj_tiled_set& S = T->sets[s];
@@ -664,12 +665,12 @@ static size_t slice_lds(const gj_tiled* T, size_t elem) { return (size_t)T->slic
 static int tiled_scatter(const gj_plan* plan, const gj_agent_state* st, const gj_step_params* p, const Groups& G,
                          hipStream_t stream) {
   const gj_tiled* T = plan->tiled;
-  if (plan->n_agents == 0 || G.n == 0) return GJ_OK;
+  if (plan->n_ext_agents == 0 || G.n == 0) return GJ_OK;
   TileAArgs A;
   fill_set_a(plan, p, G, A.sets);
   A.n_sets = plan->n_sets;
   A.slice_agents = T->slice_agents;
-  A.n_agents = plan->n_agents;
+  A.n_agents = plan->n_ext_agents;     // phase A also scatters the halo agents' values
   A.trans = st->transmission;
   A.qtrans = p->has_quarantine ? st->q_transmission : st->transmission;
   const size_t lds = slice_lds(T, sizeof(float));
@@ -756,7 +757,8 @@ static int tiled_agents(const gj_plan* plan, const gj_agent_state* st, const gj_
   const size_t lds = slice_lds(T, sizeof(fx_t));
   int rc = allow_lds(k_tile_agents, lds);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_tile_agents, dim3((unsigned)T->n_slices), dim3(kTileThreads), lds, stream, D);
+  const int64_t owned_slices = (plan->n_agents + T->slice_agents - 1) / T->slice_agents;
+  hipLaunchKernelGGL(k_tile_agents, dim3((unsigned)owned_slices), dim3(kTileThreads), lds, stream, D);
   return launch_status();
 }
 

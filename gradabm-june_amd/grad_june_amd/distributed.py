@@ -1,0 +1,262 @@
+"""Multi-GPU hot path: agents partitioned over the ranks of one node, one process per GPU.
+
+The reference is single-process; this is new design.  Everything per-agent
+(a1, a2, a4, a7-a9) is local to the rank that owns the agent.  Only pass 1 needs remote data, and
+per edge set one of two exchanges is used (decided once, identically on every rank):
+
+* ``halo``    (small venues: households, ...): every venue with a local attendee is computed in full
+  on this rank, so the transmissions of its REMOTE attendees ("halo agents") are received once per
+  step by ONE ``all_to_all_single`` with per-peer split sizes (RCCL over xGMI: direct peer-to-peer
+  sends on all links at once, no ring).  Halo agents extend the local agent index range; the
+  receive buffer IS the halo part of the transmission array (no unpack).
+* ``partial`` (venues that span ranks: schools, leisure, ...): each rank sums its own attendees and
+  the per-venue partial sums of all such sets - one flat fp32 buffer - are combined by ONE
+  ``all_reduce``; volume is bounded by the number of venues, not by the attendees.
+
+Per step:  transmission -> [all_to_all halo] -> phase A, phase B -> [all_reduce partial sums]
+           -> phase C, phase D.   Pass 2 and the epilogue are purely local.
+Sampling noise is Philox keyed by the GLOBAL agent id, so results do not depend on the partition.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import tiling as TL
+
+HALO_MAX_MEAN_DEGREE = 8.0     # sets whose venues average more attendees use partial sums
+
+
+def partition_bounds(n_agents: int, world_size: int) -> np.ndarray:
+    """Contiguous, near-equal agent ranges: rank r owns [b[r], b[r+1])."""
+    return (np.arange(world_size + 1, dtype=np.int64) * n_agents) // world_size
+
+
+def choose_modes(world: dict, world_size: int, override: Optional[Dict[str, str]] = None) -> Dict[str, str]:
+    """Exchange mode per edge set - a function of global sizes only, so all ranks agree."""
+    modes = {}
+    for name, es in world["edge_sets"].items():
+        if world_size == 1:
+            modes[name] = "local"
+        else:
+            V = max(1, len(es["people"]))
+            modes[name] = "halo" if len(es["agent"]) / V <= HALO_MAX_MEAN_DEGREE else "partial"
+    if override:
+        modes.update(override)
+    return modes
+
+
+@dataclass
+class RankWorld:
+    """The part of the world one rank compiles, in its local ("extended") index spaces."""
+    rank: int
+    world_size: int
+    bounds: np.ndarray                 # global partition
+    n_local: int
+    slice_agents: int
+    n_local_pad: int                   # first halo index: n_local rounded up to a slice boundary
+    n_ext: int                         # n_local_pad + n_halo
+    n_slices: int
+    halo_global: np.ndarray            # int64 [n_halo] global ids of the halo agents, by (owner, id)
+    halo_from: np.ndarray              # int64 [R] halo agents received from each peer
+    age: np.ndarray                    # [n_ext]
+    sex: np.ndarray
+    edge_sets: Dict[str, dict]         # local COO: agent = extended index, venue = local/global id
+    modes: Dict[str, str]
+    venue_global: Dict[str, Optional[np.ndarray]]   # halo sets: global id of each local venue
+
+    @property
+    def n_halo(self) -> int:
+        return len(self.halo_global)
+
+
+def build_rank_world(world: dict, rank: int, world_size: int, modes: Optional[Dict[str, str]] = None,
+                     slice_agents: Optional[int] = None) -> RankWorld:
+    A = world["n_agents"]
+    bounds = partition_bounds(A, world_size)
+    a0, a1 = int(bounds[rank]), int(bounds[rank + 1])
+    n_local = a1 - a0
+    modes = modes or choose_modes(world, world_size)
+    local_sets, halo_lists, venue_global = {}, [], {}
+    for name, es in world["edge_sets"].items():
+        agent = np.asarray(es["agent"], dtype=np.int64)
+        venue = np.asarray(es["venue"], dtype=np.int64)
+        people = np.asarray(es["people"])
+        mine = (agent >= a0) & (agent < a1)
+        if modes[name] in ("partial", "local"):
+            local_sets[name] = {"agent_global": agent[mine], "venue": venue[mine], "people": people}
+            venue_global[name] = None
+        else:
+            touched = np.zeros(len(people), dtype=bool)
+            touched[venue[mine]] = True
+            keep = touched[venue]                      # every edge of a touched venue, local or remote
+            vg = np.flatnonzero(touched)
+            remap = np.full(len(people), -1, dtype=np.int64)
+            remap[vg] = np.arange(len(vg))
+            local_sets[name] = {"agent_global": agent[keep], "venue": remap[venue[keep]], "people": people[vg]}
+            venue_global[name] = vg
+            remote = agent[keep & ~mine]
+            halo_lists.append(np.unique(remote))
+    halo_global = np.unique(np.concatenate(halo_lists)) if halo_lists else np.zeros(0, dtype=np.int64)
+    owner = np.searchsorted(bounds, halo_global, side="right") - 1
+    halo_from = np.bincount(owner, minlength=world_size).astype(np.int64)   # sorted ids => grouped by owner
+    if slice_agents is None:
+        _, slice_agents = TL.choose_slices(n_local + len(halo_global))
+    n_local_pad = -(-n_local // slice_agents) * slice_agents if len(halo_global) else n_local
+    n_ext = n_local_pad + len(halo_global)
+    n_slices = max(1, -(-n_ext // slice_agents))
+
+    def to_ext(g):
+        out = g - a0
+        rem = (g < a0) | (g >= a1)
+        if rem.any():
+            out[rem] = n_local_pad + np.searchsorted(halo_global, g[rem])
+        return out
+
+    edge_sets = {}
+    for name, ls in local_sets.items():
+        edge_sets[name] = {"agent": to_ext(ls["agent_global"].copy()), "venue": ls["venue"], "people": ls["people"]}
+    ext_global = np.zeros(n_ext, dtype=np.int64)
+    ext_global[:n_local] = np.arange(a0, a1)
+    ext_global[n_local_pad:] = halo_global
+    age = np.asarray(world["age"])[ext_global]
+    sex = np.asarray(world["sex"])[ext_global]
+    return RankWorld(rank, world_size, bounds, n_local, slice_agents, n_local_pad, n_ext, n_slices, halo_global,
+                     halo_from, age, sex, edge_sets, modes, venue_global)
+
+
+class HaloExchange:
+    """The once-per-step all-to-all of halo transmissions.
+
+    Setup (collective, once): every rank tells each peer which of the peer's agents it needs.
+    Per step: ``exchange(x)`` packs ``x[send_index]`` and receives straight into ``x[n_local_pad:]``.
+    Works on any backend / device torch.distributed supports (RCCL on GPUs, gloo on CPU in tests).
+    """
+
+    def __init__(self, rw: RankWorld, device, group=None, pack=None):
+        import torch.distributed as dist
+
+        self.rw, self.group, self.device = rw, group, torch.device(device)
+        self.pack = pack
+        R, r = rw.world_size, rw.rank
+        self.recv_counts = [int(c) for c in rw.halo_from]
+        need_counts = torch.tensor(self.recv_counts, dtype=torch.int64, device=self.device)
+        send_counts = torch.empty(R, dtype=torch.int64, device=self.device)
+        dist.all_to_all_single(send_counts, need_counts, group=group)
+        self.send_counts = [int(c) for c in send_counts.cpu()]
+        need_ids = torch.from_numpy(rw.halo_global).to(self.device)       # grouped by owner, ascending
+        asked = torch.empty(sum(self.send_counts), dtype=torch.int64, device=self.device)
+        dist.all_to_all_single(asked, need_ids, self.send_counts, self.recv_counts, group=group)
+        local = asked - int(rw.bounds[r])
+        if local.numel() and (int(local.min()) < 0 or int(local.max()) >= rw.n_local):
+            raise RuntimeError("halo setup: a peer asked for an agent this rank does not own")
+        self.send_index = local.to(torch.int32).contiguous()
+        self.send_buf = torch.empty(self.send_index.numel(), dtype=torch.float32, device=self.device)
+
+    @property
+    def bytes_per_step(self) -> int:
+        return 4 * (self.send_index.numel() + sum(self.recv_counts))
+
+    def exchange(self, x: torch.Tensor):
+        """x: float32[n_ext]; fills x[n_local_pad:] with the owners' current values."""
+        import torch.distributed as dist
+
+        if self.rw.world_size == 1 or (self.send_index.numel() == 0 and self.rw.n_halo == 0):
+            return
+        if self.pack is not None:
+            self.pack(self.send_index, x, self.send_buf)
+        else:
+            torch.index_select(x, 0, self.send_index.long(), out=self.send_buf)
+        recv = x[self.rw.n_local_pad:self.rw.n_local_pad + self.rw.n_halo]
+        dist.all_to_all_single(recv, self.send_buf, self.recv_counts, self.send_counts, group=self.group)
+
+
+def emulate_exchange(rank_worlds: Sequence[RankWorld], xs: Sequence[np.ndarray]) -> None:
+    """In-process stand-in for HaloExchange over all ranks at once (tests): fill every rank's halo
+    slots from the owners' local values."""
+    bounds = rank_worlds[0].bounds
+    glob = np.concatenate([x[: rw.n_local] for rw, x in zip(rank_worlds, xs)])
+    assert len(glob) == bounds[-1]
+    for rw, x in zip(rank_worlds, xs):
+        x[rw.n_local_pad:rw.n_local_pad + rw.n_halo] = glob[rw.halo_global]
+
+
+class DistributedHotPath:
+    """bench.py's stepping object for N > 1: compile this rank's part, step with the two collectives."""
+
+    def __init__(self, world: dict, specs, betas: Dict[str, float], device, rank: int, world_size: int,
+                 seed: int = 0, group=None, modes: Optional[Dict[str, str]] = None):
+        import ctypes as C
+
+        from . import _native as N
+        from .benchrun import EventLog
+        from .engine import AgentBuffers, InfectionEngine
+        from .plan import DevicePlan, compile_plan
+
+        self.device = torch.device(device)
+        self.rank, self.world_size, self.group = rank, world_size, group
+        rw = self.rw = build_rank_world(world, rank, world_size, modes)
+        host = compile_plan(rw.n_local, rw.edge_sets, age=rw.age, sex=rw.sex, n_ext_agents=rw.n_ext,
+                            layout="tiled", slices=(rw.n_slices, rw.slice_agents))
+        partial = [n for n in rw.edge_sets if rw.modes[n] == "partial"]
+        self.engine = InfectionEngine(DevicePlan(host, specs, self.device, flat_cum_sets=partial))
+        self.flat_cum = self.engine.plan.flat_cum
+        self.networks = list(world["networks"])
+        self.betas, self.seed = betas, seed
+        a0, a1 = int(rw.bounds[rank]), int(rw.bounds[rank + 1])
+        st = {k: torch.from_numpy(np.ascontiguousarray(v[a0:a1])).to(self.device) for k, v in world["state"].items()}
+        st["transmission"] = torch.zeros(rw.n_ext, dtype=torch.float32, device=self.device)
+        self.state = st
+        self.new_infected = torch.empty(rw.n_local, dtype=torch.float32, device=self.device)
+        self.bufs = AgentBuffers(self.engine.plan, max_infectiousness=st["max_infectiousness"], shape=st["shape"],
+                                 rate=st["rate"], shift=st["shift"], infection_time=st["infection_time"],
+                                 is_infected=st["is_infected"], susceptibility=st["susceptibility"],
+                                 transmission=st["transmission"], current_stage=st["current_stage"])
+        self.io = self.engine.io(new_infected=self.new_infected)
+        lib = N.load()
+
+        def pack(index, src, out):
+            N.check(lib.gj_pack_f32(index.numel(), N.ptr(index), N.ptr(src), N.ptr(out), N.current_stream()),
+                    "gj_pack_f32")
+
+        self.halo = HaloExchange(rw, self.device, group=group, pack=pack) if world_size > 1 else None
+        self.a0 = a0
+        self.t = 0
+        self.log = EventLog()
+
+    def params(self):
+        return self.engine.params(now=1.0 + self.t, delta_time=1.0, day_type=0, active=self.networks,
+                                  betas=self.betas, seed=self.seed, step=self.t, agent_offset=self.a0)
+
+    def step(self, timed: bool = False):
+        import torch.distributed as dist
+
+        p, e = self.params(), self.engine
+        mark = self.log.mark if timed else (lambda label: None)
+        mark("begin")
+        e.step_phase(self.bufs, p, self.io, 0)
+        mark("transmission")
+        if self.halo is not None:
+            self.halo.exchange(self.state["transmission"])
+            mark("halo_all_to_all")
+        e.step_phase(self.bufs, p, self.io, 1)
+        mark("tile_scatter")
+        e.step_phase(self.bufs, p, self.io, 5)
+        mark("tile_venues_B")
+        if self.world_size > 1 and self.flat_cum is not None and self.flat_cum.numel():
+            dist.all_reduce(self.flat_cum, group=self.group)
+            mark("partial_all_reduce")
+        e.step_phase(self.bufs, p, self.io, 6)
+        mark("tile_venues_C")
+        e.step_phase(self.bufs, p, self.io, 3)
+        mark("tile_agents")
+        self.t += 1
+
+    def reset_timers(self):
+        self.log.clear()
+
+    def kernel_ms(self) -> Dict[str, float]:
+        return {k: float(np.mean(v)) for k, v in self.log.spans().items()}

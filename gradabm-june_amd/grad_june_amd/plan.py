@@ -187,10 +187,10 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
         raise ValueError(layout)
     n_ext = n_agents if n_ext_agents is None else n_ext_agents
     want_csr, want_tiled = layout in ("csr", "both"), layout in ("tiled", "both")
-    if want_tiled and n_ext != n_agents:
-        raise ValueError("the tiled layout has no halo agents")
     cls_all = None if age is None else agent_class_of(age, sex)
-    S, SA = slices if slices is not None else TL.choose_slices(n_agents)
+    S, SA = slices if slices is not None else TL.choose_slices(n_ext)
+    if want_tiled and n_ext != n_agents and (-(-n_agents // SA)) * SA > n_ext:
+        raise ValueError("halo agents must start on a slice boundary (pad the owned range to a multiple of SA)")
     sets, all_blocks, all_long, work = [], [], [], []
     slot = 0
     for sid, (name, es) in enumerate(edge_sets.items()):
@@ -232,7 +232,9 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
 class DevicePlan:
     """The plan resident in HBM + the ctypes ``gj_plan`` that points at it."""
 
-    def __init__(self, host: HostPlan, networks: Sequence[NetworkSpec], device):
+    def __init__(self, host: HostPlan, networks: Sequence[NetworkSpec], device, flat_cum_sets: Sequence[str] = ()):
+        """flat_cum_sets: edge sets whose ``cum`` workspaces are carved from ONE contiguous buffer
+        (``self.flat_cum``) so that a single collective can combine them across ranks."""
         self.host = host
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -263,6 +265,11 @@ class DevicePlan:
         self.keep = []
         self.cum: List[torch.Tensor] = []
         self.tiled_c = None
+        flat_sizes = {s.name: max(1, s.n_venues) * max(1, per_set_nets.get(s.name, 1))
+                      for s in host.sets if s.name in flat_cum_sets}
+        self.flat_cum = (torch.zeros(sum(flat_sizes.values()), dtype=torch.float32, device=dev)
+                         if flat_sizes else None)
+        flat_off = 0
         plan = N.Plan()
         plan.n_agents = host.n_agents
         plan.n_ext_agents = host.n_ext_agents
@@ -274,7 +281,11 @@ class DevicePlan:
             t = dict(v_pc=up(s.v_pcontact))
             if s.v_rowptr is not None:
                 t.update(v_rowptr=up(s.v_rowptr), v_agent=up(s.v_agent), a_rowptr=up(s.a_rowptr), a_venue=up(s.a_venue))
-            cum = torch.zeros(max(1, s.n_venues) * stride, dtype=torch.float32, device=dev)
+            if s.name in flat_sizes:
+                cum = self.flat_cum[flat_off:flat_off + flat_sizes[s.name]]
+                flat_off += flat_sizes[s.name]
+            else:
+                cum = torch.zeros(max(1, s.n_venues) * stride, dtype=torch.float32, device=dev)
             e = plan.sets[i]
             e.n_venues, e.n_edges = s.n_venues, s.n_edges
             e.v_pcontact = t["v_pc"].data_ptr()

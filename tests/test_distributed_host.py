@@ -1,0 +1,141 @@
+"""CPU: agent partition, halo / partial-sum exchange plans and the real torch.distributed collectives
+(gloo, world_size 2) - the multi-GPU path minus the kernels, which are stood in by the tiled
+layout's numpy emulation (tiling.emulate_pass1/2, itself pinned against bincount sums)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from grad_june_amd.distributed import (HaloExchange, build_rank_world, choose_modes, emulate_exchange,
+                                       partition_bounds)
+from grad_june_amd.plan import compile_plan
+from grad_june_amd.synthetic import make_world
+from grad_june_amd.tiling import emulate_pass1, emulate_pass2
+
+
+def small_world(n=6000, seed=5):
+    w = make_world("c3", n_agents=n, seed=seed)
+    w["state"]["transmission"] = np.random.default_rng(seed).random(n).astype(np.float32)
+    return w
+
+
+def reference_pass(world, x):
+    """Global single-rank result per set: cum[v] (beta = 1) and per-agent sum of cum over its venues."""
+    out = {}
+    for name, es in world["edge_sets"].items():
+        pc = np.clip(1.0 / (es["people"].astype(np.float64) - 1), None, 1.0).clip(0.0)
+        V = len(es["people"])
+        cum = pc * np.bincount(es["venue"], weights=x[es["agent"]].astype(np.float64), minlength=V)
+        acc = np.bincount(es["agent"], weights=cum[es["venue"]], minlength=world["n_agents"])
+        out[name] = (cum, acc)
+    return out
+
+
+def rank_pass(rw, host, x_ext, all_reduce):
+    """One rank's pass 1 + pass 2 on its compiled (tiled) plan, `all_reduce` combining partial sets."""
+    cums = {}
+    for s in host.sets:
+        _, cums[s.name] = emulate_pass1(s.tiled, x_ext.copy() if len(x_ext) >= host.n_slices * host.slice_agents
+                                        else np.pad(x_ext, (0, host.n_slices * host.slice_agents - len(x_ext))),
+                                        host.slice_agents, beta=1.0)
+    for name in cums:
+        if rw.modes[name] == "partial":
+            cums[name] = all_reduce(name, cums[name])
+    accs = {}
+    for s in host.sets:
+        accs[s.name] = emulate_pass2(s.tiled, cums[s.name], host.n_slices * host.slice_agents, host.slice_agents)[: rw.n_local]
+    return cums, accs
+
+
+@pytest.mark.parametrize("R", [2, 3, 8])
+def test_partition_matches_single_rank(R):
+    world = small_world()
+    x = world["state"]["transmission"]
+    ref = reference_pass(world, x)
+    modes = choose_modes(world, R)
+    assert set(modes.values()) == {"halo", "partial"}
+    rws = [build_rank_world(world, r, R, modes, slice_agents=256) for r in range(R)]
+    b = partition_bounds(world["n_agents"], R)
+    xs = []
+    for rw in rws:
+        xe = np.zeros(rw.n_ext, dtype=np.float32)
+        xe[: rw.n_local] = x[b[rw.rank]:b[rw.rank + 1]]
+        xs.append(xe)
+        assert rw.n_local_pad % rw.slice_agents == 0 or rw.n_halo == 0
+        owner = np.searchsorted(b, rw.halo_global, side="right") - 1
+        assert (owner != rw.rank).all() and np.array_equal(np.bincount(owner, minlength=R), rw.halo_from)
+    emulate_exchange(rws, xs)
+    hosts = [compile_plan(rw.n_local, rw.edge_sets, age=rw.age, sex=rw.sex, n_ext_agents=rw.n_ext, layout="tiled",
+                          slices=(rw.n_slices, rw.slice_agents), sv_max=512, eb_target=4096) for rw in rws]
+    # partial sets: emulate the all-reduce by summing every rank's partial cum
+    partial_names = [n for n, m in modes.items() if m == "partial"]
+    pre = {}
+    for rw, host, xe in zip(rws, hosts, xs):
+        for s in host.sets:
+            if s.name in partial_names:
+                pad = np.pad(xe, (0, host.n_slices * host.slice_agents - len(xe)))
+                pre.setdefault(s.name, []).append(emulate_pass1(s.tiled, pad, host.slice_agents, beta=1.0)[1])
+    total = {n: np.sum(v, axis=0) for n, v in pre.items()}
+    for rw, host, xe in zip(rws, hosts, xs):
+        cums, accs = rank_pass(rw, host, xe, lambda name, c: total[name])
+        lo, hi = b[rw.rank], b[rw.rank + 1]
+        for name in world["edge_sets"]:
+            cum_ref, acc_ref = ref[name]
+            if rw.modes[name] == "halo":     # local venue numbering: compare through venue_global
+                assert np.allclose(cums[name], cum_ref[rw.venue_global[name]], rtol=1e-5, atol=1e-7), name
+            else:
+                assert np.allclose(cums[name], cum_ref, rtol=1e-5, atol=1e-7), name
+            assert np.allclose(accs[name], acc_ref[lo:hi], rtol=1e-5, atol=1e-6), name
+
+
+def test_single_rank_is_all_local():
+    world = small_world(2000)
+    rw = build_rank_world(world, 0, 1)
+    assert rw.n_halo == 0 and rw.n_ext == rw.n_local == 2000 and set(rw.modes.values()) == {"local"}
+    for name, es in world["edge_sets"].items():
+        assert np.array_equal(rw.edge_sets[name]["agent"], es["agent"])
+
+
+def _gloo_worker(rank, R, port, ok):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=R)
+    try:
+        world = small_world(3000, seed=9)
+        x = world["state"]["transmission"]
+        b = partition_bounds(3000, R)
+        rw = build_rank_world(world, rank, R, slice_agents=128)
+        xe = torch.zeros(rw.n_ext)
+        xe[: rw.n_local] = torch.from_numpy(x[b[rank]:b[rank + 1]])
+        halo = HaloExchange(rw, "cpu")
+        halo.exchange(xe)                                   # the real all_to_all_single
+        assert torch.equal(xe[rw.n_local_pad:], torch.from_numpy(x[rw.halo_global])), "halo values"
+        assert sum(halo.send_counts) == halo.send_index.numel()
+        # partial sums through the real all_reduce
+        host = compile_plan(rw.n_local, rw.edge_sets, age=rw.age, sex=rw.sex, n_ext_agents=rw.n_ext, layout="tiled",
+                            slices=(rw.n_slices, rw.slice_agents))
+        ref = reference_pass(world, x)
+        pad = np.pad(xe.numpy(), (0, host.n_slices * host.slice_agents - rw.n_ext))
+        for s in host.sets:
+            cum = emulate_pass1(s.tiled, pad, host.slice_agents, beta=1.0)[1]
+            if rw.modes[s.name] == "partial":
+                t = torch.from_numpy(cum.copy())
+                dist.all_reduce(t)
+                assert np.allclose(t.numpy(), ref[s.name][0], rtol=1e-5, atol=1e-7), s.name
+            else:
+                assert np.allclose(cum, ref[s.name][0][rw.venue_global[s.name]], rtol=1e-5, atol=1e-7), s.name
+        ok[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world_size_2_collectives():
+    R = 2
+    ok = mp.get_context("spawn").Array("i", [0] * R)
+    port = 29500 + (os.getpid() % 400)
+    mp.spawn(_gloo_worker, args=(R, port, ok), nprocs=R, join=True)
+    assert list(ok) == [1] * R
