@@ -188,7 +188,7 @@ class DistributedHotPath:
     """bench.py's stepping object for N > 1: compile this rank's part, step with the two collectives."""
 
     def __init__(self, world: dict, specs, betas: Dict[str, float], device, rank: int, world_size: int,
-                 seed: int = 0, group=None, modes: Optional[Dict[str, str]] = None):
+                 seed: int = 0, group=None, modes: Optional[Dict[str, str]] = None, collectives: bool = True):
         import ctypes as C
 
         from . import _native as N
@@ -222,7 +222,7 @@ class DistributedHotPath:
             N.check(lib.gj_pack_f32(index.numel(), N.ptr(index), N.ptr(src), N.ptr(out), N.current_stream()),
                     "gj_pack_f32")
 
-        self.halo = HaloExchange(rw, self.device, group=group, pack=pack) if world_size > 1 else None
+        self.halo = HaloExchange(rw, self.device, group=group, pack=pack) if (world_size > 1 and collectives) else None
         self.a0 = a0
         self.t = 0
         self.log = EventLog()

@@ -36,7 +36,7 @@ def test_virtual_ranks_match_single_rank(device, R):
     world = make_world("c3", n_agents=40_000, seed=3, infected_fraction=0.05)
     specs, betas = B.network_specs(world), B.betas_of(world)
     single = SingleGpuHotPath(world, specs, betas, device, seed=7, layout="tiled")
-    ranks = [VirtualRank(world, specs, betas, device, r, R, seed=7) for r in range(R)]
+    ranks = [VirtualRank(world, specs, betas, device, r, R, seed=7, collectives=False) for r in range(R)]
     assert {m for rk in ranks for m in rk.rw.modes.values()} == {"halo", "partial"}
     b = partition_bounds(world["n_agents"], R)
     for step in range(3):
