@@ -100,6 +100,9 @@ def kernel_bytes(world, networks):
         "tile_scatter": (4 * e_sets + 4 * e_nets) // 2,
         "tile_venues": (4 * e_sets + 4 * e_nets) // 2 + 12 * v_nets + (4 * e_sets + 4 * e_nets) // 2,
         "tile_agents": (4 * e_sets + 4 * e_nets) // 2 + 8 * N * A + 32 * A,
+        # multi-GPU: the venue launch runs as its two halves around the partial-sum all-reduce
+        "tile_venues_B": (4 * e_sets + 4 * e_nets) // 2 + 12 * v_nets,
+        "tile_venues_C": (4 * e_sets + 4 * e_nets) // 2,
     }
 
 
@@ -187,6 +190,9 @@ def main():
         from grad_june_amd.distributed import DistributedHotPath
 
         runner = DistributedHotPath(world, specs, betas, dev, rank, world_size, seed=args.seed)
+        extra = {"exchange": {"modes": runner.rw.modes, "halo_agents_rank0": int(runner.rw.n_halo),
+                              "halo_bytes_per_step_rank0": runner.halo.bytes_per_step if runner.halo else 0,
+                              "partial_sum_floats": int(runner.flat_cum.numel()) if runner.flat_cum is not None else 0}}
     else:
         from grad_june_amd.benchrun import SingleGpuHotPath
 
@@ -200,6 +206,7 @@ def main():
                 sa = args.slice_agents
                 kw["slices"] = (-(-world["n_agents"] // sa), sa)
         runner = SingleGpuHotPath(world, specs, betas, dev, seed=args.seed, layout=args.layout, **kw)
+        extra = {}
     t_setup = time.time() - t0
 
     def sync():
@@ -232,7 +239,7 @@ def main():
     b_step = algorithmic_bytes(world, networks)
     kb = kernel_bytes(world, networks)
     kt = runner.kernel_ms()          # mean ms per launch, HIP events on the launch stream
-    dom = max(kt, key=kt.get)
+    dom = max((k for k in kt if k in kb), key=kt.get)
     share = 1.0 / world_size         # each rank streams its own partition
     achieved = kb[dom] * share / (kt[dom] * 1e-3) / 1e9
     out = {
@@ -263,6 +270,7 @@ def main():
         "kernel_ms": kt,
         "setup_s": {"generate": t_gen, "total": t_setup},
     }
+    out.update(extra)
     if not args.no_cpu_baseline and world_size == 1:
         out["cpu_baseline"] = cpu_baseline(world, networks, betas, tables, args.cpu_seconds)
     print(json.dumps(out))
