@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--eb-target", type=int, default=None)
     ap.add_argument("--slice-agents", type=int, default=None, help="tiled: agents per slice (multiple of 64)")
     ap.add_argument("--edge-mult", type=float, default=1.0, help="experiments: memberships per agent x this")
+    ap.add_argument("--force-distributed", action="store_true",
+                    help="diagnostic: take the torch.distributed code path even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
     return ap.parse_args()
@@ -169,10 +171,13 @@ def main():
 
     if rank == 0:
         entry.build()
-    if world_size > 1:
+    distributed = world_size > 1 or args.force_distributed
+    if distributed:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
         dist.barrier()
 
     from grad_june_amd.synthetic import make_world, algorithmic_bytes, network_edges
@@ -186,10 +191,14 @@ def main():
     tables = {s.name: s.table for s in specs if s.table is not None}
     t_gen = time.time() - t0
 
-    if world_size > 1:
-        from grad_june_amd.distributed import DistributedHotPath
+    if distributed:
+        from grad_june_amd.distributed import DistributedHotPath, choose_modes
 
-        runner = DistributedHotPath(world, specs, betas, dev, rank, world_size, seed=args.seed)
+        modes = None
+        if world_size == 1:   # diagnostic: exercise the partial-sum all-reduce with a single rank
+            modes = {k: ("partial" if v == "local" and k != "household" else v)
+                     for k, v in choose_modes(world, 1).items()}
+        runner = DistributedHotPath(world, specs, betas, dev, rank, world_size, seed=args.seed, modes=modes)
         extra = {"exchange": {"modes": runner.rw.modes, "halo_agents_rank0": int(runner.rw.n_halo),
                               "halo_bytes_per_step_rank0": runner.halo.bytes_per_step if runner.halo else 0,
                               "partial_sum_floats": int(runner.flat_cum.numel()) if runner.flat_cum is not None else 0}}
@@ -211,7 +220,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world_size > 1:
+        if distributed:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -224,14 +233,13 @@ def main():
         runner.step(timed=True)
     sync()
     elapsed = time.perf_counter() - t0
-    if world_size > 1:
+    if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     if rank != 0:
-        if world_size > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     sps = args.steps / elapsed
@@ -274,7 +282,7 @@ def main():
     if not args.no_cpu_baseline and world_size == 1:
         out["cpu_baseline"] = cpu_baseline(world, networks, betas, tables, args.cpu_seconds)
     print(json.dumps(out))
-    if world_size > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

@@ -246,7 +246,7 @@ class DistributedHotPath:
         mark("tile_scatter")
         e.step_phase(self.bufs, p, self.io, 5)
         mark("tile_venues_B")
-        if self.world_size > 1 and self.flat_cum is not None and self.flat_cum.numel():
+        if self.flat_cum is not None and self.flat_cum.numel() and dist.is_initialized():
             dist.all_reduce(self.flat_cum, group=self.group)
             mark("partial_all_reduce")
         e.step_phase(self.bufs, p, self.io, 6)
