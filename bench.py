@@ -279,6 +279,16 @@ def main():
         "setup_s": {"generate": t_gen, "total": t_setup},
     }
     out.update(extra)
+    # HBM traffic of the dominant kernel from the committed PMC profile of this exact workload
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        w = pmc["workload"]
+        if (w["preset"], w["n_agents"], w["layout"]) == (args.preset, world["n_agents"], args.layout) and world_size == 1:
+            out["roofline"]["traffic"] = pmc["per_launch_bytes"][dom]["total"]
+            out["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE)"
+    except (OSError, KeyError):
+        pass
     if not args.no_cpu_baseline and world_size == 1:
         out["cpu_baseline"] = cpu_baseline(world, networks, betas, tables, args.cpu_seconds)
     print(json.dumps(out))
