@@ -384,6 +384,64 @@ __global__ __launch_bounds__(kThreads) void k_sample_infect(int64_t n, const flo
   }
 }
 
+// f1: disease-stage progression (reference grad_june/symptoms.py:204-247, 82-128), one lane per agent
+struct SymptomsArgs {
+  gj_symptoms_params P;
+  int64_t n;
+  const uint8_t* cls;
+  const float* new_inf;
+  float* cur;
+  float* nxt;
+  float* ttn;
+  const float* progresses;
+  const float* dwell;
+};
+
+__device__ __forceinline__ float dwell_sample(int kind, float loc, float scale, float z) {
+  const float v = loc + scale * z;
+  return kind == 1 ? expf(v) : v;
+}
+
+__global__ __launch_bounds__(kThreads) void k_symptoms(const SymptomsArgs S) {
+  const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= S.n) return;
+  const int n_stages = S.P.n_stages;
+  const float time = S.P.time;
+  const float nw = S.new_inf[a];
+  float cur = S.cur[a], nx = S.nxt[a], tt = S.ttn[a];
+  nx = nx + nw * (2.0f - nx);                       // newly infected: next stage = exposed, due now
+  tt = tt + nw * (time - tt);
+  const bool moving = (time >= tt) && (cur < (float)(n_stages - 1));
+  cur = cur - (cur - nx) * (moving ? 1.0f : 0.0f);
+  int s = (int)cur;
+  s = min(max(s, 0), n_stages - 1);
+  const int age = S.cls[a] % 100;
+  if (moving && s >= 2 && s <= n_stages - 2 && cur == (float)s) {
+    bool onward;
+    float d;
+    if (S.progresses) {
+      onward = S.progresses[a] != 0.0f;
+      d = S.dwell[a];
+    } else {
+      uint32_t r[4];
+      philox4x32_10((uint64_t)(S.P.agent_offset + a), S.P.step | (1ull << 63), S.P.seed, r);
+      onward = u01(r[0]) < S.P.progress[s * 100 + age];
+      const float z = sqrtf(-2.0f * logf(u01(r[1]))) * cosf(6.2831853071795865f * u01(r[2]));
+      d = onward ? dwell_sample(S.P.next_kind[s], S.P.next_loc[s], S.P.next_scale[s], z)
+                 : dwell_sample(S.P.rec_kind[s], S.P.rec_loc[s], S.P.rec_scale[s], z);
+    }
+    if (onward) {
+      nx = nx + 1.0f;
+    } else {
+      nx = nx - nx;
+    }
+    tt = tt + d;
+  }
+  S.cur[a] = cur;
+  S.nxt[a] = nx;
+  S.ttn[a] = tt;
+}
+
 // a2 alone: q*transmission for a caller-supplied transmission vector
 __global__ __launch_bounds__(kThreads) void k_quarantine_transmission(int64_t n, const float* __restrict__ stage,
                                                                       const float* __restrict__ trans,
@@ -856,6 +914,31 @@ int gj_sample_infect(int64_t n_agents, const float* not_infected_probs, const fl
   hipLaunchKernelGGL(gj::k_sample_infect, dim3((unsigned)blocks), dim3(gj::kThreads), 0, (hipStream_t)stream, n_agents,
                      not_infected_probs, exp_noise, seed, step, agent_offset, now, new_infected, susceptibility,
                      is_infected, infection_time);
+  return gj::launch_status();
+}
+
+int gj_symptoms_update(int64_t n, const uint8_t* agent_class, const float* new_infected, float* current_stage,
+                       float* next_stage, float* time_to_next_stage, const gj_symptoms_params* params,
+                       const float* progresses, const float* dwell, void* stream) {
+  if (n < 0) return GJ_E_RANGE;
+  if (n == 0) return GJ_OK;
+  if (!agent_class || !new_infected || !current_stage || !next_stage || !time_to_next_stage || !params)
+    return GJ_E_NULL;
+  if (params->n_stages < 3 || params->n_stages > GJ_MAX_STAGES) return GJ_E_RANGE;
+  if ((progresses == nullptr) != (dwell == nullptr)) return GJ_E_NULL;   // inject both or neither
+  if (!progresses && !params->progress) return GJ_E_NULL;
+  gj::SymptomsArgs S;
+  S.P = *params;
+  S.n = n;
+  S.cls = agent_class;
+  S.new_inf = new_infected;
+  S.cur = current_stage;
+  S.nxt = next_stage;
+  S.ttn = time_to_next_stage;
+  S.progresses = progresses;
+  S.dwell = dwell;
+  hipLaunchKernelGGL(gj::k_symptoms, dim3((unsigned)((n + gj::kThreads - 1) / gj::kThreads)), dim3(gj::kThreads), 0,
+                     (hipStream_t)stream, S);
   return gj::launch_status();
 }
 

@@ -136,6 +136,28 @@ class StepIO(C.Structure):
     ]
 
 
+GJ_MAX_STAGES = 16
+
+
+class SymptomsParams(C.Structure):
+    _fields_ = [
+        ("n_stages", C.c_int32),
+        ("_pad", C.c_int32),
+        ("progress", _vp),
+        ("next_kind", C.c_int32 * GJ_MAX_STAGES),
+        ("next_loc", C.c_float * GJ_MAX_STAGES),
+        ("next_scale", C.c_float * GJ_MAX_STAGES),
+        ("rec_kind", C.c_int32 * GJ_MAX_STAGES),
+        ("rec_loc", C.c_float * GJ_MAX_STAGES),
+        ("rec_scale", C.c_float * GJ_MAX_STAGES),
+        ("time", C.c_float),
+        ("_pad2", C.c_float),
+        ("seed", C.c_uint64),
+        ("step", C.c_uint64),
+        ("agent_offset", C.c_int64),
+    ]
+
+
 #: every symbol include/gradjune_hip.h declares: (restype, argtypes)
 SYMBOLS = {
     "gj_version": (C.c_int, []),
@@ -150,6 +172,10 @@ SYMBOLS = {
     "gj_sample_infect": (
         C.c_int,
         [C.c_int64, _vp, _vp, C.c_uint64, C.c_uint64, C.c_int64, C.c_float, _vp, _vp, _vp, _vp, _vp],
+    ),
+    "gj_symptoms_update": (
+        C.c_int,
+        [C.c_int64, _vp, _vp, _vp, _vp, _vp, C.POINTER(SymptomsParams), _vp, _vp, _vp],
     ),
     "gj_step": (C.c_int, [C.POINTER(Plan), C.POINTER(AgentState), C.POINTER(StepParams), C.POINTER(StepIO), _vp]),
     "gj_step_phase": (

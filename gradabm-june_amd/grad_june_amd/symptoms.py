@@ -1,16 +1,21 @@
-"""Disease-stage progression (reference grad_june/symptoms.py:10-257).
+"""Disease-stage progression (reference grad_june/symptoms.py:10-257) - row f1 of SURVEY section 8.
 
-NOT part of the accelerated path in this release ("next"): it runs
-right after the hot path each step and is kept as device-side torch ops so that ``GradJune`` /
-``Runner`` are complete.  Semantics follow the reference's state machine; unlike the reference it
-never synchronises with the host (the reference's ``if n_symp > 0`` checks force a device->host
-sync per stage), so the random-number stream differs - parity for this module is statistical.
+Runs right after the hot path each step.  ``SymptomsUpdater.forward`` is one fused per-agent HIP
+kernel (``gj_symptoms_update``): the reference's ~60 elementwise ops, ``torch.bernoulli``, up to ten
+``rsample((A,))`` draws and two device->host syncs per stage (``if n_symp > 0``) become a single
+pass over the three symptom arrays.  Randomness is Philox4x32-10 keyed by (seed, step, agent) or,
+for parity with the reference, injected (``progresses`` = the bernoulli outcome, ``dwell`` = the
+stage-time sample each agent consumes).  Stage-time distributions other than LogNormal / Normal
+are not supported by the kernel and raise.
 """
 from __future__ import annotations
+
+import ctypes as C
 
 import torch
 import yaml
 
+from . import _native as N
 from .utils import parse_age_probabilities, parse_distribution
 
 
@@ -50,6 +55,26 @@ class SymptomsSampler:
     def _get_prob_next_symptoms_stage(self, ages, stages):
         return self.stage_transition_probabilities[stages, ages]
 
+    def kernel_params(self) -> "N.SymptomsParams":
+        """Tables of the state machine as the kernel takes them."""
+        p = N.SymptomsParams()
+        n = len(self.stages)
+        if n > N.GJ_MAX_STAGES:
+            raise NotImplementedError(f"at most {N.GJ_MAX_STAGES} symptom stages")
+        p.n_stages = n
+        for table, kind, loc, scale in ((self.stage_transition_times, p.next_kind, p.next_loc, p.next_scale),
+                                        (self.recovery_times, p.rec_kind, p.rec_loc, p.rec_scale)):
+            for i, dist in table.items():
+                if dist is None:
+                    kind[i] = 0
+                elif isinstance(dist, torch.distributions.LogNormal):
+                    kind[i], loc[i], scale[i] = 1, float(dist.loc), float(dist.scale)
+                elif isinstance(dist, torch.distributions.Normal):
+                    kind[i], loc[i], scale[i] = 2, float(dist.loc), float(dist.scale)
+                else:
+                    raise NotImplementedError(f"stage-time distribution {type(dist).__name__}: only LogNormal/Normal")
+        return p
+
     def sample_next_stage(self, ages, current_stage, next_stage, time_to_next_stage, time):
         n = ages.shape[0]
         moving = self._get_need_to_transition(current_stage, time_to_next_stage, time)
@@ -86,7 +111,55 @@ class SymptomsUpdater(torch.nn.Module):
     def stages_ids(self):
         return self.symptoms_sampler.stages_ids
 
-    def forward(self, data, timer, new_infected):
+    def forward(self, data, timer, new_infected, progresses=None, dwell=None):
+        """HIP path (fused kernel).  ``progresses`` / ``dwell``: optional injected randomness [A]."""
+        from .world import require_hip
+
+        ag = data["agent"]
+        try:
+            symptoms = ag.symptoms
+        except (KeyError, AttributeError):
+            raise KeyError("data must contain the 'agent' key.")
+        for key in ("current_stage", "next_stage", "time_to_next_stage"):
+            if key not in symptoms:
+                raise KeyError("symptoms must contain the 'current_stage', 'next_stage', and "
+                               "'time_to_next_stage' keys.")
+        device = require_hip(new_infected.device)
+        n = new_infected.numel()
+        for key in ("current_stage", "next_stage", "time_to_next_stage"):
+            t = symptoms[key]
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.device != device:
+                symptoms[key] = t.detach().to(device=device, dtype=torch.float32).contiguous()
+        sampler = self.symptoms_sampler
+        cls = getattr(self, "_cls", None)
+        if cls is None or cls.numel() != n or cls.device != device:
+            sex = ag["sex"] if "sex" in ag else torch.zeros_like(ag.age)
+            cls = self._cls = (sex.to(device).long() * 100 + ag.age.to(device).long()).to(torch.uint8).contiguous()
+        table = getattr(self, "_table", None)
+        if table is None or table.device != device:
+            table = self._table = sampler.stage_transition_probabilities.to(device=device, dtype=torch.float32).contiguous()
+        p = sampler.kernel_params()
+        p.progress = table.data_ptr()
+        p.time = float(timer.now)
+        if getattr(self, "rng_seed", None) is None:
+            self.rng_seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
+        self.n_calls = getattr(self, "n_calls", 0) + 1
+        p.seed, p.step, p.agent_offset = self.rng_seed, self.n_calls, 0
+        nw = new_infected.detach().to(torch.float32).contiguous()
+        if (progresses is None) != (dwell is None):
+            raise ValueError("inject both progresses and dwell, or neither")
+        if progresses is not None:
+            progresses = progresses.to(device=device, dtype=torch.float32).contiguous()
+            dwell = dwell.to(device=device, dtype=torch.float32).contiguous()
+        N.check(N.load().gj_symptoms_update(n, N.ptr(cls), N.ptr(nw), N.ptr(symptoms["current_stage"]),
+                                            N.ptr(symptoms["next_stage"]), N.ptr(symptoms["time_to_next_stage"]),
+                                            C.byref(p), N.ptr(progresses), N.ptr(dwell), N.current_stream()),
+                "gj_symptoms_update")
+        self.used_kernel = True
+        return symptoms
+
+    def forward_torch(self, data, timer, new_infected):
+        """The same state machine as plain device-side torch ops (kept for cross-checking)."""
         try:
             symptoms = data["agent"].symptoms
         except (KeyError, AttributeError):

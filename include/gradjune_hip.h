@@ -252,6 +252,34 @@ int gj_sample_infect(int64_t n_agents, const float* not_infected_probs, const fl
                      float* new_infected, float* susceptibility, float* is_infected,
                      float* infection_time, void* stream);
 
+/* ---- row f1 ("next"): disease-stage progression, run right after the hot path each step -------
+ * replaces SymptomsUpdater.forward + SymptomsSampler.sample_next_stage
+ * (grad_june/symptoms.py:204-247, 82-128) as one fused per-agent kernel.                        */
+#define GJ_MAX_STAGES 16
+typedef struct gj_symptoms_params {
+  int32_t n_stages;                 /* len(symptoms.stages), <= GJ_MAX_STAGES (reference: 8)     */
+  int32_t _pad;
+  const float* progress;            /* device [n_stages*100] P(progress | stage, age) (symptoms.py:39-51) */
+  int32_t next_kind[GJ_MAX_STAGES]; /* dwell time before progressing: 0 none, 1 LogNormal, 2 Normal */
+  float next_loc[GJ_MAX_STAGES];
+  float next_scale[GJ_MAX_STAGES];
+  int32_t rec_kind[GJ_MAX_STAGES];  /* dwell time before recovering                              */
+  float rec_loc[GJ_MAX_STAGES];
+  float rec_scale[GJ_MAX_STAGES];
+  float time;                       /* timer.now                                                 */
+  float _pad2;
+  uint64_t seed, step;              /* Philox key / stream (when no noise is injected)           */
+  int64_t agent_offset;
+} gj_symptoms_params;
+
+/* current_stage / next_stage / time_to_next_stage: device fp32 [n], updated in place.
+ * progresses / dwell: optional injected randomness (device fp32 [n]): the torch.bernoulli outcome
+ * and the stage-time sample each agent consumes; NULL = Philox4x32-10(seed, step, agent).       */
+int gj_symptoms_update(int64_t n, const uint8_t* agent_class, const float* new_infected,
+                       float* current_stage, float* next_stage, float* time_to_next_stage,
+                       const gj_symptoms_params* params, const float* progresses, const float* dwell,
+                       void* stream);
+
 /* The production step: a1..a9 = the middle of GradJune.forward (grad_june/model.py:125-138)
  * as three dependent launches on `stream` (+1 when the plan has long rows).                */
 int gj_step(const gj_plan* plan, const gj_agent_state* state, const gj_step_params* params,

@@ -203,6 +203,45 @@ def infect_people(susceptibility, is_infected, infection_time, new_infected, now
 
 
 # --------------------------------------------------------------------------------------
+# f1 ("next" row)  SymptomsUpdater.forward + SymptomsSampler.sample_next_stage
+#     grad_june/symptoms.py:204-247, 82-128 - with the randomness supplied by the caller:
+#     progresses[a]  = the torch.bernoulli(probs) outcome (symptoms.py:96)
+#     dwell[a]       = the stage-time sample the agent would use (T_i or R_i .rsample, :113-126)
+# --------------------------------------------------------------------------------------
+def symptoms_update(age, current_stage, next_stage, time_to_next_stage, new_infected, time,
+                    n_stages: int, progresses, dwell):
+    next_stage = next_stage + new_infected * (2.0 - next_stage)
+    time_to_next_stage = time_to_next_stage + new_infected * (time - time_to_next_stage)
+    mask1 = time >= time_to_next_stage
+    mask2 = current_stage < n_stages - 1
+    mask_transition = mask1 * mask2
+    current_stage = current_stage - (current_stage - next_stage) * mask_transition
+    mask_symp_stage = progresses.to(torch.bool)
+    mask_recovered_stage = ~mask_symp_stage
+    for i in range(2, n_stages - 1):
+        mask_stage = current_stage == i
+        mask_stage = mask_stage * current_stage / i
+        mask_updating = mask_stage * mask_transition
+        mask_symp = mask_updating * mask_symp_stage
+        next_stage = next_stage + mask_symp
+        time_to_next_stage = time_to_next_stage + dwell * mask_symp
+        mask_rec = mask_updating * mask_recovered_stage
+        next_stage = next_stage - next_stage * mask_rec
+        time_to_next_stage = time_to_next_stage + dwell * mask_rec
+    return current_stage, next_stage, time_to_next_stage
+
+
+def symptoms_progress_probability(table, age, current_stage, next_stage, time_to_next_stage, new_infected, time,
+                                  n_stages: int):
+    """probs handed to torch.bernoulli: table[stage after the due transition, age] (symptoms.py:93-95)."""
+    next_stage = next_stage + new_infected * (2.0 - next_stage)
+    ttn = time_to_next_stage + new_infected * (time - time_to_next_stage)
+    mt = (time >= ttn) * (current_stage < n_stages - 1)
+    cur = current_stage - (current_stage - next_stage) * mt
+    return table[cur.long(), age]
+
+
+# --------------------------------------------------------------------------------------
 # whole hot-path step on a neutral "world" description (rows a1-a9 in model.py:125-138 order)
 # --------------------------------------------------------------------------------------
 def network_kind(name: str) -> str:

@@ -181,8 +181,74 @@ def capture_step(model, data, timer, *, run_symptoms=True):
         for k in ("susceptibility", "is_infected", "infection_time"):
             rec["post/" + k] = data["agent"][k].numpy().copy()
         if run_symptoms:
-            model.symptoms_updater(data=data, timer=timer, new_infected=new_inf)
+            record_symptoms(model, data, timer, new_inf, rec)
     return rec, pre
+
+
+class _RecordingDist:
+    """Proxy of a torch distribution that remembers what rsample returned (same RNG consumption)."""
+
+    def __init__(self, dist, log, tag):
+        self.dist, self.log, self.tag = dist, log, tag
+
+    def rsample(self, shape):
+        out = self.dist.rsample(shape)
+        self.log.append((self.tag, out.clone()))
+        return out
+
+
+def record_symptoms(model, data, timer, new_inf, rec):
+    """Run the reference's SymptomsUpdater with its randomness recorded: the bernoulli outcome and,
+    per agent, the dwell-time sample it consumed (row f1 of SURVEY section 8)."""
+    sampler = model.symptoms_updater.symptoms_sampler
+    sym = data["agent"].symptoms
+    for k in ("current_stage", "next_stage", "time_to_next_stage"):
+        rec["sym_pre/" + k] = sym[k].numpy().astype(np.float32)
+    n_stages = len(sampler.stages)
+    age = data["agent"].age
+    probs = O.symptoms_progress_probability(
+        sampler.stage_transition_probabilities, age, sym["current_stage"].float(), sym["next_stage"].float(),
+        sym["time_to_next_stage"], new_inf, timer.now, n_stages)
+    log = []
+    saved = (dict(sampler.stage_transition_times), dict(sampler.recovery_times))
+    for i in saved[0]:
+        if saved[0][i] is not None:
+            sampler.stage_transition_times[i] = _RecordingDist(saved[0][i], log, ("next", i))
+        if saved[1][i] is not None:
+            sampler.recovery_times[i] = _RecordingDist(saved[1][i], log, ("rec", i))
+    bern = {}
+    real_bernoulli = torch.bernoulli
+
+    def bernoulli(p, *a, **k):
+        out = real_bernoulli(p, *a, **k)
+        bern["p"], bern["out"] = p.clone(), out.clone()
+        return out
+
+    torch.bernoulli = bernoulli
+    try:
+        pre = {k: sym[k].clone().float() for k in ("current_stage", "next_stage", "time_to_next_stage")}
+        model.symptoms_updater(data=data, timer=timer, new_infected=new_inf)
+    finally:
+        torch.bernoulli = real_bernoulli
+        sampler.stage_transition_times.update(saved[0])
+        sampler.recovery_times.update(saved[1])
+    assert torch.equal(bern["p"], probs), "progress probabilities"
+    progresses = bern["out"]
+    # the sample each agent consumed: stage after transition selects (kind, i)
+    cur_after = sym["current_stage"].float()
+    dwell = torch.zeros(len(age))
+    for (kind, i), draw in log:
+        use = (cur_after == i) & (progresses.bool() if kind == "next" else ~progresses.bool())
+        dwell = torch.where(use, draw, dwell)
+    rec["sym/progresses"] = progresses.numpy().astype(np.float32)
+    rec["sym/dwell"] = dwell.numpy().astype(np.float32)
+    rec["sym/prob"] = probs.numpy().astype(np.float32)
+    for k in ("current_stage", "next_stage", "time_to_next_stage"):
+        rec["sym_post/" + k] = sym[k].numpy().astype(np.float32)
+    got = O.symptoms_update(age, pre["current_stage"], pre["next_stage"], pre["time_to_next_stage"], new_inf,
+                            timer.now, n_stages, progresses, dwell)
+    for k, g in zip(("current_stage", "next_stage", "time_to_next_stage"), got):
+        assert torch.equal(g.float(), sym[k].float()), "oracle symptoms != reference at " + k
 
 
 def check_oracle(rec, pre, world, tables, atol=0.0):
@@ -401,6 +467,7 @@ def make_june769(tag="june769", beta_shift=0.0, write_world=True):
         out["table/" + n] = t.numpy()
     for n, net in runner.model.infection_networks.networks.items():
         out["log_beta/" + n] = np.float32(net.log_beta.item())
+    out["sym_table"] = runner.model.symptoms_updater.symptoms_sampler.stage_transition_probabilities.numpy()
 
     # Runner.forward, instrumented
     timer, model, data = runner.timer, runner.model, runner.data
@@ -513,6 +580,7 @@ def make_synth10k():
     tabs = tables_of(model)
     for n, t in tabs.items():
         out["table/" + n] = t.numpy()
+    out["sym_table"] = model.symptoms_updater.symptoms_sampler.stage_transition_probabilities.numpy()
     recs = []
     for i in range(7):            # 2022-02-02 .. 02-08: five weekdays + a weekend
         next(timer)

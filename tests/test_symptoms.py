@@ -1,0 +1,135 @@
+"""Row f1: disease-stage progression.  CPU: the oracle restatement against every recorded step of
+the reference trajectories (randomness injected).  GPU: the fused kernel against the same records,
+its Philox mode statistically, and the API-level behaviours of the reference's test_symptoms.py."""
+import numpy as np
+import pytest
+import torch
+
+import gj_oracle as O
+import gj_testlib as L
+
+TRAJ = ["june769.npz", "june769_hot.npz", "synth10k.npz"]
+
+
+def sym_inputs(npz, rec):
+    pre = {k[8:]: torch.from_numpy(v) for k, v in rec.items() if k.startswith("sym_pre/")}
+    post = {k[9:]: v for k, v in rec.items() if k.startswith("sym_post/")}
+    return pre, post
+
+
+@pytest.mark.parametrize("name", TRAJ)
+def test_oracle_symptoms_match_reference(name):
+    npz = L.load_npz(name)
+    age = torch.from_numpy(npz["world/age"])
+    n_stages = npz["sym_table"].shape[0]
+    n_updates = 0
+    for i in range(int(npz["n_steps"])):
+        rec = L.step_record(npz, f"step{i}/")
+        pre, post = sym_inputs(npz, rec)
+        prob = O.symptoms_progress_probability(torch.from_numpy(npz["sym_table"]), age, pre["current_stage"],
+                                               pre["next_stage"], pre["time_to_next_stage"],
+                                               torch.from_numpy(rec["new_infected"]), float(rec["now"]), n_stages)
+        assert np.array_equal(prob.numpy(), rec["sym/prob"])
+        got = O.symptoms_update(age, pre["current_stage"], pre["next_stage"], pre["time_to_next_stage"],
+                                torch.from_numpy(rec["new_infected"]), float(rec["now"]), n_stages,
+                                torch.from_numpy(rec["sym/progresses"]), torch.from_numpy(rec["sym/dwell"]))
+        for k, g in zip(("current_stage", "next_stage", "time_to_next_stage"), got):
+            assert np.array_equal(g.numpy().astype(np.float32), post[k]), (i, k)
+        n_updates += int((post["current_stage"] != pre["current_stage"].numpy()).sum())
+    assert n_updates > 0
+
+
+def _updater(device):
+    from grad_june_amd.defaults import default_parameters
+    from grad_june_amd.symptoms import SymptomsUpdater
+
+    return SymptomsUpdater.from_parameters(default_parameters(str(device)))
+
+
+class _T:
+    def __init__(self, now):
+        self.now = now
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", TRAJ)
+def test_kernel_symptoms_match_reference(device, name):
+    """Injected randomness: the kernel reproduces the reference's three symptom arrays exactly."""
+    import grad_june_amd as G
+
+    npz = L.load_npz(name)
+    upd = _updater(device)
+    assert np.array_equal(upd.symptoms_sampler.stage_transition_probabilities.cpu().numpy(), npz["sym_table"])
+    d = G.HeteroData()
+    d["agent"].age = torch.from_numpy(npz["world/age"]).to(device)
+    d["agent"].sex = torch.from_numpy(npz["world/sex"]).to(device)
+    for i in range(int(npz["n_steps"])):
+        rec = L.step_record(npz, f"step{i}/")
+        pre, post = sym_inputs(npz, rec)
+        d["agent"].symptoms = {k: v.to(device) for k, v in pre.items()}
+        upd(d, _T(float(rec["now"])), torch.from_numpy(rec["new_infected"]).to(device),
+            progresses=torch.from_numpy(rec["sym/progresses"]), dwell=torch.from_numpy(rec["sym/dwell"]))
+        assert upd.used_kernel
+        for k in post:
+            assert np.array_equal(d["agent"].symptoms[k].cpu().numpy(), post[k]), (i, k)
+
+
+@pytest.mark.gpu
+def test_kernel_symptoms_statistics(device):
+    """Philox mode (reference test_symptoms.py style): everyone exposed and due -> all move to
+    'infectious' candidates; progress fraction ~ table value; dwell times ~ LogNormal means."""
+    import grad_june_amd as G
+
+    n = 200_000
+    upd = _updater(device)
+    d = G.HeteroData()
+    d["agent"].age = torch.full((n,), 45, device=device)
+    d["agent"].sex = torch.zeros(n, dtype=torch.long, device=device)
+    d["agent"].symptoms = {"current_stage": torch.full((n,), 2.0, device=device),      # exposed
+                           "next_stage": torch.full((n,), 3.0, device=device),          # -> infectious
+                           "time_to_next_stage": torch.zeros(n, device=device)}
+    upd(d, _T(1.0), torch.zeros(n, device=device))
+    s = d["agent"].symptoms
+    assert (s["current_stage"] == 3).all()
+    onward = (s["next_stage"] == 4).float().mean().item()            # infectious -> symptomatic with p=0.7 at age 45
+    assert abs(onward - 0.7) < 0.01
+    assert ((s["next_stage"] == 4) | (s["next_stage"] == 0)).all()
+    sp = upd.symptoms_sampler
+    t_on = s["time_to_next_stage"][s["next_stage"] == 4].mean().item()
+    t_rec = s["time_to_next_stage"][s["next_stage"] == 0].mean().item()
+    assert abs(t_on - sp.stage_transition_times[3].mean.item()) / sp.stage_transition_times[3].mean.item() < 0.03
+    assert abs(t_rec - sp.recovery_times[3].mean.item()) / sp.recovery_times[3].mean.item() < 0.03
+    # nobody moves before the due time; susceptibles never move
+    d["agent"].symptoms = {"current_stage": torch.ones(n, device=device), "next_stage": torch.ones(n, device=device),
+                           "time_to_next_stage": torch.zeros(n, device=device)}
+    upd(d, _T(5.0), torch.zeros(n, device=device))
+    assert (d["agent"].symptoms["current_stage"] == 1).all() and (d["agent"].symptoms["next_stage"] == 1).all()
+    # newly infected: exposed next, due now
+    new = torch.zeros(n, device=device)
+    new[::2] = 1.0
+    upd(d, _T(6.0), new)
+    s = d["agent"].symptoms
+    assert (s["current_stage"][::2] == 2).all() and (s["current_stage"][1::2] == 1).all()
+    assert (s["time_to_next_stage"][::2] > 6.0).all()
+
+
+@pytest.mark.gpu
+def test_kernel_agrees_with_torch_form(device):
+    """The fused kernel and the plain torch form of the state machine agree in distribution."""
+    import grad_june_amd as G
+
+    torch.manual_seed(3)
+    n = 100_000
+    outs = []
+    for mode in ("kernel", "torch"):
+        upd = _updater(device)
+        d = G.HeteroData()
+        d["agent"].age = (torch.arange(n, device=device) % 100)
+        d["agent"].sex = torch.zeros(n, dtype=torch.long, device=device)
+        d["agent"].symptoms = {"current_stage": torch.full((n,), 3.0, device=device),
+                               "next_stage": torch.full((n,), 4.0, device=device),
+                               "time_to_next_stage": torch.zeros(n, device=device)}
+        (upd if mode == "kernel" else upd.forward_torch)(d, _T(2.0), torch.zeros(n, device=device))
+        s = d["agent"].symptoms
+        outs.append(((s["next_stage"] == 5).float().mean().item(), s["time_to_next_stage"].mean().item()))
+    assert abs(outs[0][0] - outs[1][0]) < 0.01 and abs(outs[0][1] - outs[1][1]) / outs[1][1] < 0.03
