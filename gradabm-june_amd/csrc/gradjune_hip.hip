@@ -442,6 +442,54 @@ __global__ __launch_bounds__(kThreads) void k_symptoms(const SymptomsArgs S) {
   S.ttn[a] = tt;
 }
 
+// f2: per-step result reductions (reference grad_june/runner.py:167,198-224), one streaming pass
+struct StatsArgs {
+  int64_t n;
+  const uint8_t* cls;
+  const float* inf;
+  const float* stage;
+  int32_t n_bins;
+  int32_t edges[GJ_MAX_AGE_BINS + 1];
+  int32_t dead;
+  double* out;
+};
+
+__global__ __launch_bounds__(kThreads) void k_step_stats(const StatsArgs S) {
+  constexpr int kOut = GJ_MAX_AGE_BINS + 2;
+  __shared__ double part[kThreads / kWave][kOut];
+  double acc[kOut];
+#pragma unroll
+  for (int k = 0; k < kOut; ++k) acc[k] = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; a < S.n; a += stride) {
+    const float inf = S.inf[a];
+    const int age = S.cls[a] % 100;
+    acc[0] += inf;
+#pragma unroll
+    for (int b = 0; b < GJ_MAX_AGE_BINS; ++b)
+      if (b < S.n_bins && age > S.edges[b] && age < S.edges[b + 1]) acc[1 + b] += inf;
+    if (S.stage[a] == (float)S.dead) acc[GJ_MAX_AGE_BINS + 1] += 1.0;
+  }
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+#pragma unroll
+  for (int k = 0; k < kOut; ++k) {
+    double v = acc[k];
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    if (lane == 0) part[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kOut) {
+    double v = 0.0;
+    for (int w = 0; w < kThreads / kWave; ++w) v += part[w][threadIdx.x];
+    const int k = threadIdx.x;
+    int dst = -1;
+    if (k == 0) dst = 0;
+    else if (k <= GJ_MAX_AGE_BINS) dst = (k - 1 < S.n_bins) ? k : -1;
+    else dst = 1 + S.n_bins;
+    if (dst >= 0 && v != 0.0) atomicAdd(&S.out[dst], v);
+  }
+}
+
 // a2 alone: q*transmission for a caller-supplied transmission vector
 __global__ __launch_bounds__(kThreads) void k_quarantine_transmission(int64_t n, const float* __restrict__ stage,
                                                                       const float* __restrict__ trans,
@@ -939,6 +987,27 @@ int gj_symptoms_update(int64_t n, const uint8_t* agent_class, const float* new_i
   S.dwell = dwell;
   hipLaunchKernelGGL(gj::k_symptoms, dim3((unsigned)((n + gj::kThreads - 1) / gj::kThreads)), dim3(gj::kThreads), 0,
                      (hipStream_t)stream, S);
+  return gj::launch_status();
+}
+
+int gj_step_stats(int64_t n, const uint8_t* agent_class, const float* is_infected, const float* current_stage,
+                  int32_t n_bins, const int32_t* bin_edges, int32_t dead_stage, double* out, void* stream) {
+  if (n < 0 || n_bins < 0 || n_bins > GJ_MAX_AGE_BINS) return GJ_E_RANGE;
+  if (!out || (n_bins > 0 && !bin_edges)) return GJ_E_NULL;
+  if (n == 0) return GJ_OK;
+  if (!agent_class || !is_infected || !current_stage) return GJ_E_NULL;
+  gj::StatsArgs S;
+  S.n = n;
+  S.cls = agent_class;
+  S.inf = is_infected;
+  S.stage = current_stage;
+  S.n_bins = n_bins;
+  for (int b = 0; b <= GJ_MAX_AGE_BINS; ++b) S.edges[b] = (b <= n_bins) ? bin_edges[b] : 0;
+  S.dead = dead_stage;
+  S.out = out;
+  int64_t blocks = (n + gj::kThreads - 1) / gj::kThreads;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(gj::k_step_stats, dim3((unsigned)blocks), dim3(gj::kThreads), 0, (hipStream_t)stream, S);
   return gj::launch_status();
 }
 

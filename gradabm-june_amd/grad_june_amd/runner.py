@@ -133,25 +133,58 @@ class Runner(torch.nn.Module):
             device=self.device, fraction=10.0 ** self.log_fraction_initial_cases)
         self.model.symptoms_updater(data=self.data, timer=self.timer, new_infected=new_infected)
 
+    # per-step result reductions: one fused pass (gj_step_stats) into a preallocated series ------------
+    def _record(self, data, row):
+        import ctypes as C
+
+        from . import _native as N
+
+        ag = data["agent"]
+        n = self.n_agents
+        dev = require_hip(self.device)
+        if getattr(self, "_cls", None) is None:
+            sex = ag["sex"] if "sex" in ag else torch.zeros_like(ag.age)
+            self._cls = (sex.long() * 100 + ag.age.long()).to(device=dev, dtype=torch.uint8).contiguous()
+            self._edges = (C.c_int32 * (len(self.age_bins)))(*[int(b) for b in self.age_bins.cpu()])
+        stage = ag.symptoms["current_stage"]
+        if stage.dtype != torch.float32:
+            stage = stage.to(torch.float32)
+        inf = ag.is_infected
+        if inf.dtype != torch.float32 or not inf.is_contiguous():
+            inf = inf.to(torch.float32).contiguous()
+        dead = int(self.model.symptoms_updater.stages_ids[-1])
+        N.check(N.load().gj_step_stats(n, N.ptr(self._cls), N.ptr(inf), N.ptr(stage.contiguous()),
+                                       len(self.age_bins) - 1, self._edges, dead, N.ptr(self._series[row]),
+                                       N.current_stream()), "gj_step_stats")
+
     # time loop --------------------------------------------------------------------------------------
     def forward(self):
         timer, model, data = self.timer, self.model, self.data
         timer.reset()
         self.restore_initial_data()
         self.set_initial_cases()
-        cases = [data["agent"].is_infected.sum()]
-        by_age = [self.get_cases_by_age(data)]
-        self.store_differentiable_deaths(data)
+        n_bins = len(self.age_bins) - 1
+        n_rows = 1
+        probe = Timer.from_parameters(self.input_parameters) if isinstance(self.input_parameters, dict) else None
+        if probe is not None:
+            while probe.date < probe.final_date:
+                next(probe)
+                n_rows += 1
+        else:
+            n_rows = 4096
+        self._series = torch.zeros(n_rows, 2 + n_bins, dtype=torch.float64, device=require_hip(self.device))
+        self._record(data, 0)
         dates = [timer.date]
+        row = 0
         while timer.date < timer.final_date:
             next(timer)
             data = model(data, timer)
-            cases.append(data["agent"].is_infected.sum())
-            self.store_differentiable_deaths(data)
-            by_age.append(self.get_cases_by_age(data))
+            row += 1
+            self._record(data, row)
             dates.append(timer.date)
-        cases_per_timestep = torch.stack(cases)
-        cases_by_age = torch.stack(by_age)
+        series = self._series[: row + 1].to(torch.float32)
+        cases_per_timestep = series[:, 0]
+        data["results"]["deaths_per_timestep"] = series[:, 1 + n_bins]
         results = {
             "dates": dates,
             "cases_per_timestep": cases_per_timestep,
@@ -160,7 +193,7 @@ class Runner(torch.nn.Module):
             "deaths_per_timestep": data.results["deaths_per_timestep"],
         }
         for i, key in enumerate(self.age_bins[1:]):
-            results[f"cases_by_age_{int(key):02d}"] = cases_by_age[:, i]
+            results[f"cases_by_age_{int(key):02d}"] = series[:, 1 + i]
         return results, data["agent"].is_infected
 
     def save_results(self, results, is_infected):

@@ -280,6 +280,18 @@ int gj_symptoms_update(int64_t n, const uint8_t* agent_class, const float* new_i
                        const gj_symptoms_params* params, const float* progresses, const float* dwell,
                        void* stream);
 
+/* ---- row f2 ("next"): the Runner's per-step result reductions in one pass -----------------------
+ * replaces, per timestep, `is_infected.sum()` (grad_june/runner.py:167), get_cases_by_age
+ * (runner.py:217-224: one masked sum per age bin, OPEN intervals lo < age < hi) and the deaths
+ * count of store_differentiable_deaths (runner.py:198-215).
+ * out: device double [2 + n_bins], ZEROED by the caller:  out[0] = sum is_infected,
+ * out[1 .. n_bins] = sum is_infected over each age bin, out[1 + n_bins] = #agents at `dead_stage`.
+ * Accumulated in fp64 (exact for these integer-valued sums), so the result is order-independent. */
+#define GJ_MAX_AGE_BINS 8
+int gj_step_stats(int64_t n, const uint8_t* agent_class, const float* is_infected,
+                  const float* current_stage, int32_t n_bins, const int32_t* bin_edges /* host [n_bins+1] */,
+                  int32_t dead_stage, double* out, void* stream);
+
 /* The production step: a1..a9 = the middle of GradJune.forward (grad_june/model.py:125-138)
  * as three dependent launches on `stream` (+1 when the plan has long rows).                */
 int gj_step(const gj_plan* plan, const gj_agent_state* state, const gj_step_params* params,

@@ -272,6 +272,30 @@ def test_runner_records_and_csv(G, device, tmp_path):
     assert runner.data["agent"].symptoms["current_stage"].sum().item() == 769
 
 
+def test_runner_series_match_plain_reductions(G, device):
+    """Row f2: the fused per-step reductions (gj_step_stats) equal the reference's formulas
+    (runner.py:167, 198-224) evaluated with plain tensor ops on the final state."""
+    torch.manual_seed(11)
+    p = params_on(device, days=6)
+    for k in p["networks"]:
+        p["networks"][k]["log_beta"] += 1.0
+    runner = G.Runner.from_parameters(p)
+    with torch.no_grad():
+        results, is_inf = runner()
+    data = runner.data
+    assert results["cases_per_timestep"][-1].item() == pytest.approx(is_inf.sum().item())
+    assert torch.allclose(results["cases_by_age_18"][-1], runner.get_cases_by_age(data)[0])
+    assert torch.allclose(results["cases_by_age_65"][-1], runner.get_cases_by_age(data)[1])
+    assert torch.allclose(results["cases_by_age_100"][-1], runner.get_cases_by_age(data)[2])
+    stage = data["agent"].symptoms["current_stage"]
+    assert results["deaths_per_timestep"][-1].item() == (stage == 7).sum().item()
+    assert results["cases_per_timestep"][0].item() > 0 and results["daily_cases_per_timestep"][0] == results["cases_per_timestep"][0]
+    # open age intervals: ages exactly on a bin edge are in no bin (reference quirk, runner.py:220-222)
+    edge = (data["agent"].age == 18) | (data["agent"].age == 65) | (data["agent"].age == 0)
+    by_age_total = sum(results[f"cases_by_age_{k:02d}"][-1].item() for k in (18, 65, 100))
+    assert by_age_total == pytest.approx((is_inf * (~edge)).sum().item())
+
+
 def test_config1_plumbing_30_timesteps(G, device):
     """BASELINE.json configs[0]: the shipped 769-agent world (the London blob is absent), default
     parameters, 30 timesteps through Runner - every step on the HIP path."""
