@@ -242,6 +242,22 @@ def main():
         dist.destroy_process_group()
         return
 
+    full = None
+    if not distributed and hasattr(runner, "enable_full_step"):
+        # second timed region: the "full step" of SURVEY section 8d (hot path + symptoms + result reductions)
+        runner.enable_full_step()
+        for _ in range(3):
+            runner.full_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_full = max(10, args.steps // 2)
+        for _ in range(n_full):
+            runner.full_step()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        full = {"steps_per_s": n_full / el, "ms_per_step": 1e3 * el / n_full, "steps": n_full,
+                "includes": "hot path a1-a9 + symptoms kernel (f1) + per-step result reductions (f2)"}
+
     sps = args.steps / elapsed
     n_edges = network_edges(world, networks)
     b_step = algorithmic_bytes(world, networks)
@@ -279,6 +295,8 @@ def main():
         "setup_s": {"generate": t_gen, "total": t_setup},
     }
     out.update(extra)
+    if full:
+        out["full_step"] = full
     # HBM traffic of the dominant kernel from the committed PMC profile of this exact workload
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:

@@ -91,6 +91,39 @@ class SingleGpuHotPath:
                 self.log.mark(label)
         self.t += 1
 
+    # ---- "full step" of SURVEY section 8d: hot path + symptoms (f1) + result reductions (f2) ----------
+    def enable_full_step(self, n_rows: int = 4096):
+        from .defaults import default_parameters
+        from .symptoms import SymptomsSampler
+
+        dev = self.device
+        A = self.engine.plan.host.n_agents
+        self._sym = SymptomsSampler.from_parameters(default_parameters(str(dev)))
+        self._sym_p = self._sym.kernel_params()
+        self._sym_table = self._sym.stage_transition_probabilities.to(dev).contiguous()
+        self._sym_p.progress = self._sym_table.data_ptr()
+        st = self.state
+        st["next_stage"] = torch.where(st["is_infected"] > 0, st["current_stage"] + 1, st["current_stage"]).contiguous()
+        st["time_to_next_stage"] = torch.zeros(A, dtype=torch.float32, device=dev)
+        self._series = torch.zeros(n_rows, 5, dtype=torch.float64, device=dev)
+        self._edges = (C.c_int32 * 4)(0, 18, 65, 100)
+        self._row = 0
+
+    def full_step(self):
+        lib = N.load()
+        self.step()
+        st = self.state
+        p = self._sym_p
+        p.time, p.seed, p.step, p.agent_offset = float(self.t), self.seed, self.t, 0
+        N.check(lib.gj_symptoms_update(self.new_infected.numel(), N.ptr(self.engine.plan.agent_class),
+                                       N.ptr(self.new_infected), N.ptr(st["current_stage"]), N.ptr(st["next_stage"]),
+                                       N.ptr(st["time_to_next_stage"]), C.byref(p), None, None, N.current_stream()),
+                "gj_symptoms_update")
+        N.check(lib.gj_step_stats(self.new_infected.numel(), N.ptr(self.engine.plan.agent_class), N.ptr(st["is_infected"]),
+                                  N.ptr(st["current_stage"]), 3, self._edges, 7, N.ptr(self._series[self._row % 4096]),
+                                  N.current_stream()), "gj_step_stats")
+        self._row += 1
+
     def reset_timers(self):
         self.log.clear()
 
