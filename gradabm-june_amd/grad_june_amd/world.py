@@ -13,10 +13,15 @@ from typing import Dict, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
+import os
+
 from .engine import AgentBuffers, InfectionEngine
 from .plan import DevicePlan, NetworkSpec, compile_plan
 
 _CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+#: device layout the API mirrors compile worlds into: "tiled" (LDS-tiled fast path, default) or "csr"
+DEFAULT_LAYOUT = os.environ.get("GRAD_JUNE_AMD_LAYOUT", "tiled")
 
 
 def _np(x) -> np.ndarray:
@@ -68,7 +73,7 @@ def engine_for(data, specs: Sequence[NetworkSpec], device) -> InfectionEngine:
     for n in specs:
         if n.edge_set not in set_names:
             set_names.append(n.edge_set)
-    sig = _signature(data, set_names, specs) + (str(device),)
+    sig = _signature(data, set_names, specs) + (str(device), DEFAULT_LAYOUT)
     per_data = _CACHE.get(data)
     if per_data is None:
         per_data = _CACHE[data] = {}
@@ -78,7 +83,7 @@ def engine_for(data, specs: Sequence[NetworkSpec], device) -> InfectionEngine:
     if not specs:
         # a launch that needs no edge set (transmission profile) can ride on any plan of this world
         for other_sig, eng in per_data.items():
-            if other_sig[2] == sig[2] and other_sig[3] == sig[3]:
+            if other_sig[2] == sig[2] and other_sig[3:] == sig[3:]:
                 return eng
     sets = edge_sets_of(data, set_names)
     agent = data["agent"]
@@ -88,7 +93,7 @@ def engine_for(data, specs: Sequence[NetworkSpec], device) -> InfectionEngine:
     if age is None and any(n.table is not None for n in specs):
         raise KeyError("leisure networks need data['agent'].age and .sex")
     host = compile_plan(n_agents, {k: {kk: vv for kk, vv in v.items() if kk != "_ei"} for k, v in sets.items()},
-                        age=age, sex=sex)
+                        age=age, sex=sex, layout=DEFAULT_LAYOUT)
     present = [n for n in specs if n.edge_set in host.set_index]
     engine = InfectionEngine(DevicePlan(host, present, device))
     if len(per_data) >= 4:          # worlds whose edges are rebuilt repeatedly: keep the cache small

@@ -21,7 +21,9 @@ from grad_june_amd.synthetic import edge_set_of, make_world
 
 pytestmark = pytest.mark.gpu
 
-CASES = [("c2", None)] + ([("c3", None)] if os.environ.get("GJ_FULL_C3") == "1" else [("c3", 2_000_000)])
+# c5 = power-law venue degrees (Zipf alpha 2, venues up to 50 000 attendees), scaled to one test box
+CASES = ([("c2", None)] + ([("c3", None)] if os.environ.get("GJ_FULL_C3") == "1" else [("c3", 2_000_000)])
+         + [("c5", 1_000_000)])
 
 
 def run_stages(r, sample=False):
