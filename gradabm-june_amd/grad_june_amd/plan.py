@@ -176,10 +176,13 @@ def agent_class_of(age, sex) -> np.ndarray:
 def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
                  n_ext_agents: Optional[int] = None, block_order: str = "interleave",
                  layout: str = "csr", leisure_sets: Sequence[str] = ("leisure",),
-                 sv_max: int = TL.SV_MAX, eb_target: int = TL.EB_TARGET, slices=None) -> HostPlan:
+                 sv_max: int = TL.SV_MAX, eb_target: int = TL.EB_TARGET, slices=None,
+                 nets_per_set: Optional[Dict[str, int]] = None) -> HostPlan:
     """edge_sets: {name: {"agent": i64[E], "venue": i64[E], "people": [V]}} (insertion order = set ids).
 
     layout: "csr" (deterministic CSR kernels), "tiled" (LDS-tiled fast path) or "both".
+    nets_per_set: infection networks that may be active on a set at once (a venue block keeps one
+    8-byte LDS sum per venue and network; default 1, and 6 for the leisure sets).
     """
     if len(edge_sets) > N.GJ_MAX_SETS:
         raise ValueError(f"at most {N.GJ_MAX_SETS} edge sets")
@@ -197,9 +200,10 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
         hs = compile_edge_set(name, es["agent"], es["venue"], es["people"], n_agents, n_ext, csr=want_csr)
         sets.append(hs)
         if want_tiled:
+            k = (nets_per_set or {}).get(name, 6 if name in leisure_sets else 1)
             hs.tiled = TL.build_tiled(name, es["agent"], es["venue"], hs.n_venues, hs.v_pcontact, S, SA,
                                       agent_class=cls_all if (name in leisure_sets and cls_all is not None) else None,
-                                      sv_max=sv_max, eb_target=eb_target)
+                                      sv_max=max(16, sv_max // max(1, k)), eb_target=eb_target)
             t = hs.tiled
             for j in range(t.n_blocks):
                 work.append((int(t.blk_e0[j + 1] - t.blk_e0[j]) + int(t.blk_v0[j + 1] - t.blk_v0[j]), sid, j))
