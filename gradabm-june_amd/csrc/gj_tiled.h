@@ -19,17 +19,23 @@ constexpr int kUnroll = 8;          // 64-edge chunks a wave keeps in flight (ph
 
 // LDS float atomics run at 0.33 lanes/clk/CU on gfx950 (measured, tools/microbench/lds_atomics.hip)
 // against 4.9 for ds_add_u64 and 7.3 for ds_add_u32, so the per-venue and per-agent sums are kept
-// in 64-bit fixed point (2^-36 resolution, range +-1.3e8): integer adds are order-independent, which
-// also makes both passes bitwise reproducible, and exact (no rounding inside a sum).
+// in 64-bit fixed point: integer adds are order-independent, which also makes both passes bitwise
+// reproducible, and exact (no rounding inside a sum).
+//   pass 1 (sums of transmissions per venue):  2^-40 resolution (9e-13), |sum| < 8.3e6
+//   pass 2 (sums of cum per agent):            2^-36 resolution (1.5e-11), |sum| < 1.3e8
 typedef unsigned long long fx_t;
-constexpr float kFxScale = 68719476736.0f;            // 2^36
-constexpr double kFxInv = 1.0 / 68719476736.0;
-constexpr float kFxMax = 1.0e8f;
+template <int BITS>
 __device__ __forceinline__ fx_t to_fx(float x) {
-  x = fminf(fmaxf(x, -kFxMax), kFxMax);               // also maps NaN to -kFxMax: finite, flagged by tests
-  return (fx_t)__float2ll_rn(x * kFxScale);
+  constexpr float scale = (float)(1ull << BITS);
+  constexpr float vmax = (float)(1ull << (62 - BITS));
+  x = fminf(fmaxf(x, -vmax), vmax);                   // also maps NaN to -vmax: finite, flagged by tests
+  return (fx_t)__float2ll_rn(x * scale);
 }
-__device__ __forceinline__ float from_fx(fx_t v) { return (float)((double)(long long)v * kFxInv); }
+template <int BITS>
+__device__ __forceinline__ float from_fx(fx_t v) {
+  return (float)((double)(long long)v * (1.0 / (double)(1ull << BITS)));
+}
+constexpr int kFxVenue = 40, kFxAgent = 36;
 
 struct TSetA {            // what phases A and D need of one set
   const uint16_t* a_la;
@@ -209,12 +215,12 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
           if (lv == cur) {
             acc += x[q];
           } else {
-            if (cur != 0xFFFF) atomicAdd(&sums[cur], to_fx(acc));
+            if (cur != 0xFFFF) atomicAdd(&sums[cur], to_fx<kFxVenue>(acc));
             cur = lv;
             acc = x[q];
           }
         }
-        if (cur != 0xFFFF) atomicAdd(&sums[cur], to_fx(acc));
+        if (cur != 0xFFFF) atomicAdd(&sums[cur], to_fx<kFxVenue>(acc));
       } else {
         const uint2 craw = cls8[g];
         const uint32_t cw[2] = {craw.x, craw.y};
@@ -229,12 +235,12 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
             if (lv == cur) {
               acc += xl;
             } else {
-              if (cur != 0xFFFF) atomicAdd(&sums[k * nv + cur], to_fx(acc));
+              if (cur != 0xFFFF) atomicAdd(&sums[k * nv + cur], to_fx<kFxVenue>(acc));
               cur = lv;
               acc = xl;
             }
           }
-          if (cur != 0xFFFF) atomicAdd(&sums[k * nv + cur], to_fx(acc));
+          if (cur != 0xFFFF) atomicAdd(&sums[k * nv + cur], to_fx<kFxVenue>(acc));
         }
       }
     }
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
     for (int k = 0; k < nk; ++k) {
       const float beta = T.beta[k];
       for (int lv = tid; lv < nv; lv += kTileThreads) {
-        const float c = (beta * T.v_pc[v0 + lv]) * from_fx(sums[k * nv + lv]);
+        const float c = (beta * T.v_pc[v0 + lv]) * from_fx<kFxVenue>(sums[k * nv + lv]);
         T.cum[(int64_t)(v0 + lv) * T.stride + k] = c;
         cumf[2 * (k * nv + lv)] = c;      // low half of the lane's own 8-byte slot
       }
@@ -353,7 +359,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
           const int i = seg0 + (c0 + u) * kWave + lane;
-          if ((c0 + u < n_chunks) && (i < seg1)) atomicAdd(&lds_acc[la[u]], to_fx(v[u]));
+          if ((c0 + u < n_chunks) && (i < seg1)) atomicAdd(&lds_acc[la[u]], to_fx<kFxAgent>(v[u]));
         }
       }
     }
@@ -381,7 +387,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
       if (i >= n_local) continue;
       const int64_t a = base + i;
       float susc = susc_b[u];
-      float ts = susc * from_fx(lds_acc[i]);
+      float ts = susc * from_fx<kFxAgent>(lds_acc[i]);
       if (D.trans_susc) D.trans_susc[a] = ts;
       ts = fminf(fmaxf(ts, 1e-6f), 100.0f);
       float p = expf(-ts * D.dt);

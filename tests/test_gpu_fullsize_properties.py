@@ -95,7 +95,7 @@ def test_fullsize_properties(device, preset, agents):
             if s.name != "leisure":
                 assert torch.equal(now, 2.0 * b), (r.layout, s.name)
             else:
-                assert torch.allclose(now, 2.0 * b, rtol=1e-6, atol=0)
+                assert torch.allclose(now, 2.0 * b, rtol=1e-5, atol=1e-10)   # table product is rounded before the sum
 
     # -- determinism and decisions: a full step twice from the same state ----------------------------
     outs = []
