@@ -166,8 +166,6 @@ struct TileBArgs {
   const float* tables;
   int32_t day_type;
   int32_t mode;            // 0: B then C (fused);  1: B only (cum written);  2: C only (cum read)
-  uint32_t set_mask;       // sets handled by this launch (launches are split by LDS need)
-  int32_t _pad;
 };
 
 struct Slots8 {           // 8 consecutive block-major slots: 16 bytes of local venue indices
@@ -179,7 +177,6 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
   extern __shared__ __align__(16) float lds_s[];
   const int tid = threadIdx.x;
   const int set = B.work[2 * blockIdx.x], j = B.work[2 * blockIdx.x + 1];
-  if (!((B.set_mask >> set) & 1u)) return;
   const TSetB& T = B.sets[set];
   const int nk = T.nk;
   if (nk == 0) return;

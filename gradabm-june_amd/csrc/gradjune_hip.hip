@@ -791,11 +791,7 @@ static int tiled_venues(const gj_plan* plan, const gj_step_params* p, const Grou
   if (T->n_work == 0 || G.n == 0) return GJ_OK;
   TileBArgs B;
   for (int s = 0; s < GJ_MAX_SETS; ++s) B.sets[s] = TSetB{};
-  // sets are split into two launches by LDS need, so that blocks with few venues are not held to
-  // one workgroup per CU by the widest set's allocation
-  constexpr size_t kLightLds = 64 * 1024;
-  size_t lds_class[2] = {16, 16};
-  uint32_t mask_class[2] = {0, 0};
+  size_t lds = 16;
   for (int g = 0; g < G.n; ++g) {
     const int s = G.set[g];
     const gj_tiled_set& S = T->sets[s];
@@ -827,26 +823,16 @@ static int tiled_venues(const gj_plan* plan, const gj_step_params* p, const Grou
     }
     const size_t need = (size_t)X.nk * S.max_block_venues * sizeof(fx_t) +
                         (X.leisure ? 2 * 200 * (size_t)X.nk : 0) * sizeof(float);
-    if (X.nk) {
-      const int c = need > kLightLds ? 1 : 0;
-      mask_class[c] |= 1u << s;
-      if (need > lds_class[c]) lds_class[c] = need;
-    }
+    if (X.nk && need > lds) lds = need;
   }
   B.work = T->work;
   B.tables = plan->tables;
   B.day_type = p->day_type;
   B.mode = mode;
-  for (int c = 1; c >= 0; --c) {        // heavy class first: its workgroups are the long poles
-    if (!mask_class[c]) continue;
-    B.set_mask = mask_class[c];
-    int rc = allow_lds(k_tile_venues, lds_class[c]);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_tile_venues, dim3((unsigned)T->n_work), dim3(kTileThreads), lds_class[c], stream, B);
-    rc = launch_status();
-    if (rc) return rc;
-  }
-  return GJ_OK;
+  int rc = allow_lds(k_tile_venues, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_tile_venues, dim3((unsigned)T->n_work), dim3(kTileThreads), lds, stream, B);
+  return launch_status();
 }
 
 static int tiled_agents(const gj_plan* plan, const gj_agent_state* st, const gj_step_params* p, const Groups& G,
