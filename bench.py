@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--eb-target", type=int, default=None)
     ap.add_argument("--slice-agents", type=int, default=None, help="tiled: agents per slice (multiple of 64)")
     ap.add_argument("--edge-mult", type=float, default=1.0, help="experiments: memberships per agent x this")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: diagnostic runs with several ranks sharing one GPU (collectives staged through the host)")
     ap.add_argument("--force-distributed", action="store_true",
                     help="diagnostic: take the torch.distributed code path even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -164,6 +166,8 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU path)")
+    if args.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -177,7 +181,10 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world_size)
         dist.barrier()
 
     from grad_june_amd.synthetic import make_world, algorithmic_bytes, network_edges
@@ -234,7 +241,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

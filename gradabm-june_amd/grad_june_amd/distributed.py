@@ -142,6 +142,11 @@ class HaloExchange:
         self.rw, self.group, self.device = rw, group, torch.device(device)
         self.pack = pack
         R, r = rw.world_size, rw.rank
+        # RCCL moves device buffers directly; gloo (tests: several ranks sharing one GPU) is staged through the host
+        self.host_staged = self.device.type == "cuda" and dist.get_backend(group) == "gloo"
+        data_device = self.device
+        if self.host_staged:
+            self.device = torch.device("cpu")
         self.recv_counts = [int(c) for c in rw.halo_from]
         need_counts = torch.tensor(self.recv_counts, dtype=torch.int64, device=self.device)
         send_counts = torch.empty(R, dtype=torch.int64, device=self.device)
@@ -153,8 +158,12 @@ class HaloExchange:
         local = asked - int(rw.bounds[r])
         if local.numel() and (int(local.min()) < 0 or int(local.max()) >= rw.n_local):
             raise RuntimeError("halo setup: a peer asked for an agent this rank does not own")
-        self.send_index = local.to(torch.int32).contiguous()
-        self.send_buf = torch.empty(self.send_index.numel(), dtype=torch.float32, device=self.device)
+        self.send_index = local.to(device=data_device, dtype=torch.int32).contiguous()
+        self.send_buf = torch.empty(self.send_index.numel(), dtype=torch.float32, device=data_device)
+        # a collective is entered by every rank or by none: skip the per-step exchange only if NO rank has halo
+        total = torch.tensor([self.send_index.numel() + rw.n_halo], dtype=torch.int64, device=self.device)
+        dist.all_reduce(total, group=group)
+        self.active = int(total.item()) > 0
 
     @property
     def bytes_per_step(self) -> int:
@@ -164,13 +173,18 @@ class HaloExchange:
         """x: float32[n_ext]; fills x[n_local_pad:] with the owners' current values."""
         import torch.distributed as dist
 
-        if self.rw.world_size == 1 or (self.send_index.numel() == 0 and self.rw.n_halo == 0):
+        if not self.active:
             return
         if self.pack is not None:
             self.pack(self.send_index, x, self.send_buf)
         else:
             torch.index_select(x, 0, self.send_index.long(), out=self.send_buf)
         recv = x[self.rw.n_local_pad:self.rw.n_local_pad + self.rw.n_halo]
+        if self.host_staged:
+            tmp = torch.empty(self.rw.n_halo, dtype=torch.float32)
+            dist.all_to_all_single(tmp, self.send_buf.cpu(), self.recv_counts, self.send_counts, group=self.group)
+            recv.copy_(tmp)
+            return
         dist.all_to_all_single(recv, self.send_buf, self.recv_counts, self.send_counts, group=self.group)
 
 
@@ -247,7 +261,12 @@ class DistributedHotPath:
         e.step_phase(self.bufs, p, self.io, 5)
         mark("tile_venues_B")
         if self.flat_cum is not None and self.flat_cum.numel() and dist.is_initialized():
-            dist.all_reduce(self.flat_cum, group=self.group)
+            if dist.get_backend(self.group) == "gloo":        # tests: host-staged
+                tmp = self.flat_cum.cpu()
+                dist.all_reduce(tmp, group=self.group)
+                self.flat_cum.copy_(tmp)
+            else:
+                dist.all_reduce(self.flat_cum, group=self.group)
             mark("partial_all_reduce")
         e.step_phase(self.bufs, p, self.io, 6)
         mark("tile_venues_C")
