@@ -64,3 +64,47 @@ def test_virtual_ranks_match_single_rank(device, R):
         got_new = torch.cat([rk.new_infected for rk in ranks]).cpu().numpy()
         assert np.array_equal(got_new > 0.5, single.new_infected.cpu().numpy() > 0.5)
     assert single.state["is_infected"].sum().item() > 0.05 * world["n_agents"]
+
+
+def _two_rank_worker(rank, R, port, out):
+    """One real process per rank (both on cuda:0), torch.distributed with gloo, collectives staged
+    through the host - the multi-process flow bench.py --gpus N takes, minus RCCL."""
+    import os
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=R)
+    try:
+        device = torch.device("cuda:0")
+        world = make_world("c3", n_agents=30_000, seed=4, infected_fraction=0.05)
+        specs, betas = B.network_specs(world), B.betas_of(world)
+        rk = DistributedHotPath(world, specs, betas, device, rank, R, seed=9)
+        assert rk.halo.host_staged and rk.halo.active
+        for _ in range(3):
+            rk.step()
+        torch.cuda.synchronize()
+        mine = rk.state["is_infected"].cpu()
+        parts = [torch.empty(int(rk.rw.bounds[r + 1] - rk.rw.bounds[r])) for r in range(R)]
+        dist.all_gather(parts, mine) if len({p.numel() for p in parts}) == 1 else None
+        if rank == 0:
+            single = SingleGpuHotPath(world, specs, betas, device, seed=9, layout="tiled")
+            for _ in range(3):
+                single.step()
+            torch.cuda.synchronize()
+            ref = single.state["is_infected"].cpu()
+            assert torch.equal(torch.cat(parts), ref)
+            out[0] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_processes_gloo_match_single_rank(device):
+    import os
+
+    import torch.multiprocessing as mp
+
+    R = 2
+    out = mp.get_context("spawn").Array("i", [0])
+    mp.spawn(_two_rank_worker, args=(R, 29600 + os.getpid() % 300, out), nprocs=R, join=True)
+    assert out[0] == 1
