@@ -169,12 +169,13 @@ class HaloExchange:
     def bytes_per_step(self) -> int:
         return 4 * (self.send_index.numel() + sum(self.recv_counts))
 
-    def exchange(self, x: torch.Tensor):
-        """x: float32[n_ext]; fills x[n_local_pad:] with the owners' current values."""
+    def exchange(self, x: torch.Tensor, async_op: bool = False):
+        """x: float32[n_ext]; fills x[n_local_pad:] with the owners' current values.  With async_op the
+        collective runs on the backend's own stream and a work handle is returned (wait() before use)."""
         import torch.distributed as dist
 
         if not self.active:
-            return
+            return None
         if self.pack is not None:
             self.pack(self.send_index, x, self.send_buf)
         else:
@@ -184,8 +185,9 @@ class HaloExchange:
             tmp = torch.empty(self.rw.n_halo, dtype=torch.float32)
             dist.all_to_all_single(tmp, self.send_buf.cpu(), self.recv_counts, self.send_counts, group=self.group)
             recv.copy_(tmp)
-            return
-        dist.all_to_all_single(recv, self.send_buf, self.recv_counts, self.send_counts, group=self.group)
+            return None
+        return dist.all_to_all_single(recv, self.send_buf, self.recv_counts, self.send_counts, group=self.group,
+                                      async_op=async_op)
 
 
 def emulate_exchange(rank_worlds: Sequence[RankWorld], xs: Sequence[np.ndarray]) -> None:
@@ -241,37 +243,71 @@ class DistributedHotPath:
         self.t = 0
         self.log = EventLog()
 
-    def params(self):
-        return self.engine.params(now=1.0 + self.t, delta_time=1.0, day_type=0, active=self.networks,
+    def params(self, only: Optional[str] = None):
+        """only: None = every network; "halo" / "partial" = the networks on sets of that exchange mode."""
+        from .synthetic import edge_set_of
+
+        nets = self.networks
+        if only is not None:
+            want = ("halo",) if only == "halo" else ("partial", "local")
+            nets = [n for n in nets if self.rw.modes[edge_set_of(n)] in want]
+        return self.engine.params(now=1.0 + self.t, delta_time=1.0, day_type=0, active=nets,
                                   betas=self.betas, seed=self.seed, step=self.t, agent_offset=self.a0)
 
-    def step(self, timed: bool = False):
+    def _all_reduce(self, async_op: bool):
         import torch.distributed as dist
 
-        p, e = self.params(), self.engine
-        mark = self.log.mark if timed else (lambda label: None)
-        mark("begin")
-        e.step_phase(self.bufs, p, self.io, 0)
-        mark("transmission")
-        if self.halo is not None:
-            self.halo.exchange(self.state["transmission"])
-            mark("halo_all_to_all")
-        e.step_phase(self.bufs, p, self.io, 1)
-        mark("tile_scatter")
-        e.step_phase(self.bufs, p, self.io, 5)
-        mark("tile_venues_B")
-        if self.flat_cum is not None and self.flat_cum.numel() and dist.is_initialized():
-            if dist.get_backend(self.group) == "gloo":        # tests: host-staged
-                tmp = self.flat_cum.cpu()
-                dist.all_reduce(tmp, group=self.group)
-                self.flat_cum.copy_(tmp)
-            else:
-                dist.all_reduce(self.flat_cum, group=self.group)
+        if self.flat_cum is None or not self.flat_cum.numel() or not dist.is_initialized():
+            return None
+        if dist.get_backend(self.group) == "gloo":        # tests: host-staged, synchronous
+            tmp = self.flat_cum.cpu()
+            dist.all_reduce(tmp, group=self.group)
+            self.flat_cum.copy_(tmp)
+            return None
+        return dist.all_reduce(self.flat_cum, group=self.group, async_op=async_op)
+
+    def step(self, timed: bool = False):
+        """One step.  Untimed (production) form overlaps the two collectives with the phases that do
+        not depend on them: the halo all-to-all runs under phases A+B of the partial-sum sets, the
+        partial-sum all-reduce under phases A+B+C of the halo sets.  The timed form runs everything
+        in sequence so that every launch and collective can be bracketed by events."""
+        e = self.engine
+        p_all = self.params()
+        if timed or self.halo is None:
+            mark = self.log.mark if timed else (lambda label: None)
+            mark("begin")
+            e.step_phase(self.bufs, p_all, self.io, 0)
+            mark("transmission")
+            if self.halo is not None:
+                self.halo.exchange(self.state["transmission"])
+                mark("halo_all_to_all")
+            e.step_phase(self.bufs, p_all, self.io, 1)
+            mark("tile_scatter")
+            e.step_phase(self.bufs, p_all, self.io, 5)
+            mark("tile_venues_B")
+            if self._all_reduce(False) is None and timed:
+                pass
             mark("partial_all_reduce")
-        e.step_phase(self.bufs, p, self.io, 6)
-        mark("tile_venues_C")
-        e.step_phase(self.bufs, p, self.io, 3)
-        mark("tile_agents")
+            e.step_phase(self.bufs, p_all, self.io, 6)
+            mark("tile_venues_C")
+            e.step_phase(self.bufs, p_all, self.io, 3)
+            mark("tile_agents")
+            self.t += 1
+            return
+        p_halo, p_part = self.params("halo"), self.params("partial")
+        e.step_phase(self.bufs, p_all, self.io, 0)                        # transmission
+        h = self.halo.exchange(self.state["transmission"], async_op=True)  # all-to-all on the comm stream
+        e.step_phase(self.bufs, p_part, self.io, 1)                       # A, B of the partial-sum sets
+        e.step_phase(self.bufs, p_part, self.io, 5)
+        r = self._all_reduce(True)                                        # all-reduce on the comm stream
+        if h is not None:
+            h.wait()
+        e.step_phase(self.bufs, p_halo, self.io, 1)                       # A, B, C of the halo sets
+        e.step_phase(self.bufs, p_halo, self.io, 2)
+        if r is not None:
+            r.wait()
+        e.step_phase(self.bufs, p_part, self.io, 6)                       # C of the partial-sum sets
+        e.step_phase(self.bufs, p_all, self.io, 3)                        # D + epilogue: all sets
         self.t += 1
 
     def reset_timers(self):
