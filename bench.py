@@ -234,17 +234,19 @@ def main():
     for _ in range(args.warmup):
         runner.step()
     sync()
+    runner.reset_timers()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        runner.step()                 # the production step (N > 1: collectives overlapped with compute)
+        # one GPU: the step's launches are bracketed by HIP events (on the launch stream) inside the timed
+        # region.  N > 1: the production step overlaps collectives with compute and cannot be bracketed.
+        runner.step(timed=not distributed)
     sync()
     elapsed = time.perf_counter() - t0
-    # per-launch durations: the same K steps again, every launch / collective bracketed by HIP events
-    # recorded on the launch stream (not part of `value`)
-    runner.reset_timers()
-    for _ in range(args.steps):
-        runner.step(timed=True)
-    sync()
+    if distributed:
+        # per-launch durations for N > 1: the same K steps again in the sequential, event-bracketed form
+        for _ in range(args.steps):
+            runner.step(timed=True)
+        sync()
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
