@@ -165,6 +165,55 @@ class HostPlan:
         return sum(s.n_edges for s in self.sets)
 
 
+def save_plan(plan: HostPlan, path) -> None:
+    """Write a compiled plan as one .npz (the native on-disk form of a world: compile once, reload in
+    seconds; arrays are stored uncompressed so that ``np.load(..., mmap_mode="r")`` can map them)."""
+    out = {"meta/n_agents": plan.n_agents, "meta/n_ext_agents": plan.n_ext_agents, "meta/layout": plan.layout,
+           "meta/n_slices": plan.n_slices, "meta/slice_agents": plan.slice_agents,
+           "meta/n_partial_slots": plan.n_partial_slots, "meta/sets": ",".join(s.name for s in plan.sets),
+           "agent_class": plan.agent_class, "blocks": plan.blocks, "long_rows": plan.long_rows}
+    if plan.work is not None:
+        out["work"] = plan.work
+    for s in plan.sets:
+        p = f"set/{s.name}/"
+        out[p + "n_venues"], out[p + "n_edges"], out[p + "v_pcontact"] = s.n_venues, s.n_edges, s.v_pcontact
+        for k in ("v_rowptr", "v_agent", "a_rowptr", "a_venue"):
+            if getattr(s, k) is not None:
+                out[p + k] = getattr(s, k)
+        if s.tiled is not None:
+            t = s.tiled
+            for k in ("blk_v0", "blk_e0", "e_lv", "e_cls", "a_la", "tile_sptr", "tile_jpos", "chunk_ptr", "chunk_desc"):
+                if getattr(t, k) is not None:
+                    out[p + "tiled/" + k] = getattr(t, k)
+            out[p + "tiled/meta"] = np.array([t.n_slices, t.n_blocks, t.n_slots], dtype=np.int64)
+    np.savez(path, **out)
+
+
+def load_plan(path) -> HostPlan:
+    with np.load(path, allow_pickle=False) as z:
+        a = {k: z[k] for k in z.files}
+    sets = []
+    for name in str(a["meta/sets"]).split(","):
+        if not name:
+            continue
+        p = f"set/{name}/"
+        hs = HostEdgeSet(name, int(a[p + "n_venues"]), int(a[p + "n_edges"]), a.get(p + "v_rowptr"), a.get(p + "v_agent"),
+                         a[p + "v_pcontact"], a.get(p + "a_rowptr"), a.get(p + "a_venue"))
+        if p + "tiled/meta" in a:
+            S, J, n_slots = (int(x) for x in a[p + "tiled/meta"])
+            hs.tiled = TL.TiledEdgeSet(name=name, n_venues=hs.n_venues, n_edges=hs.n_edges, n_slices=S, n_blocks=J,
+                                       blk_v0=a[p + "tiled/blk_v0"], blk_e0=a[p + "tiled/blk_e0"], e_lv=a[p + "tiled/e_lv"],
+                                       e_cls=a.get(p + "tiled/e_cls"), a_la=a[p + "tiled/a_la"],
+                                       tile_sptr=a[p + "tiled/tile_sptr"], tile_jpos=a[p + "tiled/tile_jpos"],
+                                       v_pcontact=hs.v_pcontact, n_slots=n_slots, chunk_ptr=a[p + "tiled/chunk_ptr"],
+                                       chunk_desc=a[p + "tiled/chunk_desc"])
+        sets.append(hs)
+    return HostPlan(int(a["meta/n_agents"]), int(a["meta/n_ext_agents"]), sets, a["agent_class"], a["blocks"],
+                    a["long_rows"], int(a["meta/n_partial_slots"]), {s.name: i for i, s in enumerate(sets)},
+                    layout=str(a["meta/layout"]), n_slices=int(a["meta/n_slices"]),
+                    slice_agents=int(a["meta/slice_agents"]), work=a.get("work"))
+
+
 def agent_class_of(age, sex) -> np.ndarray:
     age = np.asarray(age).astype(np.int64)
     sex = np.asarray(sex).astype(np.int64)

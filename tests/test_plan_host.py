@@ -103,3 +103,26 @@ def test_plan_of_reference_world():
         for row in plan.long_rows[plan.long_rows[:, 0] == sid]:
             covered[row[1]] += 1
         assert (covered == 1).all()
+
+
+def test_plan_save_load_roundtrip(tmp_path):
+    from grad_june_amd.plan import load_plan, save_plan
+
+    npz = L.load_npz("world769.npz")
+    w = L.world_from(npz, prefix="")
+    es = {k: {kk: vv.numpy() for kk, vv in v.items()} for k, v in w["edge_sets"].items()}
+    for layout in ("csr", "tiled", "both"):
+        plan = compile_plan(w["n_agents"], es, age=w["age"].numpy(), sex=w["sex"].numpy(), layout=layout)
+        save_plan(plan, tmp_path / f"{layout}.npz")
+        back = load_plan(tmp_path / f"{layout}.npz")
+        assert (back.n_agents, back.layout, back.n_slices, back.slice_agents) == (plan.n_agents, layout, plan.n_slices, plan.slice_agents)
+        assert np.array_equal(back.agent_class, plan.agent_class) and np.array_equal(back.blocks, plan.blocks)
+        for a, b in zip(plan.sets, back.sets):
+            assert a.name == b.name and a.n_edges == b.n_edges
+            for k in ("v_rowptr", "v_agent", "a_rowptr", "a_venue", "v_pcontact"):
+                x, y = getattr(a, k), getattr(b, k)
+                assert (x is None and y is None) or np.array_equal(x, y), (layout, k)
+            if a.tiled is not None:
+                for k in ("blk_v0", "blk_e0", "e_lv", "e_cls", "a_la", "tile_sptr", "tile_jpos", "chunk_ptr", "chunk_desc"):
+                    x, y = getattr(a.tiled, k), getattr(b.tiled, k)
+                    assert (x is None and y is None) or np.array_equal(x, y), (layout, k)
