@@ -138,7 +138,9 @@ class SymptomsUpdater(torch.nn.Module):
         table = getattr(self, "_table", None)
         if table is None or table.device != device:
             table = self._table = sampler.stage_transition_probabilities.to(device=device, dtype=torch.float32).contiguous()
-        p = sampler.kernel_params()
+        p = getattr(self, "_params", None)
+        if p is None:      # built once: reading the distributions' parameters synchronises with the device
+            p = self._params = sampler.kernel_params()
         p.progress = table.data_ptr()
         p.time = float(timer.now)
         if getattr(self, "rng_seed", None) is None:
