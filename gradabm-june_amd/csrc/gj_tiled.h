@@ -166,6 +166,8 @@ struct TileBArgs {
   const float* tables;
   int32_t day_type;
   int32_t mode;            // 0: B then C (fused);  1: B only (cum written);  2: C only (cum read)
+  int32_t transpose;       // 1: pass-1 / pass-2 per-network tables exchanged (backward pass)
+  int32_t _pad;
 };
 
 struct Slots8 {           // 8 consecutive block-major slots: 16 bytes of local venue indices
@@ -189,8 +191,9 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
     for (int i = tid; i < nk * 200; i += kTileThreads) {
       const int k = i / 200, c = i % 200;
       const float l = B.tables[(int64_t)T.table[k] * GJ_TABLE_SIZE + B.day_type * 200 + c];
-      tabs[i] = l;
-      tabs[nk * 200 + i] = T.age75[k] ? l * (((c % 100) > 75) ? 1.0f : 0.0f) : l;
+      const float lw = T.age75[k] ? l * (((c % 100) > 75) ? 1.0f : 0.0f) : l;
+      tabs[i] = B.transpose ? lw : l;                 // weights of the transmitting side (pass 1)
+      tabs[nk * 200 + i] = B.transpose ? l : lw;      // weights of the receiving side (pass 2)
     }
   }
   const uint4* lv8 = reinterpret_cast<const uint4*>(T.e_lv);

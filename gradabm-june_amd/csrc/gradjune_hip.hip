@@ -442,6 +442,70 @@ __global__ __launch_bounds__(kThreads) void k_symptoms(const SymptomsArgs S) {
   S.ttn[a] = tt;
 }
 
+// f3: elementwise adjoints (see include/gradjune_hip.h)
+__global__ __launch_bounds__(kThreads) void k_adjoint_sample(
+    int64_t n, const float* __restrict__ susc0, const float* __restrict__ time0, const float* __restrict__ acc,
+    const float* __restrict__ noise, uint64_t seed, uint64_t step, int64_t agent_offset, float now, float dt,
+    const float* __restrict__ g_susc, const float* __restrict__ g_inf, const float* __restrict__ g_time,
+    const float* __restrict__ g_new, float* __restrict__ x_out, float* __restrict__ grad_susc,
+    float* __restrict__ grad_time) {
+  const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= n) return;
+  const float s0 = susc0[a];
+  const float ac = acc[a];
+  const float ts = s0 * ac;
+  const bool inside = (ts >= 1e-6f) && (ts <= 100.0f);
+  const float tsc = fminf(fmaxf(ts, 1e-6f), 100.0f);
+  float p = expf(-tsc * dt);
+  p = fminf(fmaxf(p, 0.0f), 1.0f);
+  float e0, e1;
+  if (noise) {
+    e0 = noise[a];
+    e1 = noise[n + a];
+  } else {
+    exp_pair(seed, step, agent_offset + a, e0, e1);
+  }
+  // forward of the straight-through sampler (same op sequence as gumbel_new_infected)
+  const float z0 = (logf(p) + (-logf(e0))) / 0.1f;
+  const float z1 = (logf(1.0f - p) + (-logf(e1))) / 0.1f;
+  const float m = fmaxf(z0, z1);
+  const float x0 = expf(z0 - m), x1 = expf(z1 - m);
+  const float y0 = x0 / (x0 + x1), y1 = x1 / (x0 + x1);
+  const float nu = (y1 > y0) ? 1.0f : 0.0f;
+  const float gs = g_susc ? g_susc[a] : 0.0f, gi = g_inf ? g_inf[a] : 0.0f, gt = g_time ? g_time[a] : 0.0f;
+  const float gn = g_new ? g_new[a] : 0.0f;
+  const float x = s0 - nu;                                   // torch.maximum(0, x): tie splits the gradient
+  const float h = (x > 0.0f) ? 1.0f : ((x == 0.0f) ? 0.5f : 0.0f);
+  const float nu_bar = gi + gt * (now - time0[a]) - gs * h + gn;
+  float dnu_dp = -(y0 * y1 / 0.1f) * (1.0f / p + 1.0f / (1.0f - p));
+  if (!(fabsf(dnu_dp) < 3.0e38f)) dnu_dp = 0.0f;             // p == 0 or 1: y0*y1 == 0 there
+  const float ts_bar = inside ? nu_bar * dnu_dp * (-dt * p) : 0.0f;
+  x_out[a] = s0 * ts_bar;
+  grad_susc[a] = gs * h + ts_bar * ac;
+  grad_time[a] = gt * (1.0f - nu);
+}
+
+__global__ __launch_bounds__(kThreads) void k_adjoint_transmission(
+    int64_t n, const float* __restrict__ mx, const float* __restrict__ shp, const float* __restrict__ rt,
+    const float* __restrict__ sh, const float* __restrict__ time0, const float* __restrict__ inf0, float now,
+    const float* __restrict__ trans_bar, const float* __restrict__ g_inf, float* __restrict__ grad_inf,
+    float* __restrict__ grad_time) {
+  const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= n) return;
+  const float tb = trans_bar[a];
+  const float t = now - time0[a];
+  const float d = t - sh[a];
+  const float sign = (sgnf(d + 1e-10f) + 1.0f) / 2.0f;
+  const float aux = expf(-lgammaf(shp[a])) * powf(d * rt[a], shp[a] - 1.0f);
+  const float aux2 = expf((sh[a] - t) * rt[a]) * rt[a];
+  const float base = mx[a] * sign * aux * aux2;              // d trans / d is_infected
+  const float inf = inf0[a];
+  float dtdt = 0.0f;                                         // d trans / d t
+  if (inf != 0.0f) dtdt = base * inf * ((shp[a] - 1.0f) / d - rt[a]);
+  grad_inf[a] = (g_inf ? g_inf[a] : 0.0f) + tb * base;
+  grad_time[a] = grad_time[a] - tb * dtdt;                   // d t / d infection_time = -1
+}
+
 // f2: per-step result reductions (reference grad_june/runner.py:167,198-224), one streaming pass
 struct StatsArgs {
   int64_t n;
@@ -551,6 +615,7 @@ struct Groups {
 
 static int group_networks(const gj_plan* plan, const gj_step_params* p, Groups* G) {
   if (!p) return GJ_E_NULL;
+  if (p->transpose && !plan->tiled) return GJ_E_PLAN;   // the backward passes exist for the tiled layout
   if (p->n_nets < 0 || p->n_nets > GJ_MAX_NETS) return GJ_E_RANGE;
   if (p->day_type < 0 || p->day_type > 1) return GJ_E_RANGE;
   G->n = 0;
@@ -829,6 +894,7 @@ static int tiled_venues(const gj_plan* plan, const gj_step_params* p, const Grou
   B.tables = plan->tables;
   B.day_type = p->day_type;
   B.mode = mode;
+  B.transpose = p->transpose;
   int rc = allow_lds(k_tile_venues, lds);
   if (rc) return rc;
   hipLaunchKernelGGL(k_tile_venues, dim3((unsigned)T->n_work), dim3(kTileThreads), lds, stream, B);
@@ -962,6 +1028,33 @@ int gj_sample_infect(int64_t n_agents, const float* not_infected_probs, const fl
   hipLaunchKernelGGL(gj::k_sample_infect, dim3((unsigned)blocks), dim3(gj::kThreads), 0, (hipStream_t)stream, n_agents,
                      not_infected_probs, exp_noise, seed, step, agent_offset, now, new_infected, susceptibility,
                      is_infected, infection_time);
+  return gj::launch_status();
+}
+
+int gj_adjoint_sample(int64_t n, const float* susceptibility0, const float* infection_time0, const float* acc,
+                      const float* exp_noise, uint64_t seed, uint64_t step, int64_t agent_offset, float now,
+                      float delta_time, const float* g_susc, const float* g_inf, const float* g_time,
+                      const float* g_new, float* x_out, float* grad_susc_out, float* grad_time_out, void* stream) {
+  if (n < 0) return GJ_E_RANGE;
+  if (n == 0) return GJ_OK;
+  if (!susceptibility0 || !infection_time0 || !acc || !x_out || !grad_susc_out || !grad_time_out) return GJ_E_NULL;
+  hipLaunchKernelGGL(gj::k_adjoint_sample, dim3((unsigned)((n + gj::kThreads - 1) / gj::kThreads)), dim3(gj::kThreads),
+                     0, (hipStream_t)stream, n, susceptibility0, infection_time0, acc, exp_noise, seed, step,
+                     agent_offset, now, delta_time, g_susc, g_inf, g_time, g_new, x_out, grad_susc_out, grad_time_out);
+  return gj::launch_status();
+}
+
+int gj_adjoint_transmission(int64_t n, const gj_agent_state* st, float now, const float* trans_bar,
+                            const float* g_inf, float* grad_inf_out, float* grad_time_inout, void* stream) {
+  if (n < 0) return GJ_E_RANGE;
+  if (n == 0) return GJ_OK;
+  if (!st || !trans_bar || !grad_inf_out || !grad_time_inout) return GJ_E_NULL;
+  if (!st->max_infectiousness || !st->shape || !st->rate || !st->shift || !st->infection_time || !st->is_infected)
+    return GJ_E_NULL;
+  hipLaunchKernelGGL(gj::k_adjoint_transmission, dim3((unsigned)((n + gj::kThreads - 1) / gj::kThreads)),
+                     dim3(gj::kThreads), 0, (hipStream_t)stream, n, st->max_infectiousness, st->shape, st->rate,
+                     st->shift, st->infection_time, st->is_infected, now, trans_bar, g_inf, grad_inf_out,
+                     grad_time_inout);
   return gj::launch_status();
 }
 

@@ -108,6 +108,8 @@ class StepParams(C.Structure):
         ("seed", C.c_uint64),
         ("step", C.c_uint64),
         ("agent_offset", C.c_int64),
+        ("transpose", C.c_int32),
+        ("_pad", C.c_int32),
         ("nets", Network * GJ_MAX_NETS),
     ]
 
@@ -173,6 +175,12 @@ SYMBOLS = {
         C.c_int,
         [C.c_int64, _vp, _vp, C.c_uint64, C.c_uint64, C.c_int64, C.c_float, _vp, _vp, _vp, _vp, _vp],
     ),
+    "gj_adjoint_sample": (
+        C.c_int,
+        [C.c_int64, _vp, _vp, _vp, _vp, C.c_uint64, C.c_uint64, C.c_int64, C.c_float, C.c_float, _vp, _vp, _vp, _vp,
+         _vp, _vp, _vp, _vp],
+    ),
+    "gj_adjoint_transmission": (C.c_int, [C.c_int64, C.POINTER(AgentState), C.c_float, _vp, _vp, _vp, _vp, _vp]),
     "gj_symptoms_update": (
         C.c_int,
         [C.c_int64, _vp, _vp, _vp, _vp, _vp, C.POINTER(SymptomsParams), _vp, _vp, _vp],

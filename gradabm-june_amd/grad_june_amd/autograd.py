@@ -1,0 +1,130 @@
+"""Differentiable hot-path step (row f3 of SURVEY section 8): gradients w.r.t. every network's
+``log_beta`` and w.r.t. the incoming state, so that a loss on the infection counts can be
+back-propagated through the timesteps like with the reference (example_scripts/run_model.py:9-11).
+
+The forward of a step is the ordinary fused HIP step on fresh output tensors.  The backward is
+hand-written (``oracle/gj_oracle.py:adjoint_step`` is its dense CPU restatement, checked against the
+reference's autograd):
+
+* the two sparse passes are self-adjoint up to exchanging the per-network masks, so the gradient
+  w.r.t. the transmissions is the SAME four tiled phases run with ``transpose = 1`` on the vector
+  ``susceptibility * ts_bar``;
+* d loss / d log_beta_n = ln(10) * sum_v cum_n[v] * cum'_n[v] / (beta_n * p_contact[v]) - a dot
+  product of the forward and transposed per-venue sums;
+* the rest (straight-through Gumbel-softmax, clamp/exp/clamp, infect_people, transmission profile)
+  is elementwise: ``gj_adjoint_sample`` and ``gj_adjoint_transmission``.
+
+The pre-state of the step is kept for the backward; the intermediates are recomputed (one extra
+forward of the two passes), so a T-step graph holds 3 per-agent floats per step plus the noise key.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import List
+
+import torch
+
+from . import _native as N
+from .engine import AgentBuffers
+
+
+class HotPathStep(torch.autograd.Function):
+    """(susceptibility, is_infected, infection_time, *log_betas) -> (susceptibility', is_infected',
+    infection_time', new_infected)."""
+
+    @staticmethod
+    def forward(ctx, env, susc, inf, time, *log_betas):
+        engine, params, fixed, stage, exp_noise, nets = (env[k] for k in ("engine", "params", "fixed", "stage",
+                                                                           "exp_noise", "nets"))
+        plan = engine.plan
+        n = plan.host.n_agents
+        out_s, out_i, out_t = (t.detach().to(torch.float32).clone().contiguous() for t in (susc, inf, time))
+        trans = torch.zeros(plan.host.n_ext_agents, dtype=torch.float32, device=plan.device)
+        new_inf = torch.empty(n, dtype=torch.float32, device=plan.device)
+        bufs = AgentBuffers(plan, **fixed, infection_time=out_t, is_infected=out_i, susceptibility=out_s,
+                            transmission=trans, current_stage=stage)
+        engine.step(bufs, params, engine.io(new_infected=new_inf, exp_noise=exp_noise))
+        ctx.env = env
+        ctx.save_for_backward(susc.detach().to(torch.float32).contiguous(), inf.detach().to(torch.float32).contiguous(),
+                              time.detach().to(torch.float32).contiguous())
+        ctx.transmission = trans
+        return out_s, out_i, out_t, new_inf
+
+    @staticmethod
+    def backward(ctx, g_susc, g_inf, g_time, g_new):
+        env = ctx.env
+        engine, params, fixed, stage, exp_noise, nets = (env[k] for k in ("engine", "params", "fixed", "stage",
+                                                                           "exp_noise", "nets"))
+        susc0, inf0, time0 = ctx.saved_tensors
+        plan, lib, dev = engine.plan, N.load(), engine.plan.device
+        n = plan.host.n_agents
+        if plan.c.tiled is None or not bool(plan.c.tiled):
+            raise NotImplementedError("the backward pass runs on the tiled layout")
+
+        def f32(g):
+            return None if g is None else g.detach().to(torch.float32).contiguous()
+
+        g_susc, g_inf, g_time, g_new = f32(g_susc), f32(g_inf), f32(g_time), f32(g_new)
+        ones = torch.ones(n, dtype=torch.float32, device=dev)
+        scratch = torch.zeros(plan.host.n_ext_agents, dtype=torch.float32, device=dev)
+        acc = torch.empty(n, dtype=torch.float32, device=dev)
+        # ---- recompute the forward of the two passes from the saved pre-state ----------------------------
+        bufs = AgentBuffers(plan, **fixed, infection_time=time0, is_infected=inf0, susceptibility=ones,
+                            transmission=scratch, current_stage=stage)
+        io = engine.io(trans_susc=acc)
+        p = params
+        p.transpose = 0
+        for phase in (0, 1, 5):
+            engine.step_phase(bufs, p, io, phase)
+        names = [net.name for net in nets]
+        cum_fwd = {}
+        for name in names:
+            es = plan.networks[name].edge_set
+            if es not in cum_fwd:
+                cum_fwd[es] = plan.cum_of(es).clone()
+        for phase in (6, 4):
+            engine.step_phase(bufs, p, io, phase)                 # acc = sum_n w_n * (L_n (m_n trans))
+        # ---- elementwise adjoint of epilogue + sampler + infect_people ------------------------------------
+        x = torch.empty(n, dtype=torch.float32, device=dev)
+        grad_susc = torch.empty(n, dtype=torch.float32, device=dev)
+        grad_time = torch.empty(n, dtype=torch.float32, device=dev)
+        N.check(lib.gj_adjoint_sample(n, N.ptr(susc0), N.ptr(time0), N.ptr(acc), N.ptr(exp_noise), int(p.seed),
+                                      int(p.step), int(p.agent_offset), float(p.now), float(p.delta_time),
+                                      N.ptr(g_susc), N.ptr(g_inf), N.ptr(g_time), N.ptr(g_new), N.ptr(x),
+                                      N.ptr(grad_susc), N.ptr(grad_time), N.current_stream()), "gj_adjoint_sample")
+        # ---- transposed passes on x = susc0 * ts_bar --------------------------------------------------------
+        scratch[:n].copy_(x)
+        tbar = torch.empty(n, dtype=torch.float32, device=dev)
+        io_t = engine.io(trans_susc=tbar)
+        p.transpose = 1
+        engine.quarantine_transmission(bufs, p)                    # q * x for the masked sets
+        for phase in (1, 5):
+            engine.step_phase(bufs, p, io_t, phase)
+        grads: List[torch.Tensor] = []
+        per_set_k = {}
+        for net in nets:
+            es = plan.networks[net.name].edge_set
+            k = per_set_k.get(es, 0)
+            per_set_k[es] = k + 1
+            i = plan.host.set_index[es]
+            pc = plan.keep[i]["v_pc"].double()
+            beta = float(env["betas"][net.name])
+            prod = cum_fwd[es][:, k].double() * plan.cum_of(es)[:, k].double()
+            dot = torch.where(pc > 0, prod / (beta * pc), torch.zeros_like(prod)).sum() if beta != 0.0 else prod.sum() * 0
+            grads.append((dot * math.log(10.0)).to(torch.float32))
+        for phase in (6, 4):
+            engine.step_phase(bufs, p, io_t, phase)                # tbar = d loss / d transmission
+        p.transpose = 0
+        # ---- through the transmission profile ------------------------------------------------------------------
+        grad_inf = torch.empty(n, dtype=torch.float32, device=dev)
+        st0 = AgentBuffers(plan, **fixed, infection_time=time0, is_infected=inf0, susceptibility=ones,
+                           transmission=scratch)
+        N.check(lib.gj_adjoint_transmission(n, C.byref(st0.c), float(p.now), N.ptr(tbar), N.ptr(g_inf),
+                                            N.ptr(grad_inf), N.ptr(grad_time), N.current_stream()),
+                "gj_adjoint_transmission")
+        out_grads = []
+        for net, g in zip(nets, grads):
+            lb = net.log_beta
+            out_grads.append(g.to(lb.device).reshape(lb.shape) if isinstance(lb, torch.Tensor) and lb.requires_grad else None)
+        return (None, grad_susc, grad_inf, grad_time, *out_grads)

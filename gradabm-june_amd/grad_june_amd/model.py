@@ -60,7 +60,9 @@ class GradJune(torch.nn.Module):
         device = require_hip(self.device)
         nets = self.infection_networks
         active = nets.active_networks(timer, self.policies)
-        _check_no_grad(active)
+        differentiable = torch.is_grad_enabled() and (
+            any(isinstance(n.log_beta, torch.Tensor) and n.log_beta.requires_grad for n in active)
+            or any(data["agent"][k].requires_grad for k in ("susceptibility", "is_infected", "infection_time")))
         self.policies.apply(timer=timer, data=data)
         engine = engine_for(data, [n.spec() for n in nets.networks.values()], device)
         for n in active:
@@ -76,6 +78,8 @@ class GradJune(torch.nn.Module):
             has_quarantine=has_q, q_threshold=qp.threshold if has_q else math.inf,
             seed=self.rng_seed, step=self.n_steps)
         self.n_steps += 1
+        if differentiable:
+            return self._hot_path_differentiable(data, engine, params, active, has_q, exp_noise, want_probs)
         bufs = agent_buffers(engine, data, need_params=True, need_stage=has_q)
         n = engine.plan.host.n_agents
         new_infected = torch.empty(n, dtype=torch.float32, device=device)
@@ -85,7 +89,31 @@ class GradJune(torch.nn.Module):
         engine.step(bufs, params, engine.io(not_infected_probs=probs, new_infected=new_infected, exp_noise=exp_noise))
         return new_infected, probs
 
+    def _hot_path_differentiable(self, data, engine, params, active, has_q, exp_noise, want_probs):
+        """Row f3: the step as an autograd node (grad_june_amd.autograd.HotPathStep)."""
+        from .autograd import HotPathStep
+
+        if want_probs:
+            raise NotImplementedError("want_probs is not available in differentiable mode")
+        dev = engine.plan.device
+        ag = data["agent"]
+        n = engine.plan.host.n_agents
+        f = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        ip = ag["infection_parameters"]
+        fixed = {k: f(ip[k]) for k in ("max_infectiousness", "shape", "rate", "shift")}
+        stage = f(ag["symptoms"]["current_stage"]).clone() if has_q else None
+        if exp_noise is not None:
+            exp_noise = exp_noise.to(device=dev, dtype=torch.float32).contiguous()
+        env = {"engine": engine, "params": params, "fixed": fixed, "stage": stage, "exp_noise": exp_noise,
+               "nets": list(active), "betas": {n_.name: float(params.nets[i].beta) for i, n_ in enumerate(active)}}
+        state = [ag[k] if ag[k].dtype == torch.float32 else ag[k].to(torch.float32) for k in
+                 ("susceptibility", "is_infected", "infection_time")]
+        susc, inf, time, new_infected = HotPathStep.apply(env, *state, *[n_.log_beta for n_ in active])
+        ag.susceptibility, ag.is_infected, ag.infection_time = susc, inf, time
+        return new_infected, None
+
     def forward(self, data, timer, exp_noise=None):
         new_infected, _ = self.hot_path(data, timer, exp_noise=exp_noise)
-        self.symptoms_updater(data=data, timer=timer, new_infected=new_infected)
+        # the symptoms state machine is not differentiated (its only gradient path feeds the deaths series)
+        self.symptoms_updater(data=data, timer=timer, new_infected=new_infected.detach())
         return data

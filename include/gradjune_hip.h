@@ -186,6 +186,10 @@ typedef struct gj_step_params {
   uint64_t seed;        /* Philox key (perf mode)                                           */
   uint64_t step;        /* Philox stream id: timestep counter                               */
   int64_t agent_offset; /* global id of local agent 0 (multi-GPU: partition-invariant RNG)  */
+  int32_t transpose;    /* 0: forward.  1 (tiled layout, backward pass): the two passes run with the
+                           pass-1 / pass-2 per-network weights exchanged - the adjoint of the
+                           aggregation w.r.t. the transmissions (row f3)                      */
+  int32_t _pad;
   gj_network nets[GJ_MAX_NETS];
 } gj_step_params;
 
@@ -291,6 +295,28 @@ int gj_symptoms_update(int64_t n, const uint8_t* agent_class, const float* new_i
 int gj_step_stats(int64_t n, const uint8_t* agent_class, const float* is_infected,
                   const float* current_stage, int32_t n_bins, const int32_t* bin_edges /* host [n_bins+1] */,
                   int32_t dead_stage, double* out, void* stream);
+
+/* ---- row f3: adjoint (backward) of one hot-path step, forward-only kernels reused ---------------
+ * The aggregation ts = susc * sum_n w_n * (M_n^T diag(beta_n p_contact) M_n)(m_n * transmission) is
+ * self-adjoint up to the exchange of the masks m_n <-> w_n, so its backward is the same four tiled
+ * phases run with gj_step_params.transpose = 1 on the vector susc0 * ts_bar.  What remains is
+ * elementwise:
+ * gj_adjoint_sample: through infect_people (model.py:103-110), the straight-through Gumbel-softmax
+ *   (infection.py:13-18) and clamp/exp/clamp (base.py:136-140).  Inputs: the step's pre-state, `acc`
+ *   (= pre-susceptibility sum, i.e. gj_agent_gather's trans_susc run with susceptibility == 1), the
+ *   step's noise (or Philox key) and the gradients w.r.t. the step's outputs (NULL = zeros).
+ *   Outputs: x_out = susc0 * ts_bar (input of the transposed passes), grad_susc_out (complete),
+ *   grad_time_out = g_time * (1 - new_infected).
+ * gj_adjoint_transmission: through the transmission profile (transmission.py:39-51):
+ *   grad_inf_out = g_inf + trans_bar * d trans/d is_infected;
+ *   grad_time_inout += trans_bar * d trans/d infection_time.                                        */
+int gj_adjoint_sample(int64_t n, const float* susceptibility0, const float* infection_time0, const float* acc,
+                      const float* exp_noise, uint64_t seed, uint64_t step, int64_t agent_offset, float now,
+                      float delta_time, const float* g_susc, const float* g_inf, const float* g_time,
+                      const float* g_new, float* x_out, float* grad_susc_out, float* grad_time_out,
+                      void* stream);
+int gj_adjoint_transmission(int64_t n, const gj_agent_state* state0, float now, const float* trans_bar,
+                            const float* g_inf, float* grad_inf_out, float* grad_time_inout, void* stream);
 
 /* The production step: a1..a9 = the middle of GradJune.forward (grad_june/model.py:125-138)
  * as three dependent launches on `stream` (+1 when the plan has long rows).                */

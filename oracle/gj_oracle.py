@@ -175,7 +175,7 @@ def sample_infected(not_infected_probs, exp_noise):
     y_soft = gumbels.softmax(0)
     index = y_soft.max(0, keepdim=True)[1]
     y_hard = torch.zeros_like(logits).scatter_(0, index, 1.0)
-    ret = y_hard - y_soft + y_soft
+    ret = y_hard - y_soft.detach() + y_soft      # straight-through: forward hard, gradient of y_soft
     return 1.0 - ret[0, :]
 
 
@@ -329,3 +329,80 @@ def hot_path_step(
         if not isinstance(qmask, float):
             out["qmask"] = qmask
     return out
+
+
+# --------------------------------------------------------------------------------------
+# f3  hand-written adjoint of one hot-path step (what the HIP backward implements), restated with
+#     dense torch ops and NO autograd - checked against autograd of hot_path_step and against the
+#     reference's recorded gradients (tests/test_gradients.py).
+#     Inputs: the step's pre-state and scalars, the noise, and the gradients flowing into its outputs
+#     (g_susc, g_inf, g_time w.r.t. the post-step susceptibility / is_infected / infection_time).
+#     Returns (grad_susc_in, grad_inf_in, grad_time_in, {network: d loss / d log_beta}).
+# --------------------------------------------------------------------------------------
+def adjoint_step(world, state, *, now, delta_time, day_type, active, betas, leisure_tables=None,
+                 quarantine_thresholds=None, exp_noise, g_susc, g_inf, g_time):
+    import math
+
+    A = world["n_agents"]
+    f64 = torch.float64
+    mx, shp, rt, sh = (state[k].to(f64) for k in ("max_infectiousness", "shape", "rate", "shift"))
+    time0, inf0, susc0 = state["infection_time"].to(f64), state["is_infected"].to(f64), state["susceptibility"].to(f64)
+    g_susc, g_inf, g_time = g_susc.to(f64), g_inf.to(f64), g_time.to(f64)
+    # ---- recompute the forward pieces -----------------------------------------------------------
+    t = now - time0
+    d = t - sh
+    sign = (torch.sign(d + 1e-10) + 1) / 2
+    aux = torch.exp(-torch.lgamma(shp)) * torch.pow(d * rt, shp - 1.0)
+    aux2 = torch.exp((sh - t) * rt) * rt
+    base = mx * sign * aux * aux2                      # d trans / d is_infected
+    trans = base * inf0
+    dtrans_dt = trans * ((shp - 1.0) / d - rt)         # d trans / d t ;  d t / d infection_time = -1
+    q = 1.0 if quarantine_thresholds is None else quarantine_mask(state["current_stage"], quarantine_thresholds).to(f64)
+    order = sorted(active, key=ACTIVITY_HIERARCHY.index)
+    acc = torch.zeros(A, dtype=f64)                    # sum_n w_n * (L_n (m_n trans)), before * susc
+    per_net = {}
+    for name in order:
+        es = world["edge_sets"][edge_set_of(name)]
+        kind = network_kind(name)
+        m = w = torch.ones(A, dtype=f64)
+        if kind != "household":
+            m = w = m * q
+        if kind in ("leisure", "care_visit"):
+            lp = leisure_agent_probabilities(leisure_tables[name], world["sex"], world["age"], day_type).to(f64)
+            m = m * lp
+            w = w * lp
+        if kind == "care_visit":
+            w = w * (world["age"] > 75)
+        y = float(betas[name]) * p_contact(es["people"]).to(f64)
+        S = torch.zeros(len(y), dtype=f64).scatter_add_(0, es["venue"], (m * trans)[es["agent"]])
+        Ln = torch.zeros(A, dtype=f64).scatter_add_(0, es["agent"], (y * S)[es["venue"]])
+        acc += w * Ln
+        per_net[name] = (es, m, w, y, S)
+    ts = susc0 * acc
+    inside = (ts >= 1e-6) & (ts <= 100)
+    tsc = torch.clamp(ts, 1e-6, 100)
+    p = torch.exp(-tsc * delta_time)
+    l0, l1 = torch.log(p), torch.log(1 - p)
+    g = -torch.log(exp_noise.to(f64))
+    z = torch.stack((l0 + g[0], l1 + g[1])) / GUMBEL_TAU
+    ysoft = torch.softmax(z, 0)
+    nu = (ysoft[1] > ysoft[0]).to(f64)                 # forward value of new_infected
+    # ---- adjoints ---------------------------------------------------------------------------------
+    x = susc0 - nu
+    h = torch.where(x > 0, torch.ones_like(x), torch.where(x == 0, torch.full_like(x, 0.5), torch.zeros_like(x)))
+    nu_bar = g_inf + g_time * (now - time0) - g_susc * h
+    dnu_dp = -(ysoft[0] * ysoft[1] / GUMBEL_TAU) * (1.0 / p + 1.0 / (1.0 - p))
+    dnu_dp = torch.nan_to_num(dnu_dp, nan=0.0, posinf=0.0, neginf=0.0)
+    ts_bar = nu_bar * dnu_dp * (-delta_time * p) * inside
+    grad_susc = g_susc * h + ts_bar * acc
+    xp = susc0 * ts_bar                                # input of the transposed pipeline
+    trans_bar = torch.zeros(A, dtype=f64)
+    grad_lb = {}
+    for name, (es, m, w, y, S) in per_net.items():
+        Sp = torch.zeros(len(y), dtype=f64).scatter_add_(0, es["venue"], (w * xp)[es["agent"]])
+        trans_bar += m * torch.zeros(A, dtype=f64).scatter_add_(0, es["agent"], (y * Sp)[es["venue"]])
+        grad_lb[name] = float((y * S * Sp).sum()) * math.log(10.0)
+    grad_inf = g_inf + trans_bar * base
+    grad_time = g_time * (1.0 - nu) - trans_bar * dtrans_dt
+    new_state = infect_people(state["susceptibility"], state["is_infected"], state["infection_time"], nu.float(), now)
+    return grad_susc, grad_inf, grad_time, grad_lb, new_state

@@ -18,6 +18,8 @@ Files written (data only - no reference source text):
     june769_hot.npz   the same with every log_beta raised by 0.9 (a real epidemic wave)
     synth10k.npz      10k-agent synthetic with degree-0/1 venues, a 5k-agent venue, duplicates
     world769.npz      test/data/data.pkl as neutral arrays (graph + agent attributes)
+    grads.npz         d(cases)/d(log_beta) of every network through 4 / 6 timesteps (autograd of the
+                      reference), with the noise of every step, on the 100- and 769-agent worlds
     default_params.json   yaml.safe_load(configs/default.yaml) (dates stringified)
 """
 from __future__ import annotations
@@ -591,6 +593,114 @@ def make_synth10k():
     save("synth10k.npz", out)
 
 
+# ------------------------------------------------------------------------------------------
+# case: gradients (row f3): d cases / d log_beta through several timesteps, noise recorded
+# ------------------------------------------------------------------------------------------
+class _NoiseRecorder(torch.nn.Module):
+    """Stands where model.is_infected_sampler is; records the Exponential(1) draw of each call."""
+
+    def __init__(self, inner):
+        super().__init__()
+        self.inner, self.noise = inner, []
+
+    def forward(self, not_infected_probs):
+        rng = torch.get_rng_state()
+        out = self.inner(not_infected_probs)
+        after = torch.get_rng_state()
+        torch.set_rng_state(rng)
+        self.noise.append(torch.empty(2, not_infected_probs.shape[0]).exponential_())
+        torch.set_rng_state(after)
+        return out
+
+
+def run_with_grads(model, data, timer, n_steps, out, prefix, step_first=True):
+    rec = _NoiseRecorder(model.is_infected_sampler)
+    model.is_infected_sampler = rec
+    names = list(model.infection_networks.networks.keys())
+    for n in names:
+        net = model.infection_networks.networks[n]
+        net.log_beta = torch.nn.Parameter(net.log_beta.detach().clone())
+    st0 = state_of(data)
+    for k, v in st0.items():
+        out[f"{prefix}state0/{k}"] = v.numpy().copy()
+    cases_series = []
+    for i in range(n_steps):
+        if step_first:
+            next(timer)
+        out[f"{prefix}step{i}/current_stage"] = data["agent"]["symptoms"]["current_stage"].detach().numpy().astype(np.float32)
+        out[f"{prefix}step{i}/now"] = np.float64(timer.now)
+        out[f"{prefix}step{i}/dt"] = np.float64(timer.duration)
+        out[f"{prefix}step{i}/day_type"] = np.int64(0 if timer.day_type == "weekday" else 1)
+        order = timer.get_activity_order()
+        if model.policies.close_venue_policies:
+            order = model.policies.close_venue_policies.apply(edge_types=order, timer=timer)
+        out[f"{prefix}step{i}/active"] = np.array(",".join(order))
+        for n in order:
+            net = model.infection_networks[n]
+            b = (10.0 ** net.log_beta.detach())
+            if model.policies.interaction_policies:
+                b = model.policies.interaction_policies.apply(beta=b, name=n, timer=timer)
+            out[f"{prefix}step{i}/beta/{n}"] = np.float32(b.item())
+        qp = model.policies.quarantine_policies
+        thr = [(float(p.stage_threshold) if p.is_active(timer.date) else np.nan) for p in qp.policies] if qp else []
+        out[f"{prefix}step{i}/q_thresholds"] = np.array(thr, dtype=np.float64)
+        out[f"{prefix}step{i}/has_quarantine"] = np.int64(1 if qp else 0)
+        data = model(data=data, timer=timer)
+        cases_series.append(data["agent"].is_infected.sum())
+        out[f"{prefix}step{i}/exp_noise"] = rec.noise[-1].numpy().copy()
+        out[f"{prefix}step{i}/is_infected"] = data["agent"].is_infected.detach().numpy().copy()
+        if not step_first:
+            next(timer)
+    out[prefix + "n_steps"] = np.int64(n_steps)
+    out[prefix + "networks"] = np.array(",".join(names))
+    # loss 1: infected count after the last step; loss 2: sum of the series (run_model.py:9-11)
+    for tag, loss in (("last", cases_series[-1]), ("series", torch.stack(cases_series).sum())):
+        for n in names:
+            model.infection_networks.networks[n].log_beta.grad = None
+        loss.backward(retain_graph=True)
+        for n in names:
+            g = model.infection_networks.networks[n].log_beta.grad
+            out[f"{prefix}grad_{tag}/{n}"] = np.float32(0.0 if g is None else g.item())
+        out[f"{prefix}loss_{tag}"] = np.float32(loss.item())
+    print(prefix, {n: float(out[f"{prefix}grad_series/{n}"]) for n in names})
+    return data
+
+
+def make_grads():
+    out = {}
+    # g1: the 100-agent fixture, three networks, 4 steps (test_model.py:34-53 style)
+    seed_all(31)
+    data = conftest_data()
+    flat_world(world_of(data), out, prefix="g1/world/")
+    nets = InfectionNetworks(household=HouseholdNetwork(log_beta=0.2), company=CompanyNetwork(log_beta=0.4),
+                             school=SchoolNetwork(log_beta=0.3))
+    model = GradJune(infection_networks=nets, policies=Policies.from_policy_list([]))
+    timer = Timer(initial_day="2022-02-01", total_days=10, weekday_step_duration=(24,), weekend_step_duration=(24,),
+                  weekday_activities=(("company", "school", "household"),),
+                  weekend_activities=(("company", "school", "household"),))
+    next(timer); next(timer)
+    run_with_grads(model, data, timer, 4, out, "g1/", step_first=True)
+    # g2: the 769-agent world, default parameters (11 networks, leisure tables) + an active quarantine
+    # and social distancing window, 6 steps
+    params = default_params()
+    params["policies"]["quarantine"] = {
+        "quarantine": {1: {"start_date": "2022-02-03", "end_date": "2022-02-20", "stage_threshold": 4}}}
+    params["policies"]["interaction"]["social_distancing"][1]["start_date"] = "2022-02-04"
+    for n in params["networks"]:
+        params["networks"][n]["log_beta"] += 0.7
+    seed_all(77)
+    runner = Runner.from_parameters(params)
+    with torch.no_grad():
+        runner.timer.reset()
+        runner.restore_initial_data()
+        runner.set_initial_cases()
+    flat_world(world_of(runner.data), out, prefix="g2/world/")
+    for n, t in tables_of(runner.model).items():
+        out["g2/table/" + n] = t.numpy()
+    run_with_grads(runner.model, runner.data, runner.timer, 6, out, "g2/", step_first=True)
+    save("grads.npz", out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     make_kat6()
@@ -598,4 +708,5 @@ if __name__ == "__main__":
     make_june769()
     make_june769("june769_hot", beta_shift=0.9, write_world=False)
     make_synth10k()
+    make_grads()
     print("all golden cases generated; oracle == reference on every recorded stage")

@@ -1,0 +1,205 @@
+"""Row f3: d(cases)/d(log_beta) through several timesteps.
+
+CPU: the oracle (autograd through its torch ops) against the gradients recorded from the reference.
+GPU: the HIP path's hand-written adjoint (`GradJune` in grad mode) against the same records."""
+import numpy as np
+import pytest
+import torch
+
+import gj_oracle as O
+import gj_testlib as L
+
+CASES = ["g1", "g2"]
+
+
+def load_case(case):
+    npz = L.load_npz("grads.npz")
+    pre = case + "/"
+    sub = {k[len(pre):]: v for k, v in npz.items() if k.startswith(pre)}
+    world = L.world_from(sub)
+    tables = {k[6:]: torch.from_numpy(v) for k, v in sub.items() if k.startswith("table/")}
+    names = str(sub["networks"]).split(",")
+    return sub, world, tables, names
+
+
+def step_info(sub, i):
+    p = f"step{i}/"
+    active = str(sub[p + "active"]).split(",") if str(sub[p + "active"]) else []
+    thr = None
+    if int(sub[p + "has_quarantine"]):
+        thr = [None if np.isnan(t) else float(t) for t in sub[p + "q_thresholds"]]
+    return dict(now=float(sub[p + "now"]), dt=float(sub[p + "dt"]), day_type=int(sub[p + "day_type"]), active=active,
+                betas={n: float(sub[p + "beta/" + n]) for n in active}, thr=thr,
+                noise=torch.from_numpy(sub[p + "exp_noise"]), stage=torch.from_numpy(sub[p + "current_stage"]),
+                is_infected=sub[p + "is_infected"])
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_autograd_matches_reference(case):
+    sub, world, tables, names = load_case(case)
+    # log_beta per network recovered from the recorded beta of a step without distancing factors is not
+    # needed: d/dlog_beta = ln(10) * beta * d/dbeta, so differentiate w.r.t. a unit multiplier of beta
+    mult = {n: torch.ones((), requires_grad=True) for n in names}
+    st = {k[7:]: torch.from_numpy(v) for k, v in sub.items() if k.startswith("state0/")}
+    series = []
+    for i in range(int(sub["n_steps"])):
+        s = step_info(sub, i)
+        st["current_stage"] = s["stage"]
+        betas = {n: torch.tensor(np.float32(s["betas"][n])) * mult[n] for n in s["active"]}
+        out = O.hot_path_step(world, st, now=s["now"], delta_time=s["dt"], day_type=s["day_type"], active=s["active"],
+                              betas=betas, leisure_tables=tables, quarantine_thresholds=s["thr"], exp_noise=s["noise"])
+        for k in ("susceptibility", "is_infected", "infection_time"):
+            st[k] = out[k]
+        assert np.array_equal(out["is_infected"].detach().numpy(), s["is_infected"]), i
+        series.append(out["is_infected"].sum())
+    for tag, loss in (("last", series[-1]), ("series", torch.stack(series).sum())):
+        grads = torch.autograd.grad(loss, [mult[n] for n in names], retain_graph=True, allow_unused=True)
+        for n, g in zip(names, grads):
+            got = 0.0 if g is None else float(g) * np.log(10.0)      # d/dlog_beta = ln10 * d/dmult
+            ref = float(sub[f"grad_{tag}/{n}"])
+            assert got == pytest.approx(ref, rel=2e-4, abs=1e-6), (tag, n)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_handwritten_adjoint_matches_reference(case):
+    """The adjoint recursion the HIP backward implements, restated densely on the CPU: reverse sweep
+    over the recorded steps, gradients of both losses against the reference's."""
+    sub, world, tables, names = load_case(case)
+    T = int(sub["n_steps"])
+    st = {k[7:]: torch.from_numpy(v) for k, v in sub.items() if k.startswith("state0/")}
+    states, infos = [], []
+    for i in range(T):                                   # forward sweep (stores the pre-state of every step)
+        s = step_info(sub, i)
+        st["current_stage"] = s["stage"]
+        states.append(dict(st))
+        infos.append(s)
+        out = O.hot_path_step(world, st, now=s["now"], delta_time=s["dt"], day_type=s["day_type"], active=s["active"],
+                              betas=s["betas"], leisure_tables=tables, quarantine_thresholds=s["thr"], exp_noise=s["noise"])
+        for k in ("susceptibility", "is_infected", "infection_time"):
+            st[k] = out[k]
+    A = world["n_agents"]
+    for tag in ("last", "series"):
+        total = {n: 0.0 for n in names}
+        gs, gi, gt = torch.zeros(A), torch.zeros(A), torch.zeros(A)
+        for i in reversed(range(T)):
+            if tag == "series" or i == T - 1:
+                gi = gi + 1.0                            # d loss / d is_infected after step i
+            s = infos[i]
+            gs, gi, gt, glb, _ = O.adjoint_step(world, states[i], now=s["now"], delta_time=s["dt"], day_type=s["day_type"],
+                                                active=s["active"], betas=s["betas"], leisure_tables=tables,
+                                                quarantine_thresholds=s["thr"], exp_noise=s["noise"],
+                                                g_susc=gs, g_inf=gi, g_time=gt)
+            for n, v in glb.items():
+                total[n] += v
+        for n in names:
+            assert total[n] == pytest.approx(float(sub[f"grad_{tag}/{n}"]), rel=5e-4, abs=1e-5), (tag, n)
+
+
+# ------------------------------------------------------------------------------------------------------
+# GPU: GradJune in grad mode (HIP forward + hand-written HIP adjoint) against the reference's gradients
+# ------------------------------------------------------------------------------------------------------
+def _hetero(G, sub, world, device):
+    d = G.HeteroData()
+    A = world["n_agents"]
+    ag = d["agent"]
+    ag.id = torch.arange(A)
+    ag.age, ag.sex = world["age"], world["sex"]
+    for s, es in world["edge_sets"].items():
+        d[s].id = torch.arange(len(es["people"]))
+        d[s].people = es["people"]
+        d["agent", "attends_" + s, s].edge_index = torch.vstack((es["agent"], es["venue"]))
+    d = d.to(device)
+    st = {k[7:]: torch.from_numpy(v).to(device) for k, v in sub.items() if k.startswith("state0/")}
+    ag.infection_parameters = {k: st[k] for k in ("max_infectiousness", "shape", "rate", "shift")}
+    for k in ("is_infected", "susceptibility", "infection_time"):
+        ag[k] = st[k]
+    ag.transmission = torch.zeros(A, device=device)
+    ag.symptoms = {"current_stage": st["current_stage"].float(), "next_stage": st["current_stage"].float(),
+                   "time_to_next_stage": torch.full((A,), 1e9, device=device)}
+    return d
+
+
+def _model_and_timer(G, case, device):
+    from grad_june_amd import infection_networks as inw
+    from grad_june_amd.defaults import default_parameters
+
+    if case == "g1":
+        nets = G.InfectionNetworks(device=device, household=inw.HouseholdNetwork(0.2, device),
+                                   company=inw.CompanyNetwork(0.4, device), school=inw.SchoolNetwork(0.3, device))
+        model = G.GradJune(infection_networks=nets, policies=G.Policies.from_policy_list([]), device=device)
+        timer = G.Timer(initial_day="2022-02-01", total_days=10, weekday_step_duration=(24,), weekend_step_duration=(24,),
+                        weekday_activities=(("company", "school", "household"),),
+                        weekend_activities=(("company", "school", "household"),))
+        next(timer); next(timer)
+        return model, timer
+    params = default_parameters(str(device))
+    params["policies"]["quarantine"] = {
+        "quarantine": {1: {"start_date": "2022-02-03", "end_date": "2022-02-20", "stage_threshold": 4}}}
+    params["policies"]["interaction"]["social_distancing"][1]["start_date"] = "2022-02-04"
+    for n in params["networks"]:
+        params["networks"][n]["log_beta"] += 0.7
+    return G.GradJune.from_parameters(params), G.Timer.from_parameters(params)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
+def test_hip_backward_matches_reference(device, case):
+    import grad_june_amd as G
+
+    sub, world, tables, names = load_case(case)
+    model, timer = _model_and_timer(G, case, device)
+    data = _hetero(G, sub, world, device)
+    for n in names:
+        net = model.infection_networks.networks[n]
+        net.log_beta = torch.nn.Parameter(net.log_beta.detach().clone())
+    series = []
+    for i in range(int(sub["n_steps"])):
+        s = step_info(sub, i)
+        next(timer)
+        assert timer.now == s["now"]
+        data["agent"].symptoms["current_stage"] = s["stage"].to(device)         # recorded symptom stage (quarantine mask)
+        for n in s["active"]:
+            assert np.float32(model.infection_networks[n].beta_value(model.policies, timer)) == np.float32(s["betas"][n])
+        new, _ = model.hot_path(data, timer, exp_noise=s["noise"])
+        assert np.array_equal(data["agent"].is_infected.detach().cpu().numpy(), s["is_infected"]), i
+        assert data["agent"].is_infected.requires_grad
+        series.append(data["agent"].is_infected.sum())
+    params = [model.infection_networks.networks[n].log_beta for n in names]
+    for tag, loss in (("last", series[-1]), ("series", torch.stack(series).sum())):
+        grads = torch.autograd.grad(loss, params, retain_graph=True, allow_unused=True)
+        for n, g in zip(names, grads):
+            got = 0.0 if g is None else float(g)
+            ref = float(sub[f"grad_{tag}/{n}"])
+            assert got == pytest.approx(ref, rel=2e-3, abs=1e-4), (tag, n, got, ref)
+
+
+@pytest.mark.gpu
+def test_gradient_is_zero_for_network_not_attended(device):
+    """test_model.py:76-143: an agent infected at school carries no gradient to the company network."""
+    import grad_june_amd as G
+    from grad_june_amd import infection_networks as inw
+
+    sub, world, tables, names = load_case("g1")
+    data = _hetero(G, sub, world, device)
+    # decoupled halves: agents 0-49 only in one school, 50-99 only in one company (test_model.py:55-74)
+    for name, lo in (("school", 0), ("company", 50)):
+        data[name].id = torch.tensor([0])
+        data[name].people = torch.tensor([50], device=device)
+        data["agent", "attends_" + name, name].edge_index = torch.vstack(
+            (torch.arange(lo, lo + 50), torch.zeros(50, dtype=torch.long))).to(device)
+    nets = G.InfectionNetworks(device=device, company=inw.CompanyNetwork(torch.nn.Parameter(torch.tensor(0.5)), device),
+                               school=inw.SchoolNetwork(torch.nn.Parameter(torch.tensor(0.5)), device))
+    model = G.GradJune(infection_networks=nets, policies=G.Policies.from_policy_list([]), device=device)
+    timer = G.Timer(initial_day="2022-02-01", total_days=10, weekday_step_duration=(24,), weekend_step_duration=(24,),
+                    weekday_activities=(("company", "school"),), weekend_activities=(("company", "school"),))
+    torch.manual_seed(2)
+    seed = data["agent"].is_infected.clone()
+    for _ in range(4):
+        next(timer)
+        model.hot_path(data, timer)
+    cases = data["agent"].is_infected
+    k = [i for i in range(50) if cases[i] == 1.0 and seed[i] == 0.0]
+    assert k, "nobody infected at school"
+    gs, gc = torch.autograd.grad(cases[k[0]], [nets["school"].log_beta, nets["company"].log_beta], allow_unused=True)
+    assert gs is not None and gs != 0.0
+    assert gc is None or gc == 0.0
