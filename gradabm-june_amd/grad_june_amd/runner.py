@@ -173,16 +173,31 @@ class Runner(torch.nn.Module):
         else:
             n_rows = 4096
         self._series = torch.zeros(n_rows, 2 + n_bins, dtype=torch.float64, device=require_hip(self.device))
-        self._record(data, 0)
+        # differentiable run (a log_beta is an nn.Parameter, grad mode on): the case series must stay on
+        # the autograd graph, so they are formed with tensor ops instead of the fused reduction kernel
+        differentiable = torch.is_grad_enabled() and any(
+            isinstance(n.log_beta, torch.Tensor) and n.log_beta.requires_grad
+            for n in model.infection_networks.networks.values())
+        diff_rows = []
+
+        def record(row):
+            self._record(data, row)
+            if differentiable:
+                ag = data["agent"]
+                diff_rows.append(torch.cat((ag.is_infected.sum().reshape(1), self.get_cases_by_age(data))))
+
+        record(0)
         dates = [timer.date]
         row = 0
         while timer.date < timer.final_date:
             next(timer)
             data = model(data, timer)
             row += 1
-            self._record(data, row)
+            record(row)
             dates.append(timer.date)
         series = self._series[: row + 1].to(torch.float32)
+        if differentiable:
+            series = torch.cat((torch.stack(diff_rows), series[:, 1 + n_bins:]), dim=1)
         cases_per_timestep = series[:, 0]
         data["results"]["deaths_per_timestep"] = series[:, 1 + n_bins]
         results = {

@@ -228,11 +228,32 @@ def test_is_infected_sampler_statistics(G, device):
     assert torch.equal(sampler(p, exp_noise=noise).cpu() > 0.5, O.sample_infected(p.cpu(), noise) > 0.5)
 
 
-def test_gradient_request_fails_loudly(G, device):
+def test_standalone_probabilities_are_forward_only(G, device):
+    """Gradients flow through GradJune / Runner (row f3); the stand-alone InfectionNetworks call, which
+    returns probabilities only, says so instead of silently dropping them."""
     d = conftest_world(G, device)
     nets = nets_of(G, device, company=torch.nn.Parameter(torch.tensor(0.5)))
     with pytest.raises(NotImplementedError, match="forward-only"):
         nets(data=d, timer=day_timer(G, ["company"]), policies=G.Policies())
+
+
+def test_run_model_script_flow_with_gradients(G, device):
+    """example_scripts/run_model.py:5-11 and test_model.py:34-53: household log_beta as nn.Parameter,
+    run, cases_per_timestep.sum().backward() -> a finite, non-zero gradient."""
+    torch.manual_seed(5)
+    runner = G.Runner.from_parameters(params_on(device, days=8))
+    for key in ("household", "company"):
+        net = runner.model.infection_networks.networks[key]
+        net.log_beta = torch.nn.Parameter(net.log_beta)
+    results, is_infected = runner()
+    assert results["cases_per_timestep"].requires_grad and results["cases_by_age_65"].requires_grad
+    cases = results["cases_per_timestep"].sum()
+    cases.backward()
+    for key in ("household", "company"):
+        g = runner.model.infection_networks.networks[key].log_beta.grad
+        assert g is not None and torch.isfinite(g) and g != 0
+    # the forward values are those of the kernel reductions
+    assert results["cases_per_timestep"][-1].item() == pytest.approx(is_infected.sum().item())
 
 
 def params_on(device, days=15):
