@@ -117,3 +117,37 @@ def test_fullsize_properties(device, preset, agents):
         assert ((z1 - z0).abs().numpy()[bad] < 1e-3).all()
     assert bad.sum() <= 1e-5 * A
     assert abs(int(dt.sum()) - int(dc.sum())) <= bad.sum()
+
+
+def test_c2_full_size_against_the_oracle(device):
+    """BASELINE.json configs[1] at full size (1 M agents, household/school/company, 15 M edges): one
+    whole step on the GPU against the CPU oracle on identical injected noise - per-agent probabilities
+    within 1e-5, infection decisions identical away from Gumbel ties, equal infection counts."""
+    import gj_oracle as O
+
+    world = make_world("c2", seed=1234, infected_fraction=0.02)
+    A = world["n_agents"]
+    specs, betas = B.network_specs(world), B.betas_of(world)
+    noise = O.draw_exp_noise(A, generator=torch.Generator().manual_seed(7))
+    w = {"n_agents": A, "age": torch.from_numpy(world["age"]), "sex": torch.from_numpy(world["sex"]),
+         "edge_sets": {k: {kk: torch.from_numpy(vv) for kk, vv in v.items()} for k, v in world["edge_sets"].items()}}
+    st = {k: torch.from_numpy(v.copy()) for k, v in world["state"].items()}
+    torch.set_num_threads(16)
+    ref = O.hot_path_step(w, st, now=1.0, delta_time=1.0, day_type=0, active=world["networks"], betas=betas,
+                          quarantine_thresholds=None, exp_noise=noise)
+    for layout in ("tiled", "csr"):
+        r = SingleGpuHotPath(world, specs, betas, device, seed=0, layout=layout, exp_noise=noise.to(device))
+        r.step()
+        torch.cuda.synchronize()
+        p = r.probs.cpu().numpy()
+        assert np.abs(p - ref["not_infected_probs"].numpy()).max() <= 1e-5, layout
+        dec, dref = r.new_infected.cpu().numpy() > 0.5, ref["new_infected"].numpy() > 0.5
+        bad = dec != dref
+        if bad.any():
+            pr = ref["not_infected_probs"]
+            margin = (((1 - pr).log() - noise[1].log()) / 0.1 - (pr.log() - noise[0].log()) / 0.1).abs().numpy()
+            assert (margin[bad] < 1e-3).all(), layout
+        assert bad.sum() <= 3, layout
+        assert abs(int(dec.sum()) - int(dref.sum())) <= bad.sum()
+        assert dref.sum() > 1000
+        assert np.allclose(r.state["transmission"].cpu().numpy(), ref["transmission"].numpy(), rtol=2e-5, atol=1e-9)
