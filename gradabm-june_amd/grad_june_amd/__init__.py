@@ -1,12 +1,13 @@
 """grad_june_amd - MI355X-native infection message-passing path behind GradABM-JUNE's Python API.
 
 Exports the reference package's names (grad_june/__init__.py:1-9) so that
-``import grad_june_amd as grad_june`` is the switch for the hot path.  ``GraphLoader`` /
-``AgentDataLoader`` (offline HDF5 -> graph build) are out of scope; worlds pickled by the
-reference load through :func:`grad_june_amd.graph.load_world`.
+``import grad_june_amd as grad_june`` is the switch.  Worlds pickled by the reference load through
+:func:`grad_june_amd.graph.load_world`; ``GraphLoader`` / ``AgentDataLoader`` build them from a JUNE
+HDF5 file (vectorised; needs ``h5py`` for ``.h5`` input).
 """
 from .graph import HeteroData, ToUndirected, load_world, save_world  # noqa: F401
 from .infection import IsInfectedSampler  # noqa: F401
+from .june_world_loader import AgentDataLoader, GraphLoader  # noqa: F401
 from .infection_networks import InfectionNetworks  # noqa: F401
 from .model import GradJune  # noqa: F401
 from .policies import Policies  # noqa: F401
