@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--sv-max", type=int, default=None)
     ap.add_argument("--eb-target", type=int, default=None)
     ap.add_argument("--slice-agents", type=int, default=None, help="tiled: agents per slice (multiple of 64)")
+    ap.add_argument("--reorder", default="none", choices=["none", "household"],
+                    help="graph-compile-time agent renumbering for locality (results map back through original_id)")
     ap.add_argument("--edge-mult", type=float, default=1.0, help="experiments: memberships per agent x this")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: diagnostic runs with several ranks sharing one GPU (collectives staged through the host)")
@@ -192,6 +194,10 @@ def main():
     t0 = time.time()
     world = make_world(args.preset, n_agents=args.agents, seed=args.seed, infected_fraction=args.infected,
                        edge_mult=args.edge_mult)
+    if args.reorder != "none":
+        from grad_june_amd.synthetic import reorder_agents
+
+        world = reorder_agents(world, by=args.reorder)
     networks = world["networks"]
     betas = betas_of(world)
     specs = network_specs(world)
