@@ -43,8 +43,9 @@ def parse():
     ap.add_argument("--sv-max", type=int, default=None)
     ap.add_argument("--eb-target", type=int, default=None)
     ap.add_argument("--slice-agents", type=int, default=None, help="tiled: agents per slice (multiple of 64)")
-    ap.add_argument("--reorder", default="none", choices=["none", "household"],
-                    help="graph-compile-time agent renumbering for locality (results map back through original_id)")
+    ap.add_argument("--reorder", default="auto", choices=["auto", "none", "household"],
+                    help="graph-compile-time agent renumbering for locality (results map back through original_id); "
+                         "auto = household-major when the world is partitioned over several GPUs (halves the halo)")
     ap.add_argument("--edge-mult", type=float, default=1.0, help="experiments: memberships per agent x this")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: diagnostic runs with several ranks sharing one GPU (collectives staged through the host)")
@@ -194,10 +195,11 @@ def main():
     t0 = time.time()
     world = make_world(args.preset, n_agents=args.agents, seed=args.seed, infected_fraction=args.infected,
                        edge_mult=args.edge_mult)
-    if args.reorder != "none":
+    reorder = args.reorder if args.reorder != "auto" else ("household" if world_size > 1 else "none")
+    if reorder != "none":
         from grad_june_amd.synthetic import reorder_agents
 
-        world = reorder_agents(world, by=args.reorder)
+        world = reorder_agents(world, by=reorder)
     networks = world["networks"]
     betas = betas_of(world)
     specs = network_specs(world)
@@ -304,7 +306,7 @@ def main():
                                f"{len(world['edge_sets'])} edge sets, {n_edges} network-edges, seed {args.seed}, "
                                f"{args.infected:.0%} infected, Philox noise",
                    "preset": args.preset, "n_agents": world["n_agents"], "network_edges": n_edges,
-                   "parallelism": f"agents partitioned over {world_size} GPU(s)"},
+                   "parallelism": f"agents partitioned over {world_size} GPU(s)", "agent_order": reorder},
         "edges_per_s": sps * n_edges,
         "algorithmic_bytes_per_step": b_step,
         "step_roofline_frac": b_step * sps / (HBM_PEAK_GBS * 1e9 * world_size),
