@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--reorder", default="auto", choices=["auto", "none", "household"],
                     help="graph-compile-time agent renumbering for locality (results map back through original_id); "
                          "auto = household-major when the world is partitioned over several GPUs (halves the halo)")
+    ap.add_argument("--quarantine", type=float, default=None,
+                    help="second configuration of SURVEY 8d: an active quarantine policy with this stage threshold")
     ap.add_argument("--edge-mult", type=float, default=1.0, help="experiments: memberships per agent x this")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: diagnostic runs with several ranks sharing one GPU (collectives staged through the host)")
@@ -229,7 +231,8 @@ def main():
             if args.slice_agents:
                 sa = args.slice_agents
                 kw["slices"] = (-(-world["n_agents"] // sa), sa)
-        runner = SingleGpuHotPath(world, specs, betas, dev, seed=args.seed, layout=args.layout, **kw)
+        runner = SingleGpuHotPath(world, specs, betas, dev, seed=args.seed, layout=args.layout,
+                                  quarantine_threshold=args.quarantine, **kw)
         extra = {}
     t_setup = time.time() - t0
 
@@ -304,7 +307,8 @@ def main():
         "layout": args.layout,
         "config": {"workload": f"{args.preset}: {world['n_agents']} agents, {len(networks)} infection networks on "
                                f"{len(world['edge_sets'])} edge sets, {n_edges} network-edges, seed {args.seed}, "
-                               f"{args.infected:.0%} infected, Philox noise",
+                               f"{args.infected:.0%} infected, Philox noise"
+                               + (f", quarantine below stage {args.quarantine:g}" if args.quarantine else ""),
                    "preset": args.preset, "n_agents": world["n_agents"], "network_edges": n_edges,
                    "parallelism": f"agents partitioned over {world_size} GPU(s)", "agent_order": reorder},
         "edges_per_s": sps * n_edges,
