@@ -195,8 +195,13 @@ def main():
     from grad_june_amd.synthetic import make_world, algorithmic_bytes, network_edges
 
     t0 = time.time()
+
+    def progress(msg):      # long set-ups keep writing: a silent command is taken for hung on the GPU pool
+        if rank == 0:
+            print(f"[bench {time.time() - t0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
     world = make_world(args.preset, n_agents=args.agents, seed=args.seed, infected_fraction=args.infected,
-                       edge_mult=args.edge_mult)
+                       edge_mult=args.edge_mult, progress=progress)
     reorder = args.reorder if args.reorder != "auto" else ("household" if world_size > 1 else "none")
     if reorder != "none":
         from grad_june_amd.synthetic import reorder_agents
@@ -232,7 +237,7 @@ def main():
                 sa = args.slice_agents
                 kw["slices"] = (-(-world["n_agents"] // sa), sa)
         runner = SingleGpuHotPath(world, specs, betas, dev, seed=args.seed, layout=args.layout,
-                                  quarantine_threshold=args.quarantine, **kw)
+                                  quarantine_threshold=args.quarantine, progress=progress, **kw)
         extra = {}
     t_setup = time.time() - t0
 

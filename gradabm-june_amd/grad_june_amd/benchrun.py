@@ -48,11 +48,12 @@ class SingleGpuHotPath:
               "tiled": ((0, "transmission"), (1, "tile_scatter"), (2, "tile_venues"), (3, "tile_agents"))}
 
     def __init__(self, world: dict, specs: Sequence[NetworkSpec], betas: Dict[str, float], device,
-                 seed: int = 0, quarantine_threshold=None, exp_noise=None, layout: str = "tiled", **plan_kw):
+                 seed: int = 0, quarantine_threshold=None, exp_noise=None, layout: str = "tiled", progress=None,
+                 **plan_kw):
         self.device = torch.device(device)
         self.layout = layout
         host = compile_plan(world["n_agents"], world["edge_sets"], age=world["age"], sex=world["sex"],
-                            layout=layout, **plan_kw)
+                            layout=layout, progress=progress, **plan_kw)
         self.engine = InfectionEngine(DevicePlan(host, specs, self.device))
         self.networks = list(world["networks"])
         self.betas = betas

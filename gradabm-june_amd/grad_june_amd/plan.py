@@ -226,7 +226,7 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
                  n_ext_agents: Optional[int] = None, block_order: str = "interleave",
                  layout: str = "csr", leisure_sets: Sequence[str] = ("leisure",),
                  sv_max: int = TL.SV_MAX, eb_target: int = TL.EB_TARGET, slices=None,
-                 nets_per_set: Optional[Dict[str, int]] = None) -> HostPlan:
+                 nets_per_set: Optional[Dict[str, int]] = None, progress=None) -> HostPlan:
     """edge_sets: {name: {"agent": i64[E], "venue": i64[E], "people": [V]}} (insertion order = set ids).
 
     layout: "csr" (deterministic CSR kernels), "tiled" (LDS-tiled fast path) or "both".
@@ -256,6 +256,8 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
             t = hs.tiled
             for j in range(t.n_blocks):
                 work.append((int(t.blk_e0[j + 1] - t.blk_e0[j]) + int(t.blk_v0[j + 1] - t.blk_v0[j]), sid, j))
+        if progress:
+            progress(f"compiled edge set {name}")
         if not want_csr:
             continue
         b, lr, ns = build_schedule(hs.v_rowptr, sid, slot)

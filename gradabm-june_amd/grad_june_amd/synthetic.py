@@ -104,7 +104,7 @@ def _edge_set(rng, n_agents: int, n_edges: int, dist) -> dict:
 
 
 def make_world(preset: str = "c3", n_agents: Optional[int] = None, seed: int = 1234,
-               infected_fraction: float = 0.01, sets=None, edge_mult: float = 1.0) -> Dict:
+               infected_fraction: float = 0.01, sets=None, edge_mult: float = 1.0, progress=None) -> Dict:
     """Returns {"n_agents", "age", "sex", "edge_sets", "networks", "state"} as numpy arrays."""
     spec = PRESETS[preset]
     if n_agents is None:
@@ -123,6 +123,8 @@ def make_world(preset: str = "c3", n_agents: Optional[int] = None, seed: int = 1
         if sets is not None and name not in sets:
             continue
         world["edge_sets"][name] = _edge_set(rng, A, int(round(per_agent * edge_mult * A)), dist)
+        if progress:
+            progress(f"generated edge set {name}: {len(world['edge_sets'][name]['agent'])} edges")
     inf = (rng.random(A) < infected_fraction).astype(np.float32)
     world["state"] = {
         "max_infectiousness": rng.lognormal(0.0, 0.5, A).astype(np.float32),
