@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--reorder", default="auto", choices=["auto", "none", "household"],
                     help="graph-compile-time agent renumbering for locality (results map back through original_id); "
                          "auto = household-major when the world is partitioned over several GPUs (halves the halo)")
+    ap.add_argument("--parts", type=int, default=0,
+                    help="one GPU: step the world as this many agent partitions in turn (0 = auto: one per 16 M "
+                         "agents, so that tiles keep a useful size)")
     ap.add_argument("--quarantine", type=float, default=None,
                     help="second configuration of SURVEY 8d: an active quarantine policy with this stage threshold")
     ap.add_argument("--edge-mult", type=float, default=1.0, help="experiments: memberships per agent x this")
@@ -236,9 +239,16 @@ def main():
             if args.slice_agents:
                 sa = args.slice_agents
                 kw["slices"] = (-(-world["n_agents"] // sa), sa)
-        runner = SingleGpuHotPath(world, specs, betas, dev, seed=args.seed, layout=args.layout,
-                                  quarantine_threshold=args.quarantine, progress=progress, **kw)
-        extra = {}
+        parts = args.parts if args.parts > 0 else max(1, -(-world["n_agents"] // 16_000_000))
+        if parts > 1 and args.layout == "tiled":
+            from grad_june_amd.distributed import PartitionedHotPath
+
+            runner = PartitionedHotPath(world, specs, betas, dev, parts, seed=args.seed, progress=progress)
+            extra = {"partitions_on_one_gpu": parts}
+        else:
+            runner = SingleGpuHotPath(world, specs, betas, dev, seed=args.seed, layout=args.layout,
+                                      quarantine_threshold=args.quarantine, progress=progress, **kw)
+            extra = {}
     t_setup = time.time() - t0
 
     def sync():

@@ -315,3 +315,73 @@ class DistributedHotPath:
 
     def kernel_ms(self) -> Dict[str, float]:
         return {k: float(np.mean(v)) for k, v in self.log.spans().items()}
+
+
+class PartitionedHotPath:
+    """Several agent partitions stepped one after the other on ONE GPU - for worlds whose tiles would
+    become too small as a single partition (edges per tile fall like 1/size: 10^8 agents on one device
+    leave ~25 edges per tile).  Each partition is exactly a rank of the multi-GPU path with its own
+    compiled plan; the two collectives become device-side copies / sums between the partitions' buffers.
+    Results are identical to the unpartitioned run (fixed-point sums, Philox keyed by global agent id)."""
+
+    def __init__(self, world: dict, specs, betas: Dict[str, float], device, parts: int, seed: int = 0,
+                 progress=None):
+        from .benchrun import EventLog
+
+        self.device = torch.device(device)
+        self.parts = parts
+        self.ranks: List[DistributedHotPath] = []
+        for r in range(parts):
+            self.ranks.append(DistributedHotPath(world, specs, betas, device, r, parts, seed=seed, collectives=False))
+            if progress:
+                progress(f"compiled partition {r + 1}/{parts}")
+        self.halo_index = [torch.from_numpy(rk.rw.halo_global).to(self.device) for rk in self.ranks]
+        self.log = EventLog()
+        self.new_infected = None
+        self.probs = None
+
+    @property
+    def state(self):
+        return {k: torch.cat([rk.state[k][: rk.rw.n_local] for rk in self.ranks]) for k in
+                ("is_infected", "susceptibility", "infection_time")}
+
+    def step(self, timed: bool = False):
+        mark = self.log.mark if timed else (lambda label: None)
+        ranks = self.ranks
+        mark("begin")
+        ps = [rk.params() for rk in ranks]
+        for rk, p in zip(ranks, ps):
+            rk.engine.step_phase(rk.bufs, p, rk.io, 0)
+        mark("transmission")
+        if any(len(h) for h in self.halo_index):
+            glob = torch.cat([rk.state["transmission"][: rk.rw.n_local] for rk in ranks])
+            for rk, idx in zip(ranks, self.halo_index):
+                if len(idx):
+                    rk.state["transmission"][rk.rw.n_local_pad:rk.rw.n_local_pad + rk.rw.n_halo] = glob[idx]
+        mark("halo_copy")
+        for rk, p in zip(ranks, ps):
+            rk.engine.step_phase(rk.bufs, p, rk.io, 1)
+        mark("tile_scatter")
+        for rk, p in zip(ranks, ps):
+            rk.engine.step_phase(rk.bufs, p, rk.io, 5)
+        mark("tile_venues_B")
+        if ranks[0].flat_cum is not None and ranks[0].flat_cum.numel():
+            total = ranks[0].flat_cum.clone()
+            for rk in ranks[1:]:
+                total += rk.flat_cum
+            for rk in ranks:
+                rk.flat_cum.copy_(total)
+        mark("partial_sum")
+        for rk, p in zip(ranks, ps):
+            rk.engine.step_phase(rk.bufs, p, rk.io, 6)
+        mark("tile_venues_C")
+        for rk, p in zip(ranks, ps):
+            rk.engine.step_phase(rk.bufs, p, rk.io, 3)
+            rk.t += 1
+        mark("tile_agents")
+
+    def reset_timers(self):
+        self.log.clear()
+
+    def kernel_ms(self) -> Dict[str, float]:
+        return {k: float(np.mean(v)) for k, v in self.log.spans().items()}

@@ -108,3 +108,20 @@ def test_two_processes_gloo_match_single_rank(device):
     out = mp.get_context("spawn").Array("i", [0])
     mp.spawn(_two_rank_worker, args=(R, 29600 + os.getpid() % 300, out), nprocs=R, join=True)
     assert out[0] == 1
+
+
+def test_partitioned_on_one_gpu_matches_unpartitioned(device):
+    """PartitionedHotPath (the >16 M-agent single-GPU mode) == the unpartitioned run, bit for bit."""
+    from grad_june_amd.distributed import PartitionedHotPath
+
+    world = make_world("c5", n_agents=60_000, seed=8, infected_fraction=0.05)
+    specs, betas = B.network_specs(world), B.betas_of(world)
+    single = SingleGpuHotPath(world, specs, betas, device, seed=5, layout="tiled")
+    parted = PartitionedHotPath(world, specs, betas, device, parts=3, seed=5)
+    for _ in range(3):
+        single.step()
+        parted.step()
+    torch.cuda.synchronize()
+    for k, v in parted.state.items():
+        assert torch.equal(v, single.state[k]), k
+    assert single.state["is_infected"].sum() > 0.05 * 60_000
