@@ -47,8 +47,8 @@ def parse():
                     help="graph-compile-time agent renumbering for locality (results map back through original_id); "
                          "auto = household-major when the world is partitioned over several GPUs (halves the halo)")
     ap.add_argument("--parts", type=int, default=0,
-                    help="one GPU: step the world as this many agent partitions in turn (0 = auto: one per 16 M "
-                         "agents, so that tiles keep a useful size)")
+                    help="one GPU: step the world as this many agent partitions in turn (0 = auto: partitions of "
+                         "~16 M agents once the world exceeds 48 M, where single-partition tiles get too small)")
     ap.add_argument("--quarantine", type=float, default=None,
                     help="second configuration of SURVEY 8d: an active quarantine policy with this stage threshold")
     ap.add_argument("--edge-mult", type=float, default=1.0, help="experiments: memberships per agent x this")
@@ -239,7 +239,8 @@ def main():
             if args.slice_agents:
                 sa = args.slice_agents
                 kw["slices"] = (-(-world["n_agents"] // sa), sa)
-        parts = args.parts if args.parts > 0 else max(1, -(-world["n_agents"] // 16_000_000))
+        parts = args.parts if args.parts > 0 else (1 if world["n_agents"] <= 48_000_000
+                                                   else -(-world["n_agents"] // 16_000_000))
         if parts > 1 and args.layout == "tiled":
             from grad_june_amd.distributed import PartitionedHotPath
 
