@@ -139,3 +139,25 @@ def test_gloo_world_size_2_collectives():
     port = 29500 + (os.getpid() % 400)
     mp.spawn(_gloo_worker, args=(R, port, ok), nprocs=R, join=True)
     assert list(ok) == [1] * R
+
+
+def test_reorder_agents_is_a_pure_renumbering_and_shrinks_the_halo():
+    from grad_june_amd.synthetic import reorder_agents
+
+    world = small_world(20_000, seed=3)
+    re = reorder_agents(world, by="household")
+    oid = re["original_id"]
+    assert np.array_equal(np.sort(oid), np.arange(20_000))
+    for k, es in world["edge_sets"].items():       # same edge multiset through the id map
+        a = np.sort(oid[re["edge_sets"][k]["agent"]] * 10**7 + re["edge_sets"][k]["venue"])
+        b = np.sort(es["agent"] * 10**7 + es["venue"])
+        assert np.array_equal(a, b), k
+    for k in world["state"]:
+        assert np.array_equal(re["state"][k], world["state"][k][oid])
+    # members of a household are consecutive: the first-household key is non-decreasing
+    first = np.full(20_000, 10**12)
+    np.minimum.at(first, re["edge_sets"]["household"]["agent"], re["edge_sets"]["household"]["venue"])
+    assert (np.diff(first[first < 10**12]) >= 0).all()
+    h0 = build_rank_world(world, 1, 4).n_halo
+    h1 = build_rank_world(re, 1, 4).n_halo
+    assert h1 < 0.7 * h0
