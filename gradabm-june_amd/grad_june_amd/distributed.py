@@ -19,7 +19,7 @@ Sampling noise is Philox keyed by the GLOBAL agent id, so results do not depend 
 """
 from __future__ import annotations
 
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -205,8 +205,6 @@ class DistributedHotPath:
 
     def __init__(self, world: dict, specs, betas: Dict[str, float], device, rank: int, world_size: int,
                  seed: int = 0, group=None, modes: Optional[Dict[str, str]] = None, collectives: bool = True):
-        import ctypes as C
-
         from . import _native as N
         from .benchrun import EventLog
         from .engine import AgentBuffers, InfectionEngine

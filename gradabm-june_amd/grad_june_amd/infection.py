@@ -16,8 +16,6 @@ _philox_step = itertools.count(1 << 40)   # sampler calls outside GradJune.forwa
 
 
 def _launch_sample(p, exp_noise, new_inf, now=0.0, state=(None, None, None), seed=None, step=None):
-    import ctypes as C
-
     lib = N.load()
     if seed is None:
         seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF

@@ -12,7 +12,7 @@ import torch
 import yaml
 
 from .infection import IsInfectedSampler
-from .infection_networks import InfectionNetworks, _check_no_grad
+from .infection_networks import InfectionNetworks
 from .policies import Policies
 from .symptoms import SymptomsUpdater
 from .transmission import TransmissionUpdater

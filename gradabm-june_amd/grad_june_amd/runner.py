@@ -8,7 +8,6 @@ hot path of each step is ``GradJune.hot_path`` (HIP kernels).  The per-step resu
 """
 from __future__ import annotations
 
-import pickle
 from pathlib import Path
 
 import numpy as np

@@ -23,7 +23,7 @@ the four phases (tests/test_tiling_host.py).
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import List, Optional
+from typing import Optional
 
 import numpy as np
 

@@ -46,9 +46,7 @@ class TransmissionUpdater(torch.nn.Module):
         """transmission[a] at ``timer.now`` - a NEW tensor, like the reference returns."""
         ag = data["agent"]
         device = require_hip(ag["is_infected"].device)
-        from .plan import NetworkSpec  # the transmission kernel needs no edge set: an empty plan does
-
-        engine = engine_for(data, [], device)
+        engine = engine_for(data, [], device)      # the transmission kernel needs no edge set
         out = torch.empty(engine.plan.host.n_agents, dtype=torch.float32, device=device)
         bufs = agent_buffers(engine, data, need_params=True, need_stage=False)
         bufs.tensors["transmission"] = out

@@ -8,7 +8,7 @@ object every timestep - exactly how the reference's Runner drives them (runner.p
 from __future__ import annotations
 
 import weakref
-from typing import Dict, Optional, Sequence, Tuple
+from typing import Dict, Sequence, Tuple
 
 import numpy as np
 import torch

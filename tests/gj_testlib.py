@@ -1,7 +1,6 @@
 """Shared helpers for the test-suite: golden fixture access and engine construction."""
 from __future__ import annotations
 
-import json
 import math
 import os
 from typing import Dict, Optional

@@ -2,7 +2,6 @@
 (gloo, world_size 2) - the multi-GPU path minus the kernels, which are stood in by the tiled
 layout's numpy emulation (tiling.emulate_pass1/2, itself pinned against bincount sums)."""
 import os
-import sys
 
 import numpy as np
 import pytest

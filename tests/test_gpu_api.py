@@ -8,7 +8,6 @@ import pytest
 import torch
 
 import gj_oracle as O
-import gj_testlib as L
 
 pytestmark = pytest.mark.gpu
 

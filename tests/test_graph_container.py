@@ -60,12 +60,6 @@ def test_unpickles_pyg_class_paths():
     raw = pickle.dumps(d, protocol=4)
     raw = raw.replace(b"grad_june_amd.graph", b"torch_geometric.data.hetero_data", 1)
     assert b"torch_geometric" in raw
-    # storages are looked up under torch_geometric.data.storage in real files; map both
-    import pickletools  # noqa: F401
-
-    class Rename(pickle.Unpickler):
-        pass
-
     e = load_world(io.BytesIO(pickle.dumps(d, protocol=4)))
     assert e["agent"].id.shape[0] == 6
     from grad_june_amd.graph import _WorldUnpickler

@@ -3,7 +3,6 @@ that decides what the kernels are launched with.  Checked against what the REFER
 recorded step of the golden trajectories (now, dt, day type, active order, beta, thresholds)."""
 import datetime
 import json
-import math
 
 import numpy as np
 import pytest
@@ -12,7 +11,7 @@ import torch
 import gj_testlib as L
 from grad_june_amd import _native as N
 from grad_june_amd.defaults import default_parameters
-from grad_june_amd.infection_networks import InfectionNetworks, LeisureNetwork, SchoolNetwork
+from grad_june_amd.infection_networks import InfectionNetworks, SchoolNetwork
 from grad_june_amd.policies import CloseVenue, Policies, Quarantine, SocialDistancing
 from grad_june_amd.timer import Timer
 from grad_june_amd.utils import parse_age_probabilities, read_date
