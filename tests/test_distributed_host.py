@@ -25,7 +25,8 @@ def reference_pass(world, x):
     """Global single-rank result per set: cum[v] (beta = 1) and per-agent sum of cum over its venues."""
     out = {}
     for name, es in world["edge_sets"].items():
-        pc = np.clip(1.0 / (es["people"].astype(np.float64) - 1), None, 1.0).clip(0.0)
+        with np.errstate(divide="ignore"):
+            pc = np.clip(1.0 / (es["people"].astype(np.float64) - 1), None, 1.0).clip(0.0)
         V = len(es["people"])
         cum = pc * np.bincount(es["venue"], weights=x[es["agent"]].astype(np.float64), minlength=V)
         acc = np.bincount(es["agent"], weights=cum[es["venue"]], minlength=world["n_agents"])

@@ -125,3 +125,22 @@ def test_partitioned_on_one_gpu_matches_unpartitioned(device):
     for k, v in parted.state.items():
         assert torch.equal(v, single.state[k]), k
     assert single.state["is_infected"].sum() > 0.05 * 60_000
+
+
+def test_pack_unpack_kernels(device):
+    """gj_pack_f32 / gj_unpack_f32 (halo send / receive buffers)."""
+    from grad_june_amd import _native as N
+
+    lib = N.load()
+    torch.manual_seed(0)
+    src = torch.rand(100_000, device=device)
+    idx = torch.randperm(100_000, device=device)[:37_001].to(torch.int32)
+    out = torch.empty(idx.numel(), device=device)
+    N.check(lib.gj_pack_f32(idx.numel(), N.ptr(idx), N.ptr(src), N.ptr(out), N.current_stream()), "gj_pack_f32")
+    assert torch.equal(out, src[idx.long()])
+    dst = torch.zeros(100_000, device=device)
+    N.check(lib.gj_unpack_f32(idx.numel(), N.ptr(idx), N.ptr(out), N.ptr(dst), N.current_stream()), "gj_unpack_f32")
+    ref = torch.zeros(100_000, device=device)
+    ref[idx.long()] = out
+    assert torch.equal(dst, ref)
+    assert lib.gj_pack_f32(0, None, None, None, None) == 0 and lib.gj_pack_f32(5, None, None, None, None) == -1
