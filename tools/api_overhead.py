@@ -85,3 +85,40 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def backward_cost(n=2_000_000, steps=8):
+    """Row f3: cost of a differentiable run (forward in grad mode + backward) per timestep."""
+    dev = "cuda:0"
+    world = make_world("c3", n_agents=n)
+    d = hetero_from(world, dev)
+    pp = default_parameters(dev)
+    pp["timer"]["step_activities"]["weekday"][0] = list(world["networks"])
+    pp["timer"]["step_activities"]["weekend"][0] = list(world["networks"])
+    pp["networks"] = {k: v for k, v in pp["networks"].items() if k in world["networks"]}
+    pp["timer"]["total_days"] = 400
+    model = G.GradJune.from_parameters(pp)
+    timer = G.Timer.from_parameters(pp)
+    for net in model.infection_networks.networks.values():
+        net.log_beta = torch.nn.Parameter(net.log_beta)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    series = []
+    for _ in range(steps):
+        next(timer)
+        model(d, timer)
+        series.append(d["agent"].is_infected.sum())
+    torch.cuda.synchronize()
+    tf = (time.perf_counter() - t0) / steps
+    loss = torch.stack(series).sum()
+    t0 = time.perf_counter()
+    loss.backward()
+    torch.cuda.synchronize()
+    tb = (time.perf_counter() - t0) / steps
+    grads = {k: float(v.log_beta.grad) for k, v in model.infection_networks.networks.items()}
+    print("differentiable run, %d agents: forward %.3f ms/step, backward %.3f ms/step; d cases/d log_beta = %s"
+          % (n, tf * 1e3, tb * 1e3, {k: round(v, 1) for k, v in grads.items()}))
+
+
+if __name__ == "__main__" and "--backward" in sys.argv:
+    backward_cost()
