@@ -74,7 +74,7 @@ class RankWorld:
 
 
 def build_rank_world(world: dict, rank: int, world_size: int, modes: Optional[Dict[str, str]] = None,
-                     slice_agents: Optional[int] = None) -> RankWorld:
+                     slice_agents: Optional[int] = None, progress=None) -> RankWorld:
     A = world["n_agents"]
     bounds = partition_bounds(A, world_size)
     a0, a1 = int(bounds[rank]), int(bounds[rank + 1])
@@ -100,6 +100,8 @@ def build_rank_world(world: dict, rank: int, world_size: int, modes: Optional[Di
             venue_global[name] = vg
             remote = agent[keep & ~mine]
             halo_lists.append(np.unique(remote))
+        if progress:
+            progress(f"rank {rank}: partitioned edge set {name} ({modes[name]})")
     halo_global = np.unique(np.concatenate(halo_lists)) if halo_lists else np.zeros(0, dtype=np.int64)
     owner = np.searchsorted(bounds, halo_global, side="right") - 1
     halo_from = np.bincount(owner, minlength=world_size).astype(np.int64)   # sorted ids => grouped by owner
@@ -204,7 +206,8 @@ class DistributedHotPath:
     """bench.py's stepping object for N > 1: compile this rank's part, step with the two collectives."""
 
     def __init__(self, world: dict, specs, betas: Dict[str, float], device, rank: int, world_size: int,
-                 seed: int = 0, group=None, modes: Optional[Dict[str, str]] = None, collectives: bool = True):
+                 seed: int = 0, group=None, modes: Optional[Dict[str, str]] = None, collectives: bool = True,
+                 progress=None):
         from . import _native as N
         from .benchrun import EventLog
         from .engine import AgentBuffers, InfectionEngine
@@ -212,9 +215,9 @@ class DistributedHotPath:
 
         self.device = torch.device(device)
         self.rank, self.world_size, self.group = rank, world_size, group
-        rw = self.rw = build_rank_world(world, rank, world_size, modes)
+        rw = self.rw = build_rank_world(world, rank, world_size, modes, progress=progress)
         host = compile_plan(rw.n_local, rw.edge_sets, age=rw.age, sex=rw.sex, n_ext_agents=rw.n_ext,
-                            layout="tiled", slices=(rw.n_slices, rw.slice_agents))
+                            layout="tiled", slices=(rw.n_slices, rw.slice_agents), progress=progress)
         partial = [n for n in rw.edge_sets if rw.modes[n] == "partial"]
         self.engine = InfectionEngine(DevicePlan(host, specs, self.device, flat_cum_sets=partial))
         self.flat_cum = self.engine.plan.flat_cum
@@ -330,7 +333,8 @@ class PartitionedHotPath:
         self.parts = parts
         self.ranks: List[DistributedHotPath] = []
         for r in range(parts):
-            self.ranks.append(DistributedHotPath(world, specs, betas, device, r, parts, seed=seed, collectives=False))
+            self.ranks.append(DistributedHotPath(world, specs, betas, device, r, parts, seed=seed, collectives=False,
+                                                 progress=progress))
             if progress:
                 progress(f"compiled partition {r + 1}/{parts}")
         self.halo_index = [torch.from_numpy(rk.rw.halo_global).to(self.device) for rk in self.ranks]
