@@ -101,6 +101,16 @@ def backward_cost(n=2_000_000, steps=8):
     timer = G.Timer.from_parameters(pp)
     for net in model.infection_networks.networks.values():
         net.log_beta = torch.nn.Parameter(net.log_beta)
+    warm = []
+    for _ in range(3):            # warm-up: plan compile, first launches of the adjoint kernels
+        next(timer)
+        model(d, timer)
+        warm.append(d["agent"].is_infected.sum())
+    torch.stack(warm).sum().backward()
+    for k in ("susceptibility", "is_infected", "infection_time"):
+        d["agent"][k] = d["agent"][k].detach()
+    for net in model.infection_networks.networks.values():
+        net.log_beta.grad = None
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     series = []
