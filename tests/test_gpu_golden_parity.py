@@ -205,3 +205,35 @@ def test_trajectory_chained_counts(device, name, layout):
         cases.append(float(st["is_infected"].sum().item()))
         assert np.array_equal(st["is_infected"].cpu().numpy(), rec["post/is_infected"]), f"step {i}"
     assert np.allclose(cases, npz["cases_per_timestep"])
+
+
+@pytest.mark.parametrize("layout", LAYOUTS, ids=LAYOUT_IDS)
+def test_no_active_network(device, layout):
+    """Every venue closed (close_venue_policies.py:11-22 can empty the list): trans_susc stays 0, the
+    reference's floor clamp(…, 1e-6) sets p = exp(-1e-6 * dt) for everyone (base.py:136-140)."""
+    from grad_june_amd.engine import AgentBuffers
+
+    npz = L.load_npz("c100.npz")
+    world = L.world_from(npz)
+    eng = engine_for(world, None, device, layout)
+    rec = L.step_record(npz, "plain_t3/")
+    st = L.device_state(L.pre_state(rec), device)
+    p = eng.params(now=3.0, delta_time=1.0, day_type=0, active=[], betas={})
+    bufs = AgentBuffers(eng.plan, max_infectiousness=st["max_infectiousness"], shape=st["shape"], rate=st["rate"],
+                        shift=st["shift"], infection_time=st["infection_time"], is_infected=st["is_infected"],
+                        susceptibility=st["susceptibility"], transmission=st["transmission"])
+    probs, new = torch.empty(100, device=device), torch.empty(100, device=device)
+    before = st["is_infected"].clone()
+    noise = torch.from_numpy(rec["exp_noise"]).to(device).contiguous()
+    eng.step(bufs, p, eng.io(not_infected_probs=probs, new_infected=new, exp_noise=noise))
+    torch.cuda.synchronize()
+    assert torch.allclose(probs, torch.full_like(probs, float(np.exp(np.float32(-1e-6)))))
+    expect = O_sample(probs.cpu(), noise.cpu())
+    assert torch.equal(new.cpu() > 0.5, expect > 0.5)
+    assert torch.equal(st["is_infected"], before + new)
+
+
+def O_sample(p, noise):
+    import gj_oracle as O
+
+    return O.sample_infected(p, noise)
