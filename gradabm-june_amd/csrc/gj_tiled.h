@@ -15,7 +15,7 @@ namespace gj {
 
 constexpr int kTileThreads = 1024;  // 16 waves: one workgroup per CU when the slice fills LDS
 constexpr int kTileWaves = kTileThreads / kWave;
-constexpr int kUnroll = 16;         // 64-edge chunks a wave keeps in flight (phases A and D)
+constexpr int kUnroll = 8;          // 64-edge chunks a wave keeps in flight (phases A and D)
 
 // LDS float atomics run at 0.33 lanes/clk/CU on gfx950 (measured, tools/microbench/lds_atomics.hip)
 // against 4.9 for ds_add_u64 and 7.3 for ds_add_u32, so the per-venue and per-agent sums are kept

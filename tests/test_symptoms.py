@@ -133,3 +133,55 @@ def test_kernel_agrees_with_torch_form(device):
         s = d["agent"].symptoms
         outs.append(((s["next_stage"] == 5).float().mean().item(), s["time_to_next_stage"].mean().item()))
     assert abs(outs[0][0] - outs[1][0]) < 0.01 and abs(outs[0][1] - outs[1][1]) / outs[1][1] < 0.03
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["june769.npz", "june769_hot.npz"])
+def test_full_timestep_chain_matches_reference(device, name):
+    """The whole GradJune timestep (hot path + symptoms kernel) carried forward for 15 steps on the GPU,
+    nothing teacher-forced: with the reference's randomness injected (sampler noise, bernoulli outcomes,
+    dwell-time samples) every state array equals the reference's after every step - including the
+    quarantine mask that the symptoms state feeds back into the hot path."""
+    import json
+
+    import grad_june_amd as G
+    from test_host_logic import _cpu
+
+    npz = L.load_npz(name)
+    world = L.world_from(npz)
+    params = _cpu(json.loads(str(npz["params_json"])))
+    params["system"]["device"] = str(device)
+    model = G.GradJune.from_parameters(params)
+    timer = G.Timer.from_parameters(params)
+    rec0 = L.step_record(npz, "step0/")
+    d = G.HeteroData()
+    ag = d["agent"]
+    A = world["n_agents"]
+    ag.id = torch.arange(A)
+    ag.age, ag.sex = world["age"], world["sex"]
+    for s, es in world["edge_sets"].items():
+        d[s].id = torch.arange(len(es["people"]))
+        d[s].people = es["people"]
+        d["agent", "attends_" + s, s].edge_index = torch.vstack((es["agent"], es["venue"]))
+    d = d.to(device)
+    pre = L.pre_state(rec0)
+    ag.infection_parameters = {k: pre[k].to(device) for k in ("max_infectiousness", "shape", "rate", "shift")}
+    for k in ("is_infected", "susceptibility", "infection_time"):
+        ag[k] = pre[k].to(device)
+    ag.transmission = torch.zeros(A, device=device)
+    ag.symptoms = {k[8:]: torch.from_numpy(v).to(device) for k, v in rec0.items() if k.startswith("sym_pre/")}
+    ag.symptoms["current_stage"] = torch.from_numpy(rec0["pre/current_stage"]).float().to(device)
+    with torch.no_grad():
+        for i in range(int(npz["n_steps"])):
+            rec = L.step_record(npz, f"step{i}/")
+            next(timer)
+            assert timer.now == float(rec["now"])
+            assert np.array_equal(ag.symptoms["current_stage"].cpu().numpy(), rec["pre/current_stage"].astype(np.float32)), i
+            new, _ = model.hot_path(d, timer, exp_noise=torch.from_numpy(rec["exp_noise"]))
+            for k in ("susceptibility", "is_infected", "infection_time"):
+                assert np.array_equal(ag[k].cpu().numpy(), rec["post/" + k]), (i, k)
+            model.symptoms_updater(d, timer, new, progresses=torch.from_numpy(rec["sym/progresses"]),
+                                   dwell=torch.from_numpy(rec["sym/dwell"]))
+            for k in ("current_stage", "next_stage", "time_to_next_stage"):
+                assert np.array_equal(ag.symptoms[k].cpu().numpy(), rec["sym_post/" + k]), (i, k)
+    assert float(ag.is_infected.sum()) == float(npz["cases_per_timestep"][-1])
