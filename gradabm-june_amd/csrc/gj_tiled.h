@@ -310,7 +310,38 @@ struct TileDArgs {
   int32_t has_q, sample;
   uint64_t seed, step;
   int64_t agent_offset;
+  float* acc_scratch;     // non-NULL: write the per-agent sums here and leave a7-a9 to k_tile_epilogue
 };
+
+// a7-a9 for one agent per lane, from the per-agent sums of phase D (split form)
+__global__ __launch_bounds__(256) void k_tile_epilogue(const TileDArgs D) {
+  const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= D.n_agents) return;
+  float susc = D.susceptibility[a];
+  float ts = susc * D.acc_scratch[a];
+  if (D.trans_susc) D.trans_susc[a] = ts;
+  ts = fminf(fmaxf(ts, 1e-6f), 100.0f);
+  float p = expf(-ts * D.dt);
+  p = fminf(fmaxf(p, 0.0f), 1.0f);
+  if (D.not_infected_probs) D.not_infected_probs[a] = p;
+  if (!D.sample) return;
+  float e0, e1;
+  if (D.exp_noise) {
+    e0 = D.exp_noise[a];
+    e1 = D.exp_noise[D.n_agents + a];
+  } else {
+    exp_pair(D.seed, D.step, D.agent_offset + a, e0, e1);
+  }
+  const float nw = gumbel_new_infected(p, e0, e1);
+  if (D.new_infected) D.new_infected[a] = nw;
+  if (nw != 0.0f) {
+    float inf = D.is_infected[a], t_inf = D.infection_time[a];
+    infect(nw, D.now, susc, inf, t_inf);
+    D.susceptibility[a] = susc;
+    D.is_infected[a] = inf;
+    D.infection_time[a] = t_inf;
+  }
+}
 
 __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D) {
   extern __shared__ __align__(16) fx_t lds_acc[];
@@ -372,6 +403,10 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
         if (!(D.stage[base + i] < D.q_thr)) lds_acc[i] = 0;
       __syncthreads();
     }
+  }
+  if (D.acc_scratch) {   // split form: hand the per-agent sums to k_tile_epilogue (runs at full occupancy)
+    for (int i = tid; i < n_local; i += kTileThreads) D.acc_scratch[base + i] = from_fx<kFxAgent>(lds_acc[i]);
+    return;
   }
   constexpr int kEp = 4;   // agents per lane whose loads are issued together
   for (int i0 = tid; i0 < n_local; i0 += kEp * kTileThreads) {

@@ -926,11 +926,15 @@ static int tiled_agents(const gj_plan* plan, const gj_agent_state* st, const gj_
   D.seed = p->seed;
   D.step = p->step;
   D.agent_offset = p->agent_offset;
+  D.acc_scratch = T->agent_scratch;
   const size_t lds = slice_lds(T, sizeof(fx_t));
   int rc = allow_lds(k_tile_agents, lds);
   if (rc) return rc;
   const int64_t owned_slices = (plan->n_agents + T->slice_agents - 1) / T->slice_agents;
   hipLaunchKernelGGL(k_tile_agents, dim3((unsigned)owned_slices), dim3(kTileThreads), lds, stream, D);
+  rc = launch_status();
+  if (rc || !D.acc_scratch) return rc;
+  hipLaunchKernelGGL(k_tile_epilogue, dim3((unsigned)((plan->n_agents + 255) / 256)), dim3(256), 0, stream, D);
   return launch_status();
 }
 

@@ -64,6 +64,7 @@ class Tiled(C.Structure):
         ("_pad", C.c_int32),
         ("n_work", C.c_int32),
         ("work", _vp),
+        ("agent_scratch", _vp),
         ("sets", TiledSet * GJ_MAX_SETS),
     ]
 

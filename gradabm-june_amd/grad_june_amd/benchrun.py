@@ -49,12 +49,12 @@ class SingleGpuHotPath:
 
     def __init__(self, world: dict, specs: Sequence[NetworkSpec], betas: Dict[str, float], device,
                  seed: int = 0, quarantine_threshold=None, exp_noise=None, layout: str = "tiled", progress=None,
-                 **plan_kw):
+                 split_epilogue: bool = False, **plan_kw):
         self.device = torch.device(device)
         self.layout = layout
         host = compile_plan(world["n_agents"], world["edge_sets"], age=world["age"], sex=world["sex"],
                             layout=layout, progress=progress, **plan_kw)
-        self.engine = InfectionEngine(DevicePlan(host, specs, self.device))
+        self.engine = InfectionEngine(DevicePlan(host, specs, self.device, split_epilogue=split_epilogue))
         self.networks = list(world["networks"])
         self.betas = betas
         self.seed = seed

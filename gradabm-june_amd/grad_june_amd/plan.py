@@ -287,7 +287,8 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
 class DevicePlan:
     """The plan resident in HBM + the ctypes ``gj_plan`` that points at it."""
 
-    def __init__(self, host: HostPlan, networks: Sequence[NetworkSpec], device, flat_cum_sets: Sequence[str] = ()):
+    def __init__(self, host: HostPlan, networks: Sequence[NetworkSpec], device, flat_cum_sets: Sequence[str] = (),
+                 split_epilogue: bool = False):
         """flat_cum_sets: edge sets whose ``cum`` workspaces are carved from ONE contiguous buffer
         (``self.flat_cum``) so that a single collective can combine them across ranks."""
         self.host = host
@@ -388,6 +389,9 @@ class DevicePlan:
             self.work = up(host.work.reshape(-1)) if len(host.work) else None
             self.tiled_c.n_work = len(host.work)
             self.tiled_c.work = N.ptr(self.work)
+            self.agent_scratch = (torch.zeros(max(1, host.n_agents), dtype=torch.float32, device=dev)
+                                  if split_epilogue else None)
+            self.tiled_c.agent_scratch = N.ptr(self.agent_scratch)
             plan.tiled = C.pointer(self.tiled_c)
         self.c = plan
 

@@ -137,6 +137,8 @@ typedef struct gj_tiled {
   int32_t _pad;
   int32_t n_work;            /* entries of `work`                                            */
   const int32_t* work;       /* device [2*n_work] (set, block) pairs, heaviest first         */
+  float* agent_scratch;      /* device [n_agents] workspace or NULL.  Non-NULL: phase D hands its
+                                per-agent sums to a separate full-occupancy epilogue launch  */
   gj_tiled_set sets[GJ_MAX_SETS];
 } gj_tiled;
 

@@ -47,9 +47,9 @@ def main():
 
     if os.environ.get("GJ_SWEEP", "geometry") == "geometry":
         run("default")
-        run("sa9792 (2 WG/CU in D)", slices=sl(9792))
-        run("default+sv8k+eb64k", sv_max=8192, eb_target=65536)
-        run("default+eb256k", eb_target=262144)
+        run("split epilogue", split_epilogue=True)
+        run("default again")
+        run("split epilogue again", split_epilogue=True)
         return
     # phase anatomy: diagnostic phases of gj_step_phase
     r = SingleGpuHotPath(world, specs, betas, dev, seed=1, layout="tiled", slices=sl(19584), sv_max=16384, eb_target=65536)
