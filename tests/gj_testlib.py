@@ -84,14 +84,14 @@ def network_specs(world, tables: Optional[dict] = None):
     return specs
 
 
-def make_engine(world, tables, device, layout="csr", **plan_kw):
+def make_engine(world, tables, device, layout="csr", split_epilogue=False, **plan_kw):
     from grad_june_amd.engine import InfectionEngine
     from grad_june_amd.plan import DevicePlan, compile_plan
 
     es = {k: {kk: vv.numpy() for kk, vv in v.items()} for k, v in world["edge_sets"].items()}
     host = compile_plan(world["n_agents"], es, age=world["age"].numpy(), sex=world["sex"].numpy(), layout=layout,
                         **plan_kw)
-    plan = DevicePlan(host, network_specs(world, tables), device)
+    plan = DevicePlan(host, network_specs(world, tables), device, split_epilogue=split_epilogue)
     return InfectionEngine(plan)
 
 

@@ -22,8 +22,9 @@ RTOL = 2e-5
 
 # every parity case runs on both device layouts: "csr" (deterministic CSR kernels) and "tiled"
 # (LDS-tiled fast path; small tiles/blocks forced so that multi-slice / multi-block paths run)
-LAYOUTS = [("csr", {}), ("tiled", {}), ("tiled", dict(sv_max=64, eb_target=512, slices="small"))]
-LAYOUT_IDS = ["csr", "tiled", "tiled-small-tiles"]
+LAYOUTS = [("csr", {}), ("tiled", {}), ("tiled", dict(sv_max=64, eb_target=512, slices="small")),
+           ("tiled", dict(split_epilogue=True))]
+LAYOUT_IDS = ["csr", "tiled", "tiled-small-tiles", "tiled-split-epilogue"]
 
 
 def engine_for(world, tables, device, layout):
