@@ -327,3 +327,18 @@ def test_config1_plumbing_30_timesteps(G, device):
     assert len(results["dates"]) == 31
     assert runner.model.n_steps == 30
     assert torch.isfinite(results["cases_per_timestep"]).all()
+
+
+def test_c_abi_from_plain_c(device, tmp_path):
+    """examples/abi_demo.c: the library called from C with hipMalloc'ed buffers - no Python objects involved."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "gradabm-june_amd", "grad_june_amd", "lib")
+    exe = str(tmp_path / "abi_demo")
+    subprocess.run(["gcc", os.path.join(root, "examples", "abi_demo.c"), "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                    "-I", os.path.join(root, "include"), "-L", lib_dir, "-lgradjune_hip", "-L/opt/rocm/lib", "-lamdhip64",
+                    f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True, capture_output=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert "ok" in out and "ABI version 1" in out
