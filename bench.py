@@ -352,7 +352,7 @@ def main():
         pass
     if not args.no_cpu_baseline and world_size == 1:
         out["cpu_baseline"] = cpu_baseline(world, networks, betas, tables, args.cpu_seconds)
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
     if distributed:
         dist.destroy_process_group()
 
