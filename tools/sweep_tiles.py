@@ -45,6 +45,13 @@ def main():
     def sl(sa):
         return (-(-A // sa), sa)
 
+    if os.environ.get("GJ_SWEEP", "geometry") == "grid":
+        # GJ_EB="16384,32768" GJ_SA="4928,9856": every combination of edges-per-block and agents-per-slice
+        run("default")
+        for sa in [int(x) for x in os.environ.get("GJ_SA", "19584").split(",")]:
+            for eb in [int(x) for x in os.environ.get("GJ_EB", "131072").split(",")]:
+                run(f"SA={sa} EB={eb}", slices=sl(sa), eb_target=eb)
+        return
     if os.environ.get("GJ_SWEEP", "geometry") == "geometry":
         run("default")
         run("split epilogue", split_epilogue=True)
