@@ -225,7 +225,7 @@ def agent_class_of(age, sex) -> np.ndarray:
 def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
                  n_ext_agents: Optional[int] = None, block_order: str = "interleave",
                  layout: str = "csr", leisure_sets: Sequence[str] = ("leisure",),
-                 sv_max: int = TL.SV_MAX, eb_target: int = TL.EB_TARGET, slices=None,
+                 sv_max: int = TL.SV_MAX, eb_target: Optional[int] = None, slices=None,
                  nets_per_set: Optional[Dict[str, int]] = None, progress=None) -> HostPlan:
     """edge_sets: {name: {"agent": i64[E], "venue": i64[E], "people": [V]}} (insertion order = set ids).
 
@@ -241,6 +241,8 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
     want_csr, want_tiled = layout in ("csr", "both"), layout in ("tiled", "both")
     cls_all = None if age is None else agent_class_of(age, sex)
     S, SA = slices if slices is not None else TL.choose_slices(n_ext)
+    if eb_target is None:
+        eb_target = TL.choose_block_edges(S)
     if want_tiled and n_ext != n_agents and (-(-n_agents // SA)) * SA > n_ext:
         raise ValueError("halo agents must start on a slice boundary (pad the owned range to a multiple of SA)")
     sets, all_blocks, all_long, work = [], [], [], []

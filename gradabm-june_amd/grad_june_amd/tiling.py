@@ -52,6 +52,15 @@ def choose_slices(n_agents: int, sa_max: int = SA_MAX, n_cu: int = N_CU):
     return s, sa
 
 
+def choose_block_edges(n_slices: int, eb_max: int = EB_TARGET) -> int:
+    """Edges per venue block.  A tile holds about eb / S edges: below ~128 the slice-major phases (A, D)
+    slow down (chunks spanning several tiles), while small blocks give phases B/C more workgroups -
+    what a small world (one rank's share of a strong-scaled run) needs to fill 256 CUs.  Measured on
+    MI355X (gpurun_out sweeps, c3 preset): 1.25M agents 0.190 -> 0.131 ms/step with 32768 instead of
+    131072; 10M agents flat between 49152 and 131072."""
+    return int(min(eb_max, max(32768, 128 * n_slices)))
+
+
 def venue_blocks(degree: np.ndarray, sv_max: int = SV_MAX, eb_target: int = EB_TARGET) -> np.ndarray:
     """Block boundaries ``blk_v0`` [J+1] over consecutive venues: <= sv_max venues, about eb_target
     edges (a venue above eb_target is a block of its own)."""
