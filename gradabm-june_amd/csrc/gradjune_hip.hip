@@ -1152,6 +1152,12 @@ int gj_step_phase(const gj_plan* plan, const gj_agent_state* state, const gj_ste
                                : gj::do_agent_gather(plan, state, params, G, io, 0, st);
     case 5: return plan->tiled ? gj::tiled_venues(plan, params, G, 1, st) : GJ_OK;
     case 6: return plan->tiled ? gj::tiled_venues(plan, params, G, 2, st) : GJ_OK;
+    case 7:   // 1 then 5 (A + B) in one call: the launch path of a partial-sum group
+    case 8:   // 1 then 2 (A + B + C)
+      if (!plan->tiled) return gj::do_venue_reduce(plan, state, params, G, st);
+      rc = gj::tiled_scatter(plan, state, params, G, st);
+      if (rc) return rc;
+      return gj::tiled_venues(plan, params, G, phase == 7 ? 1 : 0, st);
     default: return GJ_E_RANGE;
   }
 }

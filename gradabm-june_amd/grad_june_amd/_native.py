@@ -242,6 +242,11 @@ def ptr(t) -> Optional[int]:
 
 
 def current_stream() -> Optional[int]:
+    """Raw hipStream_t of torch's current stream on the current device.  This sits on every launch:
+    ``torch.cuda.current_stream().cuda_stream`` costs ~8 us, the two C calls below well under 1 us."""
     import torch
 
-    return torch.cuda.current_stream().cuda_stream
+    try:
+        return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    except AttributeError:       # a torch build without the private accessors
+        return torch.cuda.current_stream().cuda_stream

@@ -30,6 +30,16 @@ from . import tiling as TL
 HALO_MAX_MEAN_DEGREE = 8.0     # sets whose venues average more attendees use partial sums
 
 
+def reduce_groups(floats: Dict[str, int], min_floats: int = 1 << 16) -> List[List[str]]:
+    """Partial-sum edge sets -> all-reduce groups.  ``floats``: cum-buffer length per set (venues x networks;
+    global numbers, so every rank derives the same grouping).  The largest set gets an all-reduce of its
+    own, issued first, when it is big enough to be worth overlapping with the other sets' phases."""
+    names = sorted(floats, key=lambda n: (-floats[n], n))
+    if len(names) >= 2 and floats[names[0]] >= min_floats:
+        return [[names[0]], names[1:]]
+    return [names] if names else []
+
+
 def partition_bounds(n_agents: int, world_size: int) -> np.ndarray:
     """Contiguous, near-equal agent ranges: rank r owns [b[r], b[r+1])."""
     return (np.arange(world_size + 1, dtype=np.int64) * n_agents) // world_size
@@ -207,7 +217,7 @@ class DistributedHotPath:
 
     def __init__(self, world: dict, specs, betas: Dict[str, float], device, rank: int, world_size: int,
                  seed: int = 0, group=None, modes: Optional[Dict[str, str]] = None, collectives: bool = True,
-                 progress=None):
+                 progress=None, min_group_floats: int = 1 << 16):
         from . import _native as N
         from .benchrun import EventLog
         from .engine import AgentBuffers, InfectionEngine
@@ -218,9 +228,22 @@ class DistributedHotPath:
         rw = self.rw = build_rank_world(world, rank, world_size, modes, progress=progress)
         host = compile_plan(rw.n_local, rw.edge_sets, age=rw.age, sex=rw.sex, n_ext_agents=rw.n_ext,
                             layout="tiled", slices=(rw.n_slices, rw.slice_agents), progress=progress)
-        partial = [n for n in rw.edge_sets if rw.modes[n] == "partial"]
+        nets_on = {}
+        for sp in specs:
+            nets_on[sp.edge_set] = nets_on.get(sp.edge_set, 0) + 1
+        floats = {n: max(1, len(es["people"])) * max(1, nets_on.get(n, 1))
+                  for n, es in rw.edge_sets.items() if rw.modes[n] == "partial"}
+        self.reduce_groups = reduce_groups(floats, min_group_floats)                     # same on every rank (global sizes)
+        partial = [n for g in self.reduce_groups for n in g]
         self.engine = InfectionEngine(DevicePlan(host, specs, self.device, flat_cum_sets=partial))
         self.flat_cum = self.engine.plan.flat_cum
+        self.group_cum = []                                            # one contiguous view per all-reduce
+        for g in self.reduce_groups:
+            lo = self.engine.plan.flat_offsets[g[0]][0]
+            hi = sum(self.engine.plan.flat_offsets[g[-1]])
+            self.group_cum.append(self.flat_cum[lo:hi])
+        self.exchange_sets = [n for n in rw.edge_sets if rw.modes[n] != "partial"]   # halo or local
+        self._params_cache = {}
         self.networks = list(world["networks"])
         self.betas, self.seed = betas, seed
         a0, a1 = int(rw.bounds[rank]), int(rw.bounds[rank + 1])
@@ -244,34 +267,46 @@ class DistributedHotPath:
         self.t = 0
         self.log = EventLog()
 
-    def params(self, only: Optional[str] = None):
-        """only: None = every network; "halo" / "partial" = the networks on sets of that exchange mode."""
+    def params(self, only=None):
+        """only: None = every network; "halo" / "partial" = the networks on sets of that exchange mode;
+        a collection of edge-set names = the networks on those sets.  The struct is built once per
+        selection and only its clock fields change from step to step (this sits on the launch path)."""
         from .synthetic import edge_set_of
 
-        nets = self.networks
-        if only is not None:
-            want = ("halo",) if only == "halo" else ("partial", "local")
-            nets = [n for n in nets if self.rw.modes[edge_set_of(n)] in want]
-        return self.engine.params(now=1.0 + self.t, delta_time=1.0, day_type=0, active=nets,
-                                  betas=self.betas, seed=self.seed, step=self.t, agent_offset=self.a0)
+        key = only if (only is None or isinstance(only, str)) else tuple(only)
+        p = self._params_cache.get(key)
+        if p is None:
+            nets = self.networks
+            if isinstance(only, str):
+                want = ("halo",) if only == "halo" else ("partial", "local")
+                nets = [n for n in nets if self.rw.modes[edge_set_of(n)] in want]
+            elif only is not None:
+                nets = [n for n in nets if edge_set_of(n) in key]
+            p = self.engine.params(now=1.0, delta_time=1.0, day_type=0, active=nets, betas=self.betas,
+                                   seed=self.seed, step=0, agent_offset=self.a0)
+            self._params_cache[key] = p
+        p.now, p.step = 1.0 + self.t, self.t
+        return p
 
-    def _all_reduce(self, async_op: bool):
+    def _all_reduce(self, async_op: bool, buf: Optional[torch.Tensor] = None):
         import torch.distributed as dist
 
-        if self.flat_cum is None or not self.flat_cum.numel() or not dist.is_initialized():
+        buf = self.flat_cum if buf is None else buf
+        if buf is None or not buf.numel() or not dist.is_initialized():
             return None
         if dist.get_backend(self.group) == "gloo":        # tests: host-staged, synchronous
-            tmp = self.flat_cum.cpu()
+            tmp = buf.cpu()
             dist.all_reduce(tmp, group=self.group)
-            self.flat_cum.copy_(tmp)
+            buf.copy_(tmp)
             return None
-        return dist.all_reduce(self.flat_cum, group=self.group, async_op=async_op)
+        return dist.all_reduce(buf, group=self.group, async_op=async_op)
 
     def step(self, timed: bool = False):
-        """One step.  Untimed (production) form overlaps the two collectives with the phases that do
-        not depend on them: the halo all-to-all runs under phases A+B of the partial-sum sets, the
-        partial-sum all-reduce under phases A+B+C of the halo sets.  The timed form runs everything
-        in sequence so that every launch and collective can be bracketed by events."""
+        """One step.  Untimed (production) form overlaps the collectives with the phases that do not
+        depend on them: the halo all-to-all runs under phases A+B of the partial-sum sets, the
+        partial-sum all-reduces (one per group of ``reduce_groups``) under the later groups' A+B and the
+        halo sets' A+B+C.  The timed form runs everything in sequence, with a single all-reduce, so that
+        every launch and collective can be bracketed by events."""
         e = self.engine
         p_all = self.params()
         if timed or self.halo is None:
@@ -295,19 +330,27 @@ class DistributedHotPath:
             mark("tile_agents")
             self.t += 1
             return
-        p_halo, p_part = self.params("halo"), self.params("partial")
+        # Production form.  Sets that need no partial sums ("halo" / "local") run A, B, C under the
+        # all-reduces; the partial-sum sets go group by group (largest cum buffer first) so that the
+        # big all-reduce is in flight while the remaining groups are still computing.
         e.step_phase(self.bufs, p_all, self.io, 0)                        # transmission
         h = self.halo.exchange(self.state["transmission"], async_op=True)  # all-to-all on the comm stream
-        e.step_phase(self.bufs, p_part, self.io, 1)                       # A, B of the partial-sum sets
-        e.step_phase(self.bufs, p_part, self.io, 5)
-        r = self._all_reduce(True)                                        # all-reduce on the comm stream
+        pending = []
+        for g, buf in zip(self.reduce_groups, self.group_cum):
+            p_g = self.params(g)
+            if not p_g.n_nets:                                            # no active network on these sets
+                continue
+            e.step_phase(self.bufs, p_g, self.io, 7)                      # A, B of this group's sets
+            pending.append((p_g, self._all_reduce(True, buf)))            # all-reduce on the comm stream
         if h is not None:
             h.wait()
-        e.step_phase(self.bufs, p_halo, self.io, 1)                       # A, B, C of the halo sets
-        e.step_phase(self.bufs, p_halo, self.io, 2)
-        if r is not None:
-            r.wait()
-        e.step_phase(self.bufs, p_part, self.io, 6)                       # C of the partial-sum sets
+        p_x = self.params(self.exchange_sets)
+        if p_x.n_nets:
+            e.step_phase(self.bufs, p_x, self.io, 8)                      # A, B, C of the halo / local sets
+        for p_g, r in pending:
+            if r is not None:
+                r.wait()
+            e.step_phase(self.bufs, p_g, self.io, 6)                      # C of the group
         e.step_phase(self.bufs, p_all, self.io, 3)                        # D + epilogue: all sets
         self.t += 1
 

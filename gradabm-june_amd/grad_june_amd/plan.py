@@ -323,11 +323,17 @@ class DevicePlan:
         self.keep = []
         self.cum: List[torch.Tensor] = []
         self.tiled_c = None
-        flat_sizes = {s.name: max(1, s.n_venues) * max(1, per_set_nets.get(s.name, 1))
-                      for s in host.sets if s.name in flat_cum_sets}
+        # carved in the order the caller lists the sets (a collective may cover a leading / trailing run)
+        by_name = {s.name: s for s in host.sets}
+        flat_sizes = {n: max(1, by_name[n].n_venues) * max(1, per_set_nets.get(n, 1))
+                      for n in flat_cum_sets if n in by_name}
         self.flat_cum = (torch.zeros(sum(flat_sizes.values()), dtype=torch.float32, device=dev)
                          if flat_sizes else None)
-        flat_off = 0
+        self.flat_offsets: Dict[str, tuple] = {}
+        off = 0
+        for n, size in flat_sizes.items():
+            self.flat_offsets[n] = (off, size)
+            off += size
         plan = N.Plan()
         plan.n_agents = host.n_agents
         plan.n_ext_agents = host.n_ext_agents
@@ -340,8 +346,8 @@ class DevicePlan:
             if s.v_rowptr is not None:
                 t.update(v_rowptr=up(s.v_rowptr), v_agent=up(s.v_agent), a_rowptr=up(s.a_rowptr), a_venue=up(s.a_venue))
             if s.name in flat_sizes:
-                cum = self.flat_cum[flat_off:flat_off + flat_sizes[s.name]]
-                flat_off += flat_sizes[s.name]
+                o, size = self.flat_offsets[s.name]
+                cum = self.flat_cum[o:o + size]
             else:
                 cum = torch.zeros(max(1, s.n_venues) * stride, dtype=torch.float32, device=dev)
             e = plan.sets[i]

@@ -330,7 +330,8 @@ int gj_step(const gj_plan* plan, const gj_agent_state* state, const gj_step_para
  * 2 = tiled phases B+C (CSR: nothing); 3 = pass-2 + epilogue + decision + state update.
  * Calling phases 0,1,2,3 in order is exactly gj_step.  Diagnostic variants: 4 = phase 3 without
  * the decision/state update (probabilities only); 5 / 6 = the tiled venue launch split into its
- * B half (sums -> cum) and its C half (cum -> per-edge values).                                */
+ * B half (sums -> cum) and its C half (cum -> per-edge values) - the multi-GPU step all-reduces
+ * cum between the two; 7 = phases 1 then 5, 8 = phases 1 then 2, in one call.                  */
 int gj_step_phase(const gj_plan* plan, const gj_agent_state* state, const gj_step_params* params,
                   const gj_step_io* io, int phase, void* stream);
 

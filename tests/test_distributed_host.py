@@ -161,3 +161,14 @@ def test_reorder_agents_is_a_pure_renumbering_and_shrinks_the_halo():
     h0 = build_rank_world(world, 1, 4).n_halo
     h1 = build_rank_world(re, 1, 4).n_halo
     assert h1 < 0.7 * h0
+
+
+def test_reduce_groups_split_off_the_largest_partial_sum_set():
+    from grad_june_amd.distributed import reduce_groups
+
+    assert reduce_groups({}) == []
+    assert reduce_groups({"a": 10}) == [["a"]]
+    assert reduce_groups({"a": 10, "b": 20}) == [["b", "a"]]                          # too small to pipeline
+    assert reduce_groups({"school": 30_000, "company": 750_000, "care_home": 300_000}) == \
+        [["company"], ["care_home", "school"]]
+    assert reduce_groups({"x": 5, "y": 5}, min_floats=1) == [["x"], ["y"]]               # ties: by name

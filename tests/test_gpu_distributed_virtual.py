@@ -66,7 +66,7 @@ def test_virtual_ranks_match_single_rank(device, R):
     assert single.state["is_infected"].sum().item() > 0.05 * world["n_agents"]
 
 
-def _two_rank_worker(rank, R, port, out):
+def _two_rank_worker(rank, R, port, out, min_group_floats):
     """One real process per rank (both on cuda:0), torch.distributed with gloo, collectives staged
     through the host - the multi-process flow bench.py --gpus N takes, minus RCCL."""
     import os
@@ -79,8 +79,9 @@ def _two_rank_worker(rank, R, port, out):
         device = torch.device("cuda:0")
         world = make_world("c3", n_agents=30_000, seed=4, infected_fraction=0.05)
         specs, betas = B.network_specs(world), B.betas_of(world)
-        rk = DistributedHotPath(world, specs, betas, device, rank, R, seed=9)
+        rk = DistributedHotPath(world, specs, betas, device, rank, R, seed=9, min_group_floats=min_group_floats)
         assert rk.halo.host_staged and rk.halo.active
+        assert len(rk.reduce_groups) == (2 if min_group_floats == 1 else 1)
         for _ in range(3):
             rk.step()
         torch.cuda.synchronize()
@@ -99,14 +100,15 @@ def _two_rank_worker(rank, R, port, out):
         dist.destroy_process_group()
 
 
-def test_two_processes_gloo_match_single_rank(device):
+@pytest.mark.parametrize("min_group_floats", [1 << 16, 1], ids=["one-all-reduce", "pipelined-all-reduces"])
+def test_two_processes_gloo_match_single_rank(device, min_group_floats):
     import os
 
     import torch.multiprocessing as mp
 
     R = 2
     out = mp.get_context("spawn").Array("i", [0])
-    mp.spawn(_two_rank_worker, args=(R, 29600 + os.getpid() % 300, out), nprocs=R, join=True)
+    mp.spawn(_two_rank_worker, args=(R, 29600 + os.getpid() % 300, out, min_group_floats), nprocs=R, join=True)
     assert out[0] == 1
 
 
