@@ -166,6 +166,11 @@ def _es(n):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON result: libraries that print to fd 1 (RCCL's version banner
+    # at init, for one) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -352,7 +357,8 @@ def main():
         pass
     if not args.no_cpu_baseline and world_size == 1:
         out["cpu_baseline"] = cpu_baseline(world, networks, betas, tables, args.cpu_seconds)
-    print(json.dumps(out), flush=True)
+    sys.stdout.flush()
+    os.write(result_fd, (json.dumps(out) + "\n").encode())
     if distributed:
         dist.destroy_process_group()
 
