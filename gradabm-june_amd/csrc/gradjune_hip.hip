@@ -442,6 +442,62 @@ __global__ __launch_bounds__(kThreads) void k_symptoms(const SymptomsArgs S) {
   S.ttn[a] = tt;
 }
 
+// f3: adjoint of k_symptoms w.r.t. the stage values and new_infected (oracle/gj_oracle.py:adjoint_symptoms).
+// Recomputes the branch the agent took from the PRE-step state and the same randomness.
+struct SymptomsAdjointArgs {
+  gj_symptoms_params P;
+  int64_t n;
+  const uint8_t* cls;
+  const float* new_inf;
+  const float* cur0;
+  const float* nxt0;
+  const float* ttn0;
+  const float* progresses;
+  const float* g_cur;
+  const float* g_nxt;
+  float* g_cur_in;
+  float* g_nxt_in;
+  float* g_new;
+};
+
+__global__ __launch_bounds__(kThreads) void k_adjoint_symptoms(const SymptomsAdjointArgs S) {
+  const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= S.n) return;
+  const int n_stages = S.P.n_stages;
+  const float time = S.P.time;
+  const float nw = S.new_inf[a];
+  const float c0 = S.cur0[a], x0 = S.nxt0[a], t0 = S.ttn0[a];
+  const float x1 = x0 + nw * (2.0f - x0);
+  const float t1 = t0 + nw * (time - t0);
+  const bool moving = (time >= t1) && (c0 < (float)(n_stages - 1));
+  const float m = moving ? 1.0f : 0.0f;
+  const float c1 = c0 - (c0 - x1) * m;
+  int s = (int)c1;
+  s = min(max(s, 0), n_stages - 1);
+  float gc1 = S.g_cur ? S.g_cur[a] : 0.0f;
+  float gx1 = S.g_nxt ? S.g_nxt[a] : 0.0f;
+  if (moving && s >= 2 && s <= n_stages - 2 && c1 == (float)s) {
+    bool onward;
+    if (S.progresses) {
+      onward = S.progresses[a] != 0.0f;
+    } else {
+      uint32_t r[4];
+      philox4x32_10((uint64_t)(S.P.agent_offset + a), S.P.step | (1ull << 63), S.P.seed, r);
+      onward = u01(r[0]) < S.P.progress[s * 100 + (S.cls[a] % 100)];
+    }
+    if (onward) {
+      gc1 += gx1 / (float)s;                // next += (current == s) * current / s
+    } else {
+      gc1 -= gx1 * x1 / (float)s;           // next -= next * (current == s) * current / s
+      gx1 = 0.0f;
+    }
+  }
+  gx1 += gc1 * m;                           // current -= (current - next) * moving
+  S.g_cur_in[a] = gc1 * (1.0f - m);
+  S.g_nxt_in[a] = gx1 * (1.0f - nw);        // next += new_infected * (2 - next)
+  S.g_new[a] = gx1 * (2.0f - x0);
+}
+
 // f3: elementwise adjoints (see include/gradjune_hip.h)
 __global__ __launch_bounds__(kThreads) void k_adjoint_sample(
     int64_t n, const float* __restrict__ susc0, const float* __restrict__ time0, const float* __restrict__ acc,
@@ -1084,6 +1140,37 @@ int gj_symptoms_update(int64_t n, const uint8_t* agent_class, const float* new_i
   S.dwell = dwell;
   hipLaunchKernelGGL(gj::k_symptoms, dim3((unsigned)((n + gj::kThreads - 1) / gj::kThreads)), dim3(gj::kThreads), 0,
                      (hipStream_t)stream, S);
+  return gj::launch_status();
+}
+
+int gj_adjoint_symptoms(int64_t n, const uint8_t* agent_class, const float* new_infected,
+                        const float* current_stage0, const float* next_stage0, const float* time_to_next_stage0,
+                        const gj_symptoms_params* params, const float* progresses, const float* g_current,
+                        const float* g_next, float* g_current_in, float* g_next_in, float* g_new_infected,
+                        void* stream) {
+  if (n < 0) return GJ_E_RANGE;
+  if (n == 0) return GJ_OK;
+  if (!agent_class || !new_infected || !current_stage0 || !next_stage0 || !time_to_next_stage0 || !params)
+    return GJ_E_NULL;
+  if (!g_current_in || !g_next_in || !g_new_infected) return GJ_E_NULL;
+  if (params->n_stages < 3 || params->n_stages > GJ_MAX_STAGES) return GJ_E_RANGE;
+  if (!progresses && !params->progress) return GJ_E_NULL;
+  gj::SymptomsAdjointArgs S;
+  S.P = *params;
+  S.n = n;
+  S.cls = agent_class;
+  S.new_inf = new_infected;
+  S.cur0 = current_stage0;
+  S.nxt0 = next_stage0;
+  S.ttn0 = time_to_next_stage0;
+  S.progresses = progresses;
+  S.g_cur = g_current;
+  S.g_nxt = g_next;
+  S.g_cur_in = g_current_in;
+  S.g_nxt_in = g_next_in;
+  S.g_new = g_new_infected;
+  hipLaunchKernelGGL(gj::k_adjoint_symptoms, dim3((unsigned)((n + gj::kThreads - 1) / gj::kThreads)),
+                     dim3(gj::kThreads), 0, (hipStream_t)stream, S);
   return gj::launch_status();
 }
 

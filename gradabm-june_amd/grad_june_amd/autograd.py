@@ -128,3 +128,45 @@ class HotPathStep(torch.autograd.Function):
             lb = net.log_beta
             out_grads.append(g.to(lb.device).reshape(lb.shape) if isinstance(lb, torch.Tensor) and lb.requires_grad else None)
         return (None, grad_susc, grad_inf, grad_time, *out_grads)
+
+
+class SymptomsStep(torch.autograd.Function):
+    """(new_infected, current_stage, next_stage, time_to_next_stage) -> the three updated arrays, with the
+    reference's gradient paths (symptoms.py:98,105-124,231-236): a loss on the stages - the deaths series of
+    runner.py:198-215 - reaches ``log_beta`` through ``new_infected``.  Forward = ``gj_symptoms_update`` on
+    fresh tensors; backward = ``gj_adjoint_symptoms`` replaying the branch each agent took."""
+
+    @staticmethod
+    def forward(ctx, env, new_infected, cur, nxt, ttn):
+        lib = N.load()
+        n = new_infected.numel()
+        nw = new_infected.detach().to(torch.float32).contiguous()
+        cur0, nxt0, ttn0 = (t.detach().to(torch.float32).contiguous() for t in (cur, nxt, ttn))
+        out_c, out_x, out_t = cur0.clone(), nxt0.clone(), ttn0.clone()
+        p = env["params"]
+        N.check(lib.gj_symptoms_update(n, N.ptr(env["cls"]), N.ptr(nw), N.ptr(out_c), N.ptr(out_x), N.ptr(out_t),
+                                       C.byref(p), N.ptr(env["progresses"]), N.ptr(env["dwell"]), N.current_stream()),
+                "gj_symptoms_update")
+        snap = N.SymptomsParams()                       # the caller reuses its struct: keep this call's clock / key
+        C.memmove(C.byref(snap), C.byref(p), C.sizeof(N.SymptomsParams))
+        ctx.env = {"cls": env["cls"], "progresses": env["progresses"], "params": snap, "table": env.get("table")}
+        ctx.save_for_backward(nw, cur0, nxt0, ttn0)
+        ctx.mark_non_differentiable(out_t)
+        return out_c, out_x, out_t
+
+    @staticmethod
+    def backward(ctx, g_cur, g_nxt, _g_ttn):
+        nw, cur0, nxt0, ttn0 = ctx.saved_tensors
+        env = ctx.env
+        n = nw.numel()
+
+        def f32(g):
+            return None if g is None else g.detach().to(torch.float32).contiguous()
+
+        g_cur, g_nxt = f32(g_cur), f32(g_nxt)
+        g_cur_in, g_nxt_in, g_new = (torch.empty_like(nw) for _ in range(3))
+        N.check(N.load().gj_adjoint_symptoms(n, N.ptr(env["cls"]), N.ptr(nw), N.ptr(cur0), N.ptr(nxt0), N.ptr(ttn0),
+                                             C.byref(env["params"]), N.ptr(env["progresses"]), N.ptr(g_cur),
+                                             N.ptr(g_nxt), N.ptr(g_cur_in), N.ptr(g_nxt_in), N.ptr(g_new),
+                                             N.current_stream()), "gj_adjoint_symptoms")
+        return None, g_new, g_cur_in, g_nxt_in, None

@@ -114,6 +114,7 @@ class GradJune(torch.nn.Module):
 
     def forward(self, data, timer, exp_noise=None):
         new_infected, _ = self.hot_path(data, timer, exp_noise=exp_noise)
-        # the symptoms state machine is not differentiated (its only gradient path feeds the deaths series)
-        self.symptoms_updater(data=data, timer=timer, new_infected=new_infected.detach())
+        # in grad mode new_infected stays on the graph: the symptoms update is then an autograd node too
+        # (autograd.SymptomsStep), which is what makes the deaths series differentiable (runner.py:198-215)
+        self.symptoms_updater(data=data, timer=timer, new_infected=new_infected)
         return data

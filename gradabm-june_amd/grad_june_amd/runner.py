@@ -183,7 +183,11 @@ class Runner(torch.nn.Module):
             self._record(data, row)
             if differentiable:
                 ag = data["agent"]
-                diff_rows.append(torch.cat((ag.is_infected.sum().reshape(1), self.get_cases_by_age(data))))
+                stage = ag.symptoms["current_stage"]
+                dead = float(self.model.symptoms_updater.stages_ids[-1])
+                deaths = ((stage == dead) * stage / dead).sum()          # store_differentiable_deaths' form
+                diff_rows.append(torch.cat((ag.is_infected.sum().reshape(1), self.get_cases_by_age(data),
+                                            deaths.reshape(1))))
 
         record(0)
         dates = [timer.date]
@@ -196,7 +200,7 @@ class Runner(torch.nn.Module):
             dates.append(timer.date)
         series = self._series[: row + 1].to(torch.float32)
         if differentiable:
-            series = torch.cat((torch.stack(diff_rows), series[:, 1 + n_bins:]), dim=1)
+            series = torch.stack(diff_rows).to(torch.float32)
         cases_per_timestep = series[:, 0]
         data["results"]["deaths_per_timestep"] = series[:, 1 + n_bins]
         results = {

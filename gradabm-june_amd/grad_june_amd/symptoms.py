@@ -147,12 +147,22 @@ class SymptomsUpdater(torch.nn.Module):
             self.rng_seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
         self.n_calls = getattr(self, "n_calls", 0) + 1
         p.seed, p.step, p.agent_offset = self.rng_seed, self.n_calls, 0
-        nw = new_infected.detach().to(torch.float32).contiguous()
         if (progresses is None) != (dwell is None):
             raise ValueError("inject both progresses and dwell, or neither")
         if progresses is not None:
             progresses = progresses.to(device=device, dtype=torch.float32).contiguous()
             dwell = dwell.to(device=device, dtype=torch.float32).contiguous()
+        if torch.is_grad_enabled() and (new_infected.requires_grad or symptoms["current_stage"].requires_grad
+                                        or symptoms["next_stage"].requires_grad):
+            # row f3: the update as an autograd node, so that a loss on the stages (deaths) reaches log_beta
+            from .autograd import SymptomsStep
+
+            env = {"cls": cls, "params": p, "progresses": progresses, "dwell": dwell, "table": table}
+            (symptoms["current_stage"], symptoms["next_stage"], symptoms["time_to_next_stage"]) = SymptomsStep.apply(
+                env, new_infected, symptoms["current_stage"], symptoms["next_stage"], symptoms["time_to_next_stage"])
+            self.used_kernel = True
+            return symptoms
+        nw = new_infected.detach().to(torch.float32).contiguous()
         N.check(N.load().gj_symptoms_update(n, N.ptr(cls), N.ptr(nw), N.ptr(symptoms["current_stage"]),
                                             N.ptr(symptoms["next_stage"]), N.ptr(symptoms["time_to_next_stage"]),
                                             C.byref(p), N.ptr(progresses), N.ptr(dwell), N.current_stream()),

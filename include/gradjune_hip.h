@@ -320,6 +320,19 @@ int gj_adjoint_sample(int64_t n, const float* susceptibility0, const float* infe
 int gj_adjoint_transmission(int64_t n, const gj_agent_state* state0, float now, const float* trans_bar,
                             const float* g_inf, float* grad_inf_out, float* grad_time_inout, void* stream);
 
+/* gj_adjoint_symptoms: adjoint of gj_symptoms_update w.r.t. the stage values and new_infected - what
+ * makes a loss on the symptom stages (the deaths series, grad_june/runner.py:198-215; asserted to carry
+ * a gradient by test/unit/test_runner.py:82-90) differentiable w.r.t. log_beta.  Inputs: the PRE-update
+ * current / next stage and time_to_next_stage, new_infected, the SAME params (time, seed, step) or the
+ * same injected `progresses`, and the gradients w.r.t. the updated current / next stage (NULL = 0).
+ * Outputs (each [n]): gradients w.r.t. the incoming current stage, next stage and new_infected.  The
+ * gradient paths are those of symptoms.py:98,105-124,231-236; times carry none.                     */
+int gj_adjoint_symptoms(int64_t n, const uint8_t* agent_class, const float* new_infected,
+                        const float* current_stage0, const float* next_stage0, const float* time_to_next_stage0,
+                        const gj_symptoms_params* params, const float* progresses, const float* g_current,
+                        const float* g_next, float* g_current_in, float* g_next_in, float* g_new_infected,
+                        void* stream);
+
 /* The production step: a1..a9 = the middle of GradJune.forward (grad_june/model.py:125-138)
  * as three dependent launches on `stream` (+1 when the plan has long rows).                */
 int gj_step(const gj_plan* plan, const gj_agent_state* state, const gj_step_params* params,

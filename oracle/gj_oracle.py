@@ -231,6 +231,34 @@ def symptoms_update(age, current_stage, next_stage, time_to_next_stage, new_infe
     return current_stage, next_stage, time_to_next_stage
 
 
+def adjoint_symptoms(current_stage, next_stage, time_to_next_stage, new_infected, time, n_stages: int,
+                     progresses, g_cur, g_nxt):
+    """Hand-written adjoint of symptoms_update (what gj_adjoint_symptoms computes): given the gradients
+    w.r.t. the OUTPUT current / next stage, those w.r.t. the INPUT current / next stage and new_infected.
+    The only gradient paths of symptoms.py:82-128, 231-236 are next_stage += new_infected * (2 - next_stage),
+    the transition current -= (current - next) * mask and the value-1 factor ``(current == i) * current / i``
+    that multiplies the +1 (onward) / -next (recover) updates of next_stage; times carry no gradient to a
+    stage (they only enter comparisons)."""
+    f64 = torch.float64
+    c0, x0, t0, nw = (v.to(f64) for v in (current_stage, next_stage, time_to_next_stage, new_infected))
+    g_cur, g_nxt = g_cur.to(f64), g_nxt.to(f64)
+    x1 = x0 + nw * (2.0 - x0)
+    t1 = t0 + nw * (time - t0)
+    moving = (time >= t1) & (c0 < n_stages - 1)
+    m = moving.to(f64)
+    c1 = c0 - (c0 - x1) * m
+    s = c1.long().clamp(0, n_stages - 1)
+    at = moving & (s >= 2) & (s <= n_stages - 2) & (c1 == s)
+    onward = progresses.to(torch.bool)
+    sf = s.to(f64).clamp(min=1.0)
+    zero = torch.zeros_like(g_cur)
+    gc1 = g_cur + torch.where(at & onward, g_nxt / sf, zero) - torch.where(at & ~onward, g_nxt * x1 / sf, zero)
+    gx1 = torch.where(at & ~onward, zero, g_nxt)
+    g_cur_in = gc1 * (1.0 - m)
+    gx1 = gx1 + gc1 * m
+    return g_cur_in, gx1 * (1.0 - nw), gx1 * (2.0 - x0)
+
+
 def symptoms_progress_probability(table, age, current_stage, next_stage, time_to_next_stage, new_infected, time,
                                   n_stages: int):
     """probs handed to torch.bernoulli: table[stage after the due transition, age] (symptoms.py:93-95)."""
@@ -340,7 +368,7 @@ def hot_path_step(
 #     Returns (grad_susc_in, grad_inf_in, grad_time_in, {network: d loss / d log_beta}).
 # --------------------------------------------------------------------------------------
 def adjoint_step(world, state, *, now, delta_time, day_type, active, betas, leisure_tables=None,
-                 quarantine_thresholds=None, exp_noise, g_susc, g_inf, g_time):
+                 quarantine_thresholds=None, exp_noise, g_susc, g_inf, g_time, g_new=None):
     import math
 
     A = world["n_agents"]
@@ -391,6 +419,8 @@ def adjoint_step(world, state, *, now, delta_time, day_type, active, betas, leis
     x = susc0 - nu
     h = torch.where(x > 0, torch.ones_like(x), torch.where(x == 0, torch.full_like(x, 0.5), torch.zeros_like(x)))
     nu_bar = g_inf + g_time * (now - time0) - g_susc * h
+    if g_new is not None:                              # new_infected is also read by the symptoms updater
+        nu_bar = nu_bar + g_new.to(f64)
     dnu_dp = -(ysoft[0] * ysoft[1] / GUMBEL_TAU) * (1.0 / p + 1.0 / (1.0 - p))
     dnu_dp = torch.nan_to_num(dnu_dp, nan=0.0, posinf=0.0, neginf=0.0)
     ts_bar = nu_bar * dnu_dp * (-delta_time * p) * inside

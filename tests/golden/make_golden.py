@@ -701,6 +701,126 @@ def make_grads():
     save("grads.npz", out)
 
 
+class _SymptomsRecorder(torch.nn.Module):
+    """Stands where model.symptoms_updater is: lets the reference run on the autograd graph and records,
+    per call, the bernoulli outcome and the dwell-time sample each agent consumed (as record_symptoms)."""
+
+    def __init__(self, inner):
+        super().__init__()
+        self.inner, self.calls = inner, []
+
+    @property
+    def stages_ids(self):
+        return self.inner.stages_ids
+
+    def forward(self, data, timer, new_infected):
+        sampler = self.inner.symptoms_sampler
+        sym = data["agent"].symptoms
+        rec = {"pre/" + k: sym[k].detach().clone().float().numpy()
+               for k in ("current_stage", "next_stage", "time_to_next_stage")}
+        log = []
+        saved = (dict(sampler.stage_transition_times), dict(sampler.recovery_times))
+        for i in saved[0]:
+            if saved[0][i] is not None:
+                sampler.stage_transition_times[i] = _RecordingDist(saved[0][i], log, ("next", i))
+            if saved[1][i] is not None:
+                sampler.recovery_times[i] = _RecordingDist(saved[1][i], log, ("rec", i))
+        bern = {}
+        real_bernoulli = torch.bernoulli
+
+        def bernoulli(p, *a, **k):
+            out = real_bernoulli(p, *a, **k)
+            bern["out"] = out.detach().clone()
+            return out
+
+        torch.bernoulli = bernoulli
+        try:
+            out = self.inner(data=data, timer=timer, new_infected=new_infected)
+        finally:
+            torch.bernoulli = real_bernoulli
+            sampler.stage_transition_times.update(saved[0])
+            sampler.recovery_times.update(saved[1])
+        progresses = bern["out"]
+        cur_after = sym["current_stage"].detach().float()
+        dwell = torch.zeros(len(progresses))
+        for (kind, i), draw in log:
+            use = (cur_after == i) & (progresses.bool() if kind == "next" else ~progresses.bool())
+            dwell = torch.where(use, draw.detach(), dwell)
+        rec["progresses"] = progresses.numpy().astype(np.float32)
+        rec["dwell"] = dwell.numpy().astype(np.float32)
+        for k in ("current_stage", "next_stage", "time_to_next_stage"):
+            rec["post/" + k] = sym[k].detach().float().numpy().copy()
+        self.calls.append(rec)
+        return out
+
+
+def make_grads_symptoms():
+    """g3: gradients that reach log_beta THROUGH the symptoms state machine (the deaths series of
+    runner.py:198-215 is such a loss; test_runner.py:82-90) - the whole timestep on the autograd graph."""
+    out = {}
+    params = default_params()
+    for n in params["networks"]:
+        params["networks"][n]["log_beta"] += 0.7
+    seed_all(123)
+    runner = Runner.from_parameters(params)
+    with torch.no_grad():
+        runner.timer.reset()
+        runner.restore_initial_data()
+        runner.set_initial_cases()
+    model, data, timer = runner.model, runner.data, runner.timer
+    flat_world(world_of(data), out, prefix="g3/world/")
+    for n, t in tables_of(model).items():
+        out["g3/table/" + n] = t.numpy()
+    out["g3/sym_table"] = model.symptoms_updater.symptoms_sampler.stage_transition_probabilities.numpy()
+    for k in ("current_stage", "next_stage", "time_to_next_stage"):
+        out["g3/state0/sym/" + k] = data["agent"].symptoms[k].detach().float().numpy().copy()
+    sym_rec = _SymptomsRecorder(model.symptoms_updater)
+    model.symptoms_updater = sym_rec
+    n_steps = 12
+    A = len(data["agent"].id)
+    dead = int(sym_rec.stages_ids[-1])
+    stage_series = {k: [] for k in range(2, dead + 1)}
+    hook = {}
+
+    # run_with_grads drives the steps; sample the occupancy series right after every model call
+    real_forward = sym_rec.forward
+
+    def forward_and_sample(data, timer, new_infected):
+        res = real_forward(data, timer, new_infected)
+        cur = data["agent"].symptoms["current_stage"]
+        for k in stage_series:
+            stage_series[k].append(((cur == k) * cur / k).sum())
+        hook["data"] = data
+        return res
+
+    sym_rec.forward = forward_and_sample
+    data = run_with_grads(model, data, timer, n_steps, out, "g3/", step_first=True)
+    for i, rec in enumerate(sym_rec.calls):
+        for k, v in rec.items():
+            out[f"g3/step{i}/sym/{k}"] = v
+    names = list(model.infection_networks.networks.keys())
+    g = torch.Generator().manual_seed(5)
+    w_cur, w_nxt = torch.rand(A, generator=g), torch.rand(A, generator=g)
+    out["g3/w_cur"], out["g3/w_nxt"] = w_cur.numpy(), w_nxt.numpy()
+    sym = data["agent"].symptoms
+    losses = {"stage_lin": (w_cur * sym["current_stage"]).sum() + (w_nxt * sym["next_stage"]).sum(),
+              "deaths": torch.stack(stage_series[dead]).sum()}
+    for k in range(2, dead):
+        losses[f"occupancy{k}"] = torch.stack(stage_series[k]).sum()
+    for tag, loss in losses.items():
+        for n in names:
+            model.infection_networks.networks[n].log_beta.grad = None
+        if loss.requires_grad:
+            loss.backward(retain_graph=True)
+        for n in names:
+            gr = model.infection_networks.networks[n].log_beta.grad
+            out[f"g3/grad_{tag}/{n}"] = np.float32(0.0 if gr is None else gr.item())
+        out[f"g3/loss_{tag}"] = np.float32(loss.item())
+        print("g3", tag, float(loss), {n: float(out[f"g3/grad_{tag}/{n}"]) for n in names})
+    out["g3/loss_tags"] = np.array(",".join(losses))
+    save("grads_symptoms.npz", out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     make_kat6()
@@ -709,4 +829,5 @@ if __name__ == "__main__":
     make_june769("june769_hot", beta_shift=0.9, write_world=False)
     make_synth10k()
     make_grads()
+    make_grads_symptoms()
     print("all golden cases generated; oracle == reference on every recorded stage")

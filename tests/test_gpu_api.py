@@ -256,6 +256,32 @@ def test_run_model_script_flow_with_gradients(G, device):
     assert results["cases_per_timestep"][-1].item() == pytest.approx(is_infected.sum().item())
 
 
+def test_deaths_gradient(G, device):
+    """test_runner.py:82-90: in a differentiable run the deaths series stays on the autograd graph
+    (one record per day + the initial one) and equals data["results"]["deaths_per_timestep"]."""
+    torch.manual_seed(6)
+    runner = G.Runner.from_parameters(params_on(device, days=15))
+    for net in runner.model.infection_networks.networks.values():
+        net.log_beta = torch.nn.Parameter(net.log_beta)
+    results, is_infected = runner()
+    assert results["cases_per_timestep"].requires_grad
+    daily_deaths = runner.data["results"]["deaths_per_timestep"]
+    assert (results["deaths_per_timestep"] == daily_deaths).all()
+    assert daily_deaths.shape[0] == runner.input_parameters["timer"]["total_days"] + 1
+    assert daily_deaths.requires_grad
+    # the graph reaches the parameters through the symptoms updates: backward runs and is finite
+    (daily_deaths.sum() + results["cases_per_timestep"][-1]).backward()
+    g = runner.model.infection_networks.networks["household"].log_beta.grad
+    assert g is not None and torch.isfinite(g)
+    # forward values are those of the non-differentiable run with the same seed
+    torch.manual_seed(6)
+    plain = G.Runner.from_parameters(params_on(device, days=15))
+    with torch.no_grad():
+        res2, inf2 = plain()
+    assert torch.equal(res2["cases_per_timestep"].cpu(), results["cases_per_timestep"].detach().cpu())
+    assert torch.equal(res2["deaths_per_timestep"].cpu(), daily_deaths.detach().cpu())
+
+
 def params_on(device, days=15):
     from grad_june_amd.defaults import default_parameters
 

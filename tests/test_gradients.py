@@ -13,7 +13,7 @@ CASES = ["g1", "g2"]
 
 
 def load_case(case):
-    npz = L.load_npz("grads.npz")
+    npz = L.load_npz("grads_symptoms.npz" if case == "g3" else "grads.npz")
     pre = case + "/"
     sub = {k[len(pre):]: v for k, v in npz.items() if k.startswith(pre)}
     world = L.world_from(sub)
@@ -93,6 +93,124 @@ def test_handwritten_adjoint_matches_reference(case):
                 total[n] += v
         for n in names:
             assert total[n] == pytest.approx(float(sub[f"grad_{tag}/{n}"]), rel=5e-4, abs=1e-5), (tag, n)
+
+
+# ------------------------------------------------------------------------------------------------------
+# g3: gradients that reach log_beta THROUGH the symptoms state machine (deaths-style losses,
+# reference runner.py:198-215 / test_runner.py:82-90)
+# ------------------------------------------------------------------------------------------------------
+def symptom_losses(sub, sym, occupancy):
+    """The losses recorded in g3 from the final symptoms state and the per-step occupancy sums."""
+    w_cur, w_nxt = torch.from_numpy(sub["w_cur"]), torch.from_numpy(sub["w_nxt"])
+    dev = sym["current_stage"].device
+    losses = {"stage_lin": (w_cur.to(dev) * sym["current_stage"]).sum() + (w_nxt.to(dev) * sym["next_stage"]).sum()}
+    for tag in str(sub["loss_tags"]).split(","):
+        if tag.startswith("occupancy"):
+            losses[tag] = torch.stack(occupancy[int(tag[9:])]).sum()
+    return losses
+
+
+def occupancy_of(cur, k):
+    return ((cur == k) * cur / k).sum()          # store_differentiable_deaths' form for stage k (runner.py:204-215)
+
+
+def test_oracle_autograd_through_symptoms_matches_reference():
+    sub, world, tables, names = load_case("g3")
+    mult = {n: torch.ones((), requires_grad=True) for n in names}
+    st = {k[7:]: torch.from_numpy(v) for k, v in sub.items() if k.startswith("state0/") and "/sym/" not in k}
+    sym = {k: torch.from_numpy(sub["state0/sym/" + k]) for k in ("current_stage", "next_stage", "time_to_next_stage")}
+    n_stages = sub["sym_table"].shape[0]
+    occupancy = {k: [] for k in range(2, n_stages)}
+    for i in range(int(sub["n_steps"])):
+        s = step_info(sub, i)
+        st["current_stage"] = sym["current_stage"]
+        assert np.array_equal(sym["current_stage"].detach().numpy(), sub[f"step{i}/sym/pre/current_stage"]), i
+        betas = {n: torch.tensor(np.float32(s["betas"][n])) * mult[n] for n in s["active"]}
+        out = O.hot_path_step(world, st, now=s["now"], delta_time=s["dt"], day_type=s["day_type"], active=s["active"],
+                              betas=betas, leisure_tables=tables, quarantine_thresholds=s["thr"], exp_noise=s["noise"])
+        for k in ("susceptibility", "is_infected", "infection_time"):
+            st[k] = out[k]
+        assert np.array_equal(out["is_infected"].detach().numpy(), s["is_infected"]), i
+        cur, nxt, ttn = O.symptoms_update(world["age"], sym["current_stage"], sym["next_stage"], sym["time_to_next_stage"],
+                                          out["new_infected"], s["now"], n_stages,
+                                          torch.from_numpy(sub[f"step{i}/sym/progresses"]),
+                                          torch.from_numpy(sub[f"step{i}/sym/dwell"]))
+        sym = {"current_stage": cur, "next_stage": nxt, "time_to_next_stage": ttn}
+        for k in sym:
+            assert np.array_equal(sym[k].detach().numpy(), sub[f"step{i}/sym/post/{k}"]), (i, k)
+        for k in occupancy:
+            occupancy[k].append(occupancy_of(cur, k))
+    for tag, loss in symptom_losses(sub, sym, occupancy).items():
+        assert float(loss.detach()) == pytest.approx(float(sub["loss_" + tag]), rel=1e-6)
+        grads = torch.autograd.grad(loss, [mult[n] for n in names], retain_graph=True, allow_unused=True) \
+            if loss.requires_grad else [None] * len(names)
+        for n, g in zip(names, grads):
+            got = 0.0 if g is None else float(g) * np.log(10.0)
+            assert got == pytest.approx(float(sub[f"grad_{tag}/{n}"]), rel=5e-4, abs=1e-6), (tag, n)
+
+
+def test_handwritten_symptoms_adjoint_matches_autograd():
+    """adjoint_symptoms against autograd through the op-for-op restatement, on random states that put
+    agents in every branch (not due, due and progressing, due and recovering, newly infected, dead)."""
+    g = torch.Generator().manual_seed(3)
+    n, n_stages = 4000, 8
+    cur = torch.randint(0, n_stages, (n,), generator=g).float().requires_grad_()
+    nxt = torch.randint(0, n_stages, (n,), generator=g).float().requires_grad_()
+    ttn = torch.rand(n, generator=g) * 10
+    new = (torch.rand(n, generator=g) < 0.2).float().requires_grad_()
+    progresses = (torch.rand(n, generator=g) < 0.5).float()
+    dwell = torch.rand(n, generator=g) * 5
+    age = torch.randint(0, 100, (n,), generator=g)
+    c, x, _ = O.symptoms_update(age, cur, nxt, ttn, new, 5.0, n_stages, progresses, dwell)
+    g_cur, g_nxt = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    ref = torch.autograd.grad((c * g_cur).sum() + (x * g_nxt).sum(), (cur, nxt, new))
+    got = O.adjoint_symptoms(cur.detach(), nxt.detach(), ttn, new.detach(), 5.0, n_stages, progresses, g_cur, g_nxt)
+    for a, b, what in zip(got, ref, ("current_stage", "next_stage", "new_infected")):
+        assert torch.allclose(a.float(), b, rtol=1e-6, atol=1e-6), what
+
+
+def test_handwritten_adjoint_through_symptoms_matches_reference():
+    """Reverse sweep over g3 with the two hand-written adjoints (hot path + symptoms) only."""
+    sub, world, tables, names = load_case("g3")
+    T = int(sub["n_steps"])
+    n_stages = sub["sym_table"].shape[0]
+    st = {k[7:]: torch.from_numpy(v) for k, v in sub.items() if k.startswith("state0/") and "/sym/" not in k}
+    states, infos = [], []
+    for i in range(T):
+        s = step_info(sub, i)
+        st["current_stage"] = torch.from_numpy(sub[f"step{i}/sym/pre/current_stage"])
+        states.append(dict(st))
+        infos.append(s)
+        out = O.hot_path_step(world, st, now=s["now"], delta_time=s["dt"], day_type=s["day_type"], active=s["active"],
+                              betas=s["betas"], leisure_tables=tables, quarantine_thresholds=s["thr"], exp_noise=s["noise"])
+        for k in ("susceptibility", "is_infected", "infection_time"):
+            st[k] = out[k]
+        states[-1]["new_infected"] = out["new_infected"]
+    A = world["n_agents"]
+    w_cur, w_nxt = torch.from_numpy(sub["w_cur"]).double(), torch.from_numpy(sub["w_nxt"]).double()
+    for tag in str(sub["loss_tags"]).split(","):
+        if tag == "deaths":
+            continue
+        total = {n: 0.0 for n in names}
+        gs, gi, gt = torch.zeros(A), torch.zeros(A), torch.zeros(A)
+        gc, gx = (w_cur, w_nxt) if tag == "stage_lin" else (torch.zeros(A).double(), torch.zeros(A).double())
+        for i in reversed(range(T)):
+            pre = {k: torch.from_numpy(sub[f"step{i}/sym/pre/{k}"]) for k in ("current_stage", "next_stage", "time_to_next_stage")}
+            if tag.startswith("occupancy"):
+                k = int(tag[9:])
+                gc = gc + (torch.from_numpy(sub[f"step{i}/sym/post/current_stage"]) == k).double() / k
+            s = infos[i]
+            gc, gx, gnew = O.adjoint_symptoms(pre["current_stage"], pre["next_stage"], pre["time_to_next_stage"],
+                                              states[i]["new_infected"], s["now"], n_stages,
+                                              torch.from_numpy(sub[f"step{i}/sym/progresses"]), gc, gx)
+            gs, gi, gt, glb, _ = O.adjoint_step(world, states[i], now=s["now"], delta_time=s["dt"], day_type=s["day_type"],
+                                                active=s["active"], betas=s["betas"], leisure_tables=tables,
+                                                quarantine_thresholds=s["thr"], exp_noise=s["noise"],
+                                                g_susc=gs, g_inf=gi, g_time=gt, g_new=gnew)
+            for n, v in glb.items():
+                total[n] += v
+        for n in names:
+            assert total[n] == pytest.approx(float(sub[f"grad_{tag}/{n}"]), rel=1e-3, abs=1e-5), (tag, n)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -203,3 +321,88 @@ def test_gradient_is_zero_for_network_not_attended(device):
     gs, gc = torch.autograd.grad(cases[k[0]], [nets["school"].log_beta, nets["company"].log_beta], allow_unused=True)
     assert gs is not None and gs != 0.0
     assert gc is None or gc == 0.0
+
+
+@pytest.mark.gpu
+def test_hip_symptoms_adjoint_matches_oracle(device):
+    """gj_adjoint_symptoms against the hand-written CPU adjoint, with injected and with Philox randomness."""
+    import ctypes as C
+
+    import grad_june_amd as G
+    from grad_june_amd import _native as N
+    from grad_june_amd.defaults import default_parameters
+
+    g = torch.Generator().manual_seed(11)
+    n = 50_000
+    upd = G.SymptomsUpdater.from_parameters(default_parameters(str(device)))
+    n_stages = len(upd.symptoms_sampler.stages)
+    cur = torch.randint(0, n_stages, (n,), generator=g).float()
+    nxt = torch.randint(0, n_stages, (n,), generator=g).float()
+    ttn = torch.rand(n, generator=g) * 10
+    new = (torch.rand(n, generator=g) < 0.2).float()
+    age = torch.randint(0, 100, (n,), generator=g)
+    g_cur, g_nxt = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    for inject in (True, False):
+        d = G.HeteroData()
+        d["agent"].age, d["agent"].sex = age.to(device), torch.zeros(n, dtype=torch.long, device=device)
+        c0, x0, t0 = (t.clone().to(device).requires_grad_(k < 2) for k, t in enumerate((cur, nxt, ttn)))
+        d["agent"].symptoms = {"current_stage": c0, "next_stage": x0, "time_to_next_stage": t0}
+        nw = new.clone().to(device).requires_grad_()
+        if inject:
+            progresses = (torch.rand(n, generator=g) < 0.5).float()
+            sym = upd(d, type("T", (), {"now": 5.0})(), nw, progresses=progresses, dwell=torch.ones(n))
+        else:
+            sym = upd(d, type("T", (), {"now": 5.0})(), nw)
+            # the branch the kernel's Philox draw took, read off the forward result: next = next + 1 <=> onward
+            moved = (sym["current_stage"].detach().cpu() != cur) | ((5.0 >= ttn + new * (5.0 - ttn)) & (cur < n_stages - 1))
+            x1 = nxt + new * (2.0 - nxt)
+            progresses = (sym["next_stage"].detach().cpu() == x1 + 1).float()
+        loss = (sym["current_stage"] * g_cur.to(device)).sum() + (sym["next_stage"] * g_nxt.to(device)).sum()
+        got = torch.autograd.grad(loss, (c0, x0, nw))
+        ref = O.adjoint_symptoms(cur, nxt, ttn, new, 5.0, n_stages, progresses, g_cur, g_nxt)
+        for a, b, what in zip(got, ref, ("current_stage", "next_stage", "new_infected")):
+            assert torch.allclose(a.cpu(), b.float(), rtol=1e-5, atol=1e-6), (inject, what)
+
+
+@pytest.mark.gpu
+def test_hip_backward_through_symptoms_matches_reference(device):
+    """g3 on the GPU: hot path + symptoms as autograd nodes for 12 steps, the reference's randomness injected;
+    the stage-dependent losses (occupancy sums in the deaths series' form, a random linear form of the final
+    stages) give the reference's gradients w.r.t. every log_beta."""
+    import grad_june_amd as G
+    from grad_june_amd.defaults import default_parameters
+
+    sub, world, tables, names = load_case("g3")
+    params = default_parameters(str(device))
+    for n in params["networks"]:
+        params["networks"][n]["log_beta"] += 0.7
+    model, timer = G.GradJune.from_parameters(params), G.Timer.from_parameters(params)
+    data = _hetero(G, sub, world, device)
+    data["agent"].symptoms = {k: torch.from_numpy(sub["state0/sym/" + k]).to(device)
+                              for k in ("current_stage", "next_stage", "time_to_next_stage")}
+    for n in names:
+        net = model.infection_networks.networks[n]
+        net.log_beta = torch.nn.Parameter(net.log_beta.detach().clone())
+    n_stages = sub["sym_table"].shape[0]
+    occupancy = {k: [] for k in range(2, n_stages)}
+    for i in range(int(sub["n_steps"])):
+        s = step_info(sub, i)
+        next(timer)
+        assert timer.now == s["now"]
+        new, _ = model.hot_path(data, timer, exp_noise=s["noise"])
+        assert np.array_equal(data["agent"].is_infected.detach().cpu().numpy(), s["is_infected"]), i
+        sym = model.symptoms_updater(data, timer, new, progresses=torch.from_numpy(sub[f"step{i}/sym/progresses"]),
+                                     dwell=torch.from_numpy(sub[f"step{i}/sym/dwell"]))
+        for k in ("current_stage", "next_stage", "time_to_next_stage"):
+            assert np.array_equal(sym[k].detach().cpu().numpy(), sub[f"step{i}/sym/post/{k}"]), (i, k)
+        assert sym["current_stage"].requires_grad and not sym["time_to_next_stage"].requires_grad
+        for k in occupancy:
+            occupancy[k].append(occupancy_of(sym["current_stage"], k))
+    plist = [model.infection_networks.networks[n].log_beta for n in names]
+    for tag, loss in symptom_losses(sub, data["agent"].symptoms, occupancy).items():
+        assert float(loss.detach()) == pytest.approx(float(sub["loss_" + tag]), rel=1e-6)
+        grads = torch.autograd.grad(loss, plist, retain_graph=True, allow_unused=True)
+        for n, g in zip(names, grads):
+            got = 0.0 if g is None else float(g)
+            ref = float(sub[f"grad_{tag}/{n}"])
+            assert got == pytest.approx(ref, rel=3e-3, abs=1e-4), (tag, n, got, ref)
