@@ -453,10 +453,13 @@ struct SymptomsAdjointArgs {
   const float* nxt0;
   const float* ttn0;
   const float* progresses;
+  const float* dwell;
   const float* g_cur;
   const float* g_nxt;
+  const float* g_ttn;
   float* g_cur_in;
   float* g_nxt_in;
+  float* g_ttn_in;
   float* g_new;
 };
 
@@ -476,15 +479,22 @@ __global__ __launch_bounds__(kThreads) void k_adjoint_symptoms(const SymptomsAdj
   s = min(max(s, 0), n_stages - 1);
   float gc1 = S.g_cur ? S.g_cur[a] : 0.0f;
   float gx1 = S.g_nxt ? S.g_nxt[a] : 0.0f;
+  const float gt1 = S.g_ttn ? S.g_ttn[a] : 0.0f;
   if (moving && s >= 2 && s <= n_stages - 2 && c1 == (float)s) {
     bool onward;
+    float d;
     if (S.progresses) {
       onward = S.progresses[a] != 0.0f;
+      d = S.dwell[a];
     } else {
       uint32_t r[4];
       philox4x32_10((uint64_t)(S.P.agent_offset + a), S.P.step | (1ull << 63), S.P.seed, r);
       onward = u01(r[0]) < S.P.progress[s * 100 + (S.cls[a] % 100)];
+      const float z = sqrtf(-2.0f * logf(u01(r[1]))) * cosf(6.2831853071795865f * u01(r[2]));
+      d = onward ? dwell_sample(S.P.next_kind[s], S.P.next_loc[s], S.P.next_scale[s], z)
+                 : dwell_sample(S.P.rec_kind[s], S.P.rec_loc[s], S.P.rec_scale[s], z);
     }
+    gc1 += gt1 * d / (float)s;              // time += dwell * (current == s) * current / s  (either branch)
     if (onward) {
       gc1 += gx1 / (float)s;                // next += (current == s) * current / s
     } else {
@@ -495,7 +505,8 @@ __global__ __launch_bounds__(kThreads) void k_adjoint_symptoms(const SymptomsAdj
   gx1 += gc1 * m;                           // current -= (current - next) * moving
   S.g_cur_in[a] = gc1 * (1.0f - m);
   S.g_nxt_in[a] = gx1 * (1.0f - nw);        // next += new_infected * (2 - next)
-  S.g_new[a] = gx1 * (2.0f - x0);
+  if (S.g_ttn_in) S.g_ttn_in[a] = gt1 * (1.0f - nw);   // time += new_infected * (now - time)
+  S.g_new[a] = gx1 * (2.0f - x0) + gt1 * (time - t0);
 }
 
 // f3: elementwise adjoints (see include/gradjune_hip.h)
@@ -1145,15 +1156,16 @@ int gj_symptoms_update(int64_t n, const uint8_t* agent_class, const float* new_i
 
 int gj_adjoint_symptoms(int64_t n, const uint8_t* agent_class, const float* new_infected,
                         const float* current_stage0, const float* next_stage0, const float* time_to_next_stage0,
-                        const gj_symptoms_params* params, const float* progresses, const float* g_current,
-                        const float* g_next, float* g_current_in, float* g_next_in, float* g_new_infected,
-                        void* stream) {
+                        const gj_symptoms_params* params, const float* progresses, const float* dwell,
+                        const float* g_current, const float* g_next, const float* g_time, float* g_current_in,
+                        float* g_next_in, float* g_time_in, float* g_new_infected, void* stream) {
   if (n < 0) return GJ_E_RANGE;
   if (n == 0) return GJ_OK;
   if (!agent_class || !new_infected || !current_stage0 || !next_stage0 || !time_to_next_stage0 || !params)
     return GJ_E_NULL;
   if (!g_current_in || !g_next_in || !g_new_infected) return GJ_E_NULL;
   if (params->n_stages < 3 || params->n_stages > GJ_MAX_STAGES) return GJ_E_RANGE;
+  if ((progresses == nullptr) != (dwell == nullptr)) return GJ_E_NULL;   // inject both or neither
   if (!progresses && !params->progress) return GJ_E_NULL;
   gj::SymptomsAdjointArgs S;
   S.P = *params;
@@ -1164,10 +1176,13 @@ int gj_adjoint_symptoms(int64_t n, const uint8_t* agent_class, const float* new_
   S.nxt0 = next_stage0;
   S.ttn0 = time_to_next_stage0;
   S.progresses = progresses;
+  S.dwell = dwell;
   S.g_cur = g_current;
   S.g_nxt = g_next;
+  S.g_ttn = g_time;
   S.g_cur_in = g_current_in;
   S.g_nxt_in = g_next_in;
+  S.g_ttn_in = g_time_in;
   S.g_new = g_new_infected;
   hipLaunchKernelGGL(gj::k_adjoint_symptoms, dim3((unsigned)((n + gj::kThreads - 1) / gj::kThreads)),
                      dim3(gj::kThreads), 0, (hipStream_t)stream, S);

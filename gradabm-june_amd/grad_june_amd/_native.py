@@ -188,7 +188,7 @@ SYMBOLS = {
     ),
     "gj_adjoint_symptoms": (
         C.c_int,
-        [C.c_int64, _vp, _vp, _vp, _vp, _vp, C.POINTER(SymptomsParams), _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+        [C.c_int64, _vp, _vp, _vp, _vp, _vp, C.POINTER(SymptomsParams)] + [_vp] * 10,
     ),
     "gj_step_stats": (C.c_int, [C.c_int64, _vp, _vp, _vp, C.c_int32, C.POINTER(C.c_int32), C.c_int32, _vp, _vp]),
     "gj_step": (C.c_int, [C.POINTER(Plan), C.POINTER(AgentState), C.POINTER(StepParams), C.POINTER(StepIO), _vp]),

@@ -133,7 +133,8 @@ class HotPathStep(torch.autograd.Function):
 class SymptomsStep(torch.autograd.Function):
     """(new_infected, current_stage, next_stage, time_to_next_stage) -> the three updated arrays, with the
     reference's gradient paths (symptoms.py:98,105-124,231-236): a loss on the stages - the deaths series of
-    runner.py:198-215 - reaches ``log_beta`` through ``new_infected``.  Forward = ``gj_symptoms_update`` on
+    runner.py:198-215 - reaches ``log_beta`` through ``new_infected``.  All three outputs carry a gradient,
+    as test_symptoms.py:208-231 expects.  Forward = ``gj_symptoms_update`` on
     fresh tensors; backward = ``gj_adjoint_symptoms`` replaying the branch each agent took."""
 
     @staticmethod
@@ -149,13 +150,13 @@ class SymptomsStep(torch.autograd.Function):
                 "gj_symptoms_update")
         snap = N.SymptomsParams()                       # the caller reuses its struct: keep this call's clock / key
         C.memmove(C.byref(snap), C.byref(p), C.sizeof(N.SymptomsParams))
-        ctx.env = {"cls": env["cls"], "progresses": env["progresses"], "params": snap, "table": env.get("table")}
+        ctx.env = {"cls": env["cls"], "progresses": env["progresses"], "dwell": env["dwell"], "params": snap,
+                   "table": env.get("table")}
         ctx.save_for_backward(nw, cur0, nxt0, ttn0)
-        ctx.mark_non_differentiable(out_t)
         return out_c, out_x, out_t
 
     @staticmethod
-    def backward(ctx, g_cur, g_nxt, _g_ttn):
+    def backward(ctx, g_cur, g_nxt, g_ttn):
         nw, cur0, nxt0, ttn0 = ctx.saved_tensors
         env = ctx.env
         n = nw.numel()
@@ -163,10 +164,11 @@ class SymptomsStep(torch.autograd.Function):
         def f32(g):
             return None if g is None else g.detach().to(torch.float32).contiguous()
 
-        g_cur, g_nxt = f32(g_cur), f32(g_nxt)
-        g_cur_in, g_nxt_in, g_new = (torch.empty_like(nw) for _ in range(3))
+        g_cur, g_nxt, g_ttn = f32(g_cur), f32(g_nxt), f32(g_ttn)
+        g_cur_in, g_nxt_in, g_ttn_in, g_new = (torch.empty_like(nw) for _ in range(4))
         N.check(N.load().gj_adjoint_symptoms(n, N.ptr(env["cls"]), N.ptr(nw), N.ptr(cur0), N.ptr(nxt0), N.ptr(ttn0),
-                                             C.byref(env["params"]), N.ptr(env["progresses"]), N.ptr(g_cur),
-                                             N.ptr(g_nxt), N.ptr(g_cur_in), N.ptr(g_nxt_in), N.ptr(g_new),
-                                             N.current_stream()), "gj_adjoint_symptoms")
-        return None, g_new, g_cur_in, g_nxt_in, None
+                                             C.byref(env["params"]), N.ptr(env["progresses"]), N.ptr(env["dwell"]),
+                                             N.ptr(g_cur), N.ptr(g_nxt), N.ptr(g_ttn), N.ptr(g_cur_in),
+                                             N.ptr(g_nxt_in), N.ptr(g_ttn_in), N.ptr(g_new), N.current_stream()),
+                "gj_adjoint_symptoms")
+        return None, g_new, g_cur_in, g_nxt_in, g_ttn_in

@@ -152,8 +152,8 @@ class SymptomsUpdater(torch.nn.Module):
         if progresses is not None:
             progresses = progresses.to(device=device, dtype=torch.float32).contiguous()
             dwell = dwell.to(device=device, dtype=torch.float32).contiguous()
-        if torch.is_grad_enabled() and (new_infected.requires_grad or symptoms["current_stage"].requires_grad
-                                        or symptoms["next_stage"].requires_grad):
+        if torch.is_grad_enabled() and (new_infected.requires_grad or any(
+                symptoms[k].requires_grad for k in ("current_stage", "next_stage", "time_to_next_stage"))):
             # row f3: the update as an autograd node, so that a loss on the stages (deaths) reaches log_beta
             from .autograd import SymptomsStep
 

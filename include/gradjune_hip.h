@@ -320,18 +320,21 @@ int gj_adjoint_sample(int64_t n, const float* susceptibility0, const float* infe
 int gj_adjoint_transmission(int64_t n, const gj_agent_state* state0, float now, const float* trans_bar,
                             const float* g_inf, float* grad_inf_out, float* grad_time_inout, void* stream);
 
-/* gj_adjoint_symptoms: adjoint of gj_symptoms_update w.r.t. the stage values and new_infected - what
- * makes a loss on the symptom stages (the deaths series, grad_june/runner.py:198-215; asserted to carry
- * a gradient by test/unit/test_runner.py:82-90) differentiable w.r.t. log_beta.  Inputs: the PRE-update
- * current / next stage and time_to_next_stage, new_infected, the SAME params (time, seed, step) or the
- * same injected `progresses`, and the gradients w.r.t. the updated current / next stage (NULL = 0).
- * Outputs (each [n]): gradients w.r.t. the incoming current stage, next stage and new_infected.  The
- * gradient paths are those of symptoms.py:98,105-124,231-236; times carry none.                     */
+/* gj_adjoint_symptoms: adjoint of gj_symptoms_update - what makes a loss on the symptom stages (the
+ * deaths series, grad_june/runner.py:198-215; test/unit/test_runner.py:82-90 and
+ * test_symptoms.py:208-231 assert the gradient exists) differentiable w.r.t. log_beta.  Inputs: the
+ * PRE-update current / next stage and time_to_next_stage, new_infected, the SAME params (time, seed,
+ * step) or the same injected `progresses` + `dwell`, and the gradients w.r.t. the updated current /
+ * next stage / time (each may be NULL = 0).  Outputs ([n] each; g_time_in may be NULL): gradients
+ * w.r.t. the incoming current stage, next stage, time_to_next_stage and w.r.t. new_infected.  The
+ * gradient paths are those of symptoms.py:98,105-124,231-236: next += new*(2-next), time +=
+ * new*(now-time), current -= (current-next)*mask, and the value-1 factor (current==i)*current/i on
+ * the +1 / -next updates of next_stage and on the dwell time added to time_to_next_stage.          */
 int gj_adjoint_symptoms(int64_t n, const uint8_t* agent_class, const float* new_infected,
                         const float* current_stage0, const float* next_stage0, const float* time_to_next_stage0,
-                        const gj_symptoms_params* params, const float* progresses, const float* g_current,
-                        const float* g_next, float* g_current_in, float* g_next_in, float* g_new_infected,
-                        void* stream);
+                        const gj_symptoms_params* params, const float* progresses, const float* dwell,
+                        const float* g_current, const float* g_next, const float* g_time, float* g_current_in,
+                        float* g_next_in, float* g_time_in, float* g_new_infected, void* stream);
 
 /* The production step: a1..a9 = the middle of GradJune.forward (grad_june/model.py:125-138)
  * as three dependent launches on `stream` (+1 when the plan has long rows).                */

@@ -232,16 +232,18 @@ def symptoms_update(age, current_stage, next_stage, time_to_next_stage, new_infe
 
 
 def adjoint_symptoms(current_stage, next_stage, time_to_next_stage, new_infected, time, n_stages: int,
-                     progresses, g_cur, g_nxt):
+                     progresses, g_cur, g_nxt, g_ttn=None, dwell=None):
     """Hand-written adjoint of symptoms_update (what gj_adjoint_symptoms computes): given the gradients
-    w.r.t. the OUTPUT current / next stage, those w.r.t. the INPUT current / next stage and new_infected.
-    The only gradient paths of symptoms.py:82-128, 231-236 are next_stage += new_infected * (2 - next_stage),
-    the transition current -= (current - next) * mask and the value-1 factor ``(current == i) * current / i``
-    that multiplies the +1 (onward) / -next (recover) updates of next_stage; times carry no gradient to a
-    stage (they only enter comparisons)."""
+    w.r.t. the OUTPUT current / next stage / time, those w.r.t. the INPUT current / next stage / time and
+    new_infected.  The gradient paths of symptoms.py:82-128, 231-236 are next += new_infected * (2 - next),
+    time += new_infected * (now - time), the transition current -= (current - next) * mask and the value-1
+    factor ``(current == i) * current / i`` that multiplies the +1 (onward) / -next (recover) updates of
+    next_stage and the dwell time added to time_to_next_stage; times never feed a stage (comparisons only)."""
     f64 = torch.float64
     c0, x0, t0, nw = (v.to(f64) for v in (current_stage, next_stage, time_to_next_stage, new_infected))
     g_cur, g_nxt = g_cur.to(f64), g_nxt.to(f64)
+    g_ttn = torch.zeros_like(g_cur) if g_ttn is None else g_ttn.to(f64)
+    d = torch.zeros_like(g_cur) if dwell is None else dwell.to(f64)
     x1 = x0 + nw * (2.0 - x0)
     t1 = t0 + nw * (time - t0)
     moving = (time >= t1) & (c0 < n_stages - 1)
@@ -252,11 +254,12 @@ def adjoint_symptoms(current_stage, next_stage, time_to_next_stage, new_infected
     onward = progresses.to(torch.bool)
     sf = s.to(f64).clamp(min=1.0)
     zero = torch.zeros_like(g_cur)
-    gc1 = g_cur + torch.where(at & onward, g_nxt / sf, zero) - torch.where(at & ~onward, g_nxt * x1 / sf, zero)
+    gc1 = (g_cur + torch.where(at, g_ttn * d / sf, zero) + torch.where(at & onward, g_nxt / sf, zero)
+           - torch.where(at & ~onward, g_nxt * x1 / sf, zero))
     gx1 = torch.where(at & ~onward, zero, g_nxt)
     g_cur_in = gc1 * (1.0 - m)
     gx1 = gx1 + gc1 * m
-    return g_cur_in, gx1 * (1.0 - nw), gx1 * (2.0 - x0)
+    return g_cur_in, gx1 * (1.0 - nw), g_ttn * (1.0 - nw), gx1 * (2.0 - x0) + g_ttn * (time - t0)
 
 
 def symptoms_progress_probability(table, age, current_stage, next_stage, time_to_next_stage, new_infected, time,

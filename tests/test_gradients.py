@@ -156,17 +156,18 @@ def test_handwritten_symptoms_adjoint_matches_autograd():
     n, n_stages = 4000, 8
     cur = torch.randint(0, n_stages, (n,), generator=g).float().requires_grad_()
     nxt = torch.randint(0, n_stages, (n,), generator=g).float().requires_grad_()
-    ttn = torch.rand(n, generator=g) * 10
+    ttn = (torch.rand(n, generator=g) * 10).requires_grad_()
     new = (torch.rand(n, generator=g) < 0.2).float().requires_grad_()
     progresses = (torch.rand(n, generator=g) < 0.5).float()
     dwell = torch.rand(n, generator=g) * 5
     age = torch.randint(0, 100, (n,), generator=g)
-    c, x, _ = O.symptoms_update(age, cur, nxt, ttn, new, 5.0, n_stages, progresses, dwell)
-    g_cur, g_nxt = torch.randn(n, generator=g), torch.randn(n, generator=g)
-    ref = torch.autograd.grad((c * g_cur).sum() + (x * g_nxt).sum(), (cur, nxt, new))
-    got = O.adjoint_symptoms(cur.detach(), nxt.detach(), ttn, new.detach(), 5.0, n_stages, progresses, g_cur, g_nxt)
-    for a, b, what in zip(got, ref, ("current_stage", "next_stage", "new_infected")):
-        assert torch.allclose(a.float(), b, rtol=1e-6, atol=1e-6), what
+    c, x, t = O.symptoms_update(age, cur, nxt, ttn, new, 5.0, n_stages, progresses, dwell)
+    g_cur, g_nxt, g_ttn = (torch.randn(n, generator=g) for _ in range(3))
+    ref = torch.autograd.grad((c * g_cur).sum() + (x * g_nxt).sum() + (t * g_ttn).sum(), (cur, nxt, ttn, new))
+    got = O.adjoint_symptoms(cur.detach(), nxt.detach(), ttn.detach(), new.detach(), 5.0, n_stages, progresses,
+                             g_cur, g_nxt, g_ttn, dwell)
+    for a, b, what in zip(got, ref, ("current_stage", "next_stage", "time_to_next_stage", "new_infected")):
+        assert torch.allclose(a.float(), b, rtol=1e-5, atol=1e-5), what
 
 
 def test_handwritten_adjoint_through_symptoms_matches_reference():
@@ -200,9 +201,9 @@ def test_handwritten_adjoint_through_symptoms_matches_reference():
                 k = int(tag[9:])
                 gc = gc + (torch.from_numpy(sub[f"step{i}/sym/post/current_stage"]) == k).double() / k
             s = infos[i]
-            gc, gx, gnew = O.adjoint_symptoms(pre["current_stage"], pre["next_stage"], pre["time_to_next_stage"],
-                                              states[i]["new_infected"], s["now"], n_stages,
-                                              torch.from_numpy(sub[f"step{i}/sym/progresses"]), gc, gx)
+            gc, gx, _, gnew = O.adjoint_symptoms(pre["current_stage"], pre["next_stage"], pre["time_to_next_stage"],
+                                                 states[i]["new_infected"], s["now"], n_stages,
+                                                 torch.from_numpy(sub[f"step{i}/sym/progresses"]), gc, gx)
             gs, gi, gt, glb, _ = O.adjoint_step(world, states[i], now=s["now"], delta_time=s["dt"], day_type=s["day_type"],
                                                 active=s["active"], betas=s["betas"], leisure_tables=tables,
                                                 quarantine_thresholds=s["thr"], exp_noise=s["noise"],
@@ -341,27 +342,31 @@ def test_hip_symptoms_adjoint_matches_oracle(device):
     ttn = torch.rand(n, generator=g) * 10
     new = (torch.rand(n, generator=g) < 0.2).float()
     age = torch.randint(0, 100, (n,), generator=g)
-    g_cur, g_nxt = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    g_cur, g_nxt, g_ttn = (torch.randn(n, generator=g) for _ in range(3))
     for inject in (True, False):
         d = G.HeteroData()
         d["agent"].age, d["agent"].sex = age.to(device), torch.zeros(n, dtype=torch.long, device=device)
-        c0, x0, t0 = (t.clone().to(device).requires_grad_(k < 2) for k, t in enumerate((cur, nxt, ttn)))
+        c0, x0, t0 = (t.clone().to(device).requires_grad_() for t in (cur, nxt, ttn))
         d["agent"].symptoms = {"current_stage": c0, "next_stage": x0, "time_to_next_stage": t0}
         nw = new.clone().to(device).requires_grad_()
         if inject:
             progresses = (torch.rand(n, generator=g) < 0.5).float()
-            sym = upd(d, type("T", (), {"now": 5.0})(), nw, progresses=progresses, dwell=torch.ones(n))
+            dwell = torch.rand(n, generator=g) * 5
+            sym = upd(d, type("T", (), {"now": 5.0})(), nw, progresses=progresses, dwell=dwell)
         else:
             sym = upd(d, type("T", (), {"now": 5.0})(), nw)
-            # the branch the kernel's Philox draw took, read off the forward result: next = next + 1 <=> onward
-            moved = (sym["current_stage"].detach().cpu() != cur) | ((5.0 >= ttn + new * (5.0 - ttn)) & (cur < n_stages - 1))
+            # the branch and the dwell time of the kernel's Philox draw, read off the forward result
             x1 = nxt + new * (2.0 - nxt)
+            t1 = ttn + new * (5.0 - ttn)
             progresses = (sym["next_stage"].detach().cpu() == x1 + 1).float()
-        loss = (sym["current_stage"] * g_cur.to(device)).sum() + (sym["next_stage"] * g_nxt.to(device)).sum()
-        got = torch.autograd.grad(loss, (c0, x0, nw))
-        ref = O.adjoint_symptoms(cur, nxt, ttn, new, 5.0, n_stages, progresses, g_cur, g_nxt)
-        for a, b, what in zip(got, ref, ("current_stage", "next_stage", "new_infected")):
-            assert torch.allclose(a.cpu(), b.float(), rtol=1e-5, atol=1e-6), (inject, what)
+            dwell = sym["time_to_next_stage"].detach().cpu() - t1
+        assert all(sym[k].requires_grad for k in sym)                      # test_symptoms.py:225-231
+        loss = ((sym["current_stage"] * g_cur.to(device)).sum() + (sym["next_stage"] * g_nxt.to(device)).sum()
+                + (sym["time_to_next_stage"] * g_ttn.to(device)).sum())
+        got = torch.autograd.grad(loss, (c0, x0, t0, nw))
+        ref = O.adjoint_symptoms(cur, nxt, ttn, new, 5.0, n_stages, progresses, g_cur, g_nxt, g_ttn, dwell)
+        for a, b, what in zip(got, ref, ("current_stage", "next_stage", "time_to_next_stage", "new_infected")):
+            assert torch.allclose(a.cpu(), b.float(), rtol=1e-4, atol=1e-4), (inject, what)
 
 
 @pytest.mark.gpu
@@ -395,7 +400,7 @@ def test_hip_backward_through_symptoms_matches_reference(device):
                                      dwell=torch.from_numpy(sub[f"step{i}/sym/dwell"]))
         for k in ("current_stage", "next_stage", "time_to_next_stage"):
             assert np.array_equal(sym[k].detach().cpu().numpy(), sub[f"step{i}/sym/post/{k}"]), (i, k)
-        assert sym["current_stage"].requires_grad and not sym["time_to_next_stage"].requires_grad
+        assert sym["current_stage"].requires_grad and sym["time_to_next_stage"].requires_grad
         for k in occupancy:
             occupancy[k].append(occupancy_of(sym["current_stage"], k))
     plist = [model.infection_networks.networks[n].log_beta for n in names]

@@ -185,3 +185,39 @@ def test_full_timestep_chain_matches_reference(device, name):
             for k in ("current_stage", "next_stage", "time_to_next_stage"):
                 assert np.array_equal(ag.symptoms[k].cpu().numpy(), rec["sym_post/" + k]), (i, k)
     assert float(ag.is_infected.sum()) == float(npz["cases_per_timestep"][-1])
+
+
+@pytest.mark.gpu
+def test_symptoms_differentiable(device):
+    """test_symptoms.py:208-231 of the reference: new_infected from a hard Gumbel-softmax on a parameter,
+    mortality raised to 1, 100 further steps - the dead agents' stage carries a gradient back to beta and
+    all three symptom arrays stay on the autograd graph."""
+    import grad_june_amd as G
+    from grad_june_amd.defaults import default_parameters
+
+    torch.manual_seed(0)
+    params = default_parameters(str(device))
+    su = G.SymptomsUpdater.from_parameters(params)
+    su.symptoms_sampler.stage_transition_probabilities[2:, :] = 1.0
+    timer = G.Timer.from_parameters(params)
+    n = 100
+    d = G.HeteroData()
+    d["agent"].id = torch.arange(n, device=device)
+    d["agent"].age = torch.randint(0, 100, (n,), device=device)
+    d["agent"].sex = torch.zeros(n, dtype=torch.long, device=device)
+    d["agent"].symptoms = {"current_stage": torch.ones(n, device=device), "next_stage": torch.ones(n, device=device),
+                           "time_to_next_stage": torch.zeros(n, device=device)}
+    beta = torch.nn.Parameter(torch.tensor(10.0, device=device))
+    probs = 1 - torch.exp(-beta) * torch.ones(n, device=device)
+    new_infected = torch.nn.functional.gumbel_softmax(probs, tau=0.1, hard=True)
+    symptoms = su(data=d, timer=timer, new_infected=new_infected)
+    for _ in range(100):
+        next(timer)
+        symptoms = su(data=d, timer=timer, new_infected=torch.zeros(n, device=device))
+    dead = float(su.stages_ids[-1])
+    deaths = symptoms["current_stage"][symptoms["current_stage"] == dead]
+    assert len(deaths) > 0
+    deaths.sum().backward()
+    assert deaths.requires_grad
+    assert all(symptoms[k].requires_grad for k in ("current_stage", "next_stage", "time_to_next_stage"))
+    assert beta.grad is not None and torch.isfinite(beta.grad)
