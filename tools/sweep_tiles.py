@@ -50,7 +50,8 @@ def main():
         run("default")
         for sa in [int(x) for x in os.environ.get("GJ_SA", "19584").split(",")]:
             for eb in [int(x) for x in os.environ.get("GJ_EB", "131072").split(",")]:
-                run(f"SA={sa} EB={eb}", slices=sl(sa), eb_target=eb)
+                for sv in [int(x) for x in os.environ.get("GJ_SV", "16384").split(",")]:
+                    run(f"SA={sa} EB={eb} SV={sv}", slices=sl(sa), eb_target=eb, sv_max=sv)
         return
     if os.environ.get("GJ_SWEEP", "geometry") == "geometry":
         run("default")
