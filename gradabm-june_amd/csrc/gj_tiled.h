@@ -47,7 +47,7 @@ struct TSetA {            // what phases A and D need of one set
   int32_t J;
   int32_t active;         // networks active on the set in this step (0: skip)
   int32_t raw;            // 1: reads raw transmission / susceptibility weight (household)
-  int32_t _pad;
+  int32_t wide;           // chunk_desc holds two int4 per chunk (up to 6 tiles per chunk), see tiling.py
 };
 
 struct TileAArgs {
@@ -84,6 +84,116 @@ __device__ __noinline__ int chunk_slot_slow(const TSetA& T, const int4 d, int ro
   return T.tile_jpos[row + j] + (i - T.tile_sptr[row + j]);
 }
 
+// Wide descriptors (sets with small tiles): d0 = base_0..3, d1 = base_4, base_5, start_1..4 (bytes),
+// start_5 | multi << 8 | j0 << 9.  Lanes [start_k, start_k+1) of the chunk map to slots base_k + lane.
+__device__ __forceinline__ int chunk_slot_wide(const int4 d0, const int4 d1, int lane) {
+  int b = d0.x;
+  b = (lane >= (d1.z & 0xFF)) ? d0.y : b;
+  b = (lane >= ((d1.z >> 8) & 0xFF)) ? d0.z : b;
+  b = (lane >= ((d1.z >> 16) & 0xFF)) ? d0.w : b;
+  b = (lane >= ((d1.z >> 24) & 0xFF)) ? d1.x : b;
+  b = (lane >= (d1.w & 0xFF)) ? d1.y : b;
+  return b + lane;
+}
+// More than six tiles in one chunk (tiles of a few edges): walk the tile tables from block j0.
+__device__ __noinline__ int chunk_slot_walk(const TSetA& T, int row, int i, int j) {
+  while (i >= T.tile_sptr[row + j + 1]) ++j;
+  return T.tile_jpos[row + j] + (i - T.tile_sptr[row + j]);
+}
+
+// One batch of chunks of a set: the block-major slot of this lane's edge in each of them.  Straight-line
+// (clamped, unconditional loads) so that the whole batch is in flight; a wave-uniform branch takes the
+// table walk for batches that contain a chunk the descriptor cannot express.
+template <bool WIDE, int U>
+__device__ __forceinline__ void batch_slots(const TSetA& T, int row, int seg0, int seg1, int c_base, int n_chunks,
+                                            int c0, int lane, int (&slot)[U]) {
+  if (!WIDE) {
+    int4 d[U];
+    int multi = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      d[u] = T.chunk_desc[c_base + min(c0 + u, n_chunks - 1)];
+      multi |= d[u].z;
+    }
+    if (__builtin_amdgcn_readfirstlane(multi >> 16) == 0) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) slot[u] = chunk_slot_fast(d[u], lane);
+    } else {
+      for (int u = 0; u < U; ++u) {
+        const int i = min(seg0 + (c0 + u) * kWave + lane, seg1 - 1);
+        slot[u] = (d[u].z >> 16) ? chunk_slot_slow(T, d[u], row, i, lane) : chunk_slot_fast(d[u], lane);
+      }
+    }
+  } else {
+    int4 d0[U], d1[U];
+    int multi = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c_base + min(c0 + u, n_chunks - 1);
+      d0[u] = T.chunk_desc[2 * c];
+      d1[u] = T.chunk_desc[2 * c + 1];
+      multi |= d1[u].w;
+    }
+    if (__builtin_amdgcn_readfirstlane(multi & 0x100) == 0) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) slot[u] = chunk_slot_wide(d0[u], d1[u], lane);
+    } else {
+      for (int u = 0; u < U; ++u) {
+        const int i = min(seg0 + (c0 + u) * kWave + lane, seg1 - 1);
+        slot[u] = (d1[u].w & 0x100) ? chunk_slot_walk(T, row, i, (int)((unsigned)d1[u].w >> 9))
+                                    : chunk_slot_wide(d0[u], d1[u], lane);
+      }
+    }
+  }
+}
+
+template <bool WIDE>
+__device__ __forceinline__ void scatter_set(const TSetA& T, const float* lds_x, int s, int wave, int lane) {
+  const int row = s * T.J;
+  const int seg0 = T.tile_sptr[row], seg1 = T.tile_sptr[row + T.J];
+  const int c_base = T.chunk_ptr[s];
+  const int n_chunks = T.chunk_ptr[s + 1] - c_base;
+  for (int c0 = wave * kUnroll; c0 < n_chunks; c0 += kTileWaves * kUnroll) {
+    int la[kUnroll], slot[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u)    // unconditional (clamped) loads: straight-line, all in flight
+      la[u] = T.a_la[min(seg0 + (c0 + u) * kWave + lane, seg1 - 1)];
+    batch_slots<WIDE, kUnroll>(T, row, seg0, seg1, c_base, n_chunks, c0, lane, slot);
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int i = seg0 + (c0 + u) * kWave + lane;
+      if ((c0 + u < n_chunks) && (i < seg1)) T.val[slot[u]] = lds_x[la[u]];
+    }
+  }
+}
+
+template <bool WIDE>
+__device__ __forceinline__ void gather_set(const TSetA& T, fx_t* lds_acc, int s, int wave, int lane) {
+  const int row = s * T.J;
+  const int seg0 = T.tile_sptr[row], seg1 = T.tile_sptr[row + T.J];
+  const int c_base = T.chunk_ptr[s];
+  const int n_chunks = T.chunk_ptr[s + 1] - c_base;
+  for (int c0 = wave * kUnroll; c0 < n_chunks; c0 += kTileWaves * kUnroll) {
+    int la[kUnroll], slot[kUnroll];
+    float v[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u)    // unconditional (clamped) loads: straight-line, all in flight
+      la[u] = T.a_la[min(seg0 + (c0 + u) * kWave + lane, seg1 - 1)];
+    batch_slots<WIDE, kUnroll>(T, row, seg0, seg1, c_base, n_chunks, c0, lane, slot);
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {  // the slot depends on the position only: these loads overlap the ones above
+      const int i = seg0 + (c0 + u) * kWave + lane;
+      const bool ok = (c0 + u < n_chunks) && (i < seg1);
+      v[u] = T.val[ok ? slot[u] : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int i = seg0 + (c0 + u) * kWave + lane;
+      if ((c0 + u < n_chunks) && (i < seg1)) atomicAdd(&lds_acc[la[u]], to_fx<kFxAgent>(v[u]));
+    }
+  }
+}
+
 // ---- phase A: scatter the slice's transmissions to every edge, in block-major tile order -------
 __global__ __launch_bounds__(kTileThreads) void k_tile_scatter(const TileAArgs A) {
   extern __shared__ __align__(16) float lds_x[];
@@ -106,37 +216,10 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_scatter(const TileAArgs A
     for (int t = 0; t < A.n_sets; ++t) {
       const TSetA& T = A.sets[t];
       if (!T.active || (two_sources && T.raw != pass)) continue;
-      const int row = s * T.J;
-      const int seg0 = T.tile_sptr[row], seg1 = T.tile_sptr[row + T.J];
-      const int c_base = T.chunk_ptr[s];
-      const int n_chunks = T.chunk_ptr[s + 1] - c_base;
-      for (int c0 = wave * kUnroll; c0 < n_chunks; c0 += kTileWaves * kUnroll) {
-        int la[kUnroll];
-        int4 d[kUnroll];
-        int multi = 0;
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {  // wave-uniform descriptors, all loads in flight together
-          d[u] = T.chunk_desc[c_base + min(c0 + u, n_chunks - 1)];
-          multi |= d[u].z;
-        }
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u)    // unconditional (clamped) loads: straight-line, all in flight
-          la[u] = T.a_la[min(seg0 + (c0 + u) * kWave + lane, seg1 - 1)];
-        if (__builtin_amdgcn_readfirstlane(multi >> 16) == 0) {
-#pragma unroll
-          for (int u = 0; u < kUnroll; ++u) {
-            const int i = seg0 + (c0 + u) * kWave + lane;
-            if ((c0 + u < n_chunks) && (i < seg1)) T.val[chunk_slot_fast(d[u], lane)] = lds_x[la[u]];
-          }
-        } else {
-          for (int u = 0; u < kUnroll; ++u) {
-            const int i = seg0 + (c0 + u) * kWave + lane;
-            if ((c0 + u < n_chunks) && (i < seg1)) {
-              const int slot = (d[u].z >> 16) ? chunk_slot_slow(T, d[u], row, i, lane) : chunk_slot_fast(d[u], lane);
-              T.val[slot] = lds_x[la[u]];
-            }
-          }
-        }
+      if (T.wide) {
+        scatter_set<true>(T, lds_x, s, wave, lane);
+      } else {
+        scatter_set<false>(T, lds_x, s, wave, lane);
       }
     }
   }
@@ -357,44 +440,10 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
     for (int t = 0; t < D.n_sets; ++t) {
       const TSetA& T = D.sets[t];
       if (!T.active || T.raw != pass) continue;
-      const int row = s * T.J;
-      const int seg0 = T.tile_sptr[row], seg1 = T.tile_sptr[row + T.J];
-      const int c_base = T.chunk_ptr[s];
-      const int n_chunks = T.chunk_ptr[s + 1] - c_base;
-      for (int c0 = wave * kUnroll; c0 < n_chunks; c0 += kTileWaves * kUnroll) {
-        int la[kUnroll];
-        float v[kUnroll];
-        int4 d[kUnroll];
-        int multi = 0;
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {  // wave-uniform descriptors, all loads in flight together
-          d[u] = T.chunk_desc[c_base + min(c0 + u, n_chunks - 1)];
-          multi |= d[u].z;
-        }
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u)    // unconditional (clamped) loads: straight-line, all in flight
-          la[u] = T.a_la[min(seg0 + (c0 + u) * kWave + lane, seg1 - 1)];
-        if (__builtin_amdgcn_readfirstlane(multi >> 16) == 0) {
-#pragma unroll
-          for (int u = 0; u < kUnroll; ++u) {  // the slot depends on the position only: loads overlap the ones above
-            const int i = seg0 + (c0 + u) * kWave + lane;
-            const bool ok = (c0 + u < n_chunks) && (i < seg1);
-            v[u] = T.val[ok ? chunk_slot_fast(d[u], lane) : 0];
-          }
-        } else {
-          for (int u = 0; u < kUnroll; ++u) {
-            const int i = seg0 + (c0 + u) * kWave + lane;
-            const bool ok = (c0 + u < n_chunks) && (i < seg1);
-            int slot = 0;
-            if (ok) slot = (d[u].z >> 16) ? chunk_slot_slow(T, d[u], row, i, lane) : chunk_slot_fast(d[u], lane);
-            v[u] = T.val[slot];
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-          const int i = seg0 + (c0 + u) * kWave + lane;
-          if ((c0 + u < n_chunks) && (i < seg1)) atomicAdd(&lds_acc[la[u]], to_fx<kFxAgent>(v[u]));
-        }
+      if (T.wide) {
+        gather_set<true>(T, lds_acc, s, wave, lane);
+      } else {
+        gather_set<false>(T, lds_acc, s, wave, lane);
       }
     }
     __syncthreads();

@@ -894,6 +894,7 @@ static void fill_set_a(const gj_plan* plan, const gj_step_params* p, const Group
     sets[s].J = S.n_blocks;
     sets[s].active = (S.n_blocks > 0 && plan->sets[s].n_edges > 0) ? G.nk[g] : 0;
     sets[s].raw = p->nets[G.first[g]].mask_kind == GJ_MASK_RAW;
+    sets[s].wide = S.desc_wide != 0;
   }
 }
 

@@ -44,6 +44,8 @@ class TiledSet(C.Structure):
     _fields_ = [
         ("n_blocks", C.c_int32),
         ("max_block_venues", C.c_int32),
+        ("desc_wide", C.c_int32),
+        ("_pad", C.c_int32),
         ("blk_v0", _vp),
         ("blk_e0", _vp),
         ("e_lv", _vp),

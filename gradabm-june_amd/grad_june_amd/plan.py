@@ -185,7 +185,7 @@ def save_plan(plan: HostPlan, path) -> None:
             for k in ("blk_v0", "blk_e0", "e_lv", "e_cls", "a_la", "tile_sptr", "tile_jpos", "chunk_ptr", "chunk_desc"):
                 if getattr(t, k) is not None:
                     out[p + "tiled/" + k] = getattr(t, k)
-            out[p + "tiled/meta"] = np.array([t.n_slices, t.n_blocks, t.n_slots], dtype=np.int64)
+            out[p + "tiled/meta"] = np.array([t.n_slices, t.n_blocks, t.n_slots, int(t.desc_wide)], dtype=np.int64)
     np.savez(path, **out)
 
 
@@ -200,13 +200,13 @@ def load_plan(path) -> HostPlan:
         hs = HostEdgeSet(name, int(a[p + "n_venues"]), int(a[p + "n_edges"]), a.get(p + "v_rowptr"), a.get(p + "v_agent"),
                          a[p + "v_pcontact"], a.get(p + "a_rowptr"), a.get(p + "a_venue"))
         if p + "tiled/meta" in a:
-            S, J, n_slots = (int(x) for x in a[p + "tiled/meta"])
+            S, J, n_slots, wide = (int(x) for x in a[p + "tiled/meta"])
             hs.tiled = TL.TiledEdgeSet(name=name, n_venues=hs.n_venues, n_edges=hs.n_edges, n_slices=S, n_blocks=J,
                                        blk_v0=a[p + "tiled/blk_v0"], blk_e0=a[p + "tiled/blk_e0"], e_lv=a[p + "tiled/e_lv"],
                                        e_cls=a.get(p + "tiled/e_cls"), a_la=a[p + "tiled/a_la"],
                                        tile_sptr=a[p + "tiled/tile_sptr"], tile_jpos=a[p + "tiled/tile_jpos"],
                                        v_pcontact=hs.v_pcontact, n_slots=n_slots, chunk_ptr=a[p + "tiled/chunk_ptr"],
-                                       chunk_desc=a[p + "tiled/chunk_desc"])
+                                       chunk_desc=a[p + "tiled/chunk_desc"], desc_wide=bool(wide))
         sets.append(hs)
     return HostPlan(int(a["meta/n_agents"]), int(a["meta/n_ext_agents"]), sets, a["agent_class"], a["blocks"],
                     a["long_rows"], int(a["meta/n_partial_slots"]), {s.name: i for i, s in enumerate(sets)},
@@ -226,12 +226,14 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
                  n_ext_agents: Optional[int] = None, block_order: str = "interleave",
                  layout: str = "csr", leisure_sets: Sequence[str] = ("leisure",),
                  sv_max: int = TL.SV_MAX, eb_target: Optional[int] = None, slices=None,
-                 nets_per_set: Optional[Dict[str, int]] = None, progress=None) -> HostPlan:
+                 nets_per_set: Optional[Dict[str, int]] = None, progress=None,
+                 desc_wide: Optional[bool] = None) -> HostPlan:
     """edge_sets: {name: {"agent": i64[E], "venue": i64[E], "people": [V]}} (insertion order = set ids).
 
     layout: "csr" (deterministic CSR kernels), "tiled" (LDS-tiled fast path) or "both".
     nets_per_set: infection networks that may be active on a set at once (a venue block keeps one
     8-byte LDS sum per venue and network; default 1, and 6 for the leisure sets).
+    desc_wide: chunk descriptor format of the tiled layout (None: per set, from its tile sizes).
     """
     if len(edge_sets) > N.GJ_MAX_SETS:
         raise ValueError(f"at most {N.GJ_MAX_SETS} edge sets")
@@ -254,7 +256,7 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
             k = (nets_per_set or {}).get(name, 6 if name in leisure_sets else 1)
             hs.tiled = TL.build_tiled(name, es["agent"], es["venue"], hs.n_venues, hs.v_pcontact, S, SA,
                                       agent_class=cls_all if (name in leisure_sets and cls_all is not None) else None,
-                                      sv_max=max(16, sv_max // max(1, k)), eb_target=eb_target)
+                                      sv_max=max(16, sv_max // max(1, k)), eb_target=eb_target, wide=desc_wide)
             t = hs.tiled
             for j in range(t.n_blocks):
                 work.append((int(t.blk_e0[j + 1] - t.blk_e0[j]) + int(t.blk_v0[j + 1] - t.blk_v0[j]), sid, j))
@@ -372,6 +374,7 @@ class DevicePlan:
                 c = self.tiled_c.sets[i]
                 c.n_blocks = ts.n_blocks
                 c.max_block_venues = int(np.diff(ts.blk_v0).max()) if ts.n_blocks else 0
+                c.desc_wide = 1 if ts.desc_wide else 0
                 c.blk_v0, c.blk_e0 = t["blk_v0"].data_ptr(), t["blk_e0"].data_ptr()
                 c.e_lv, c.a_la = t["e_lv"].data_ptr(), t["a_la"].data_ptr()
                 c.e_cls = N.ptr(t.get("e_cls"))

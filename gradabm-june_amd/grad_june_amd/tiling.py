@@ -98,15 +98,56 @@ class TiledEdgeSet:
     n_slots: int = 0        # length of the block-major arrays: every block padded to a multiple of 8
     chunk_ptr: Optional[np.ndarray] = None   # int32 [S+1] first 64-edge chunk of slice s (slice-major)
     chunk_desc: Optional[np.ndarray] = None  # int32 [n_chunks, 4]: slot0, slot1, split | multi << 16, j0
+    desc_wide: bool = False                  # chunk_desc is int32 [n_chunks, 8], see wide_descriptors()
     # A chunk = 64 consecutive slice-major edges.  Its first `split` edges lie in one tile and map to
     # block-major slots slot0, slot0+1, ...; the rest lie in the next non-empty tile and map to slot1,
     # slot1+1, ...  `multi` flags the rare chunk that spans more than two tiles (tiny tiles): its
     # lanes resolve their slot from the tile tables, starting at block j0.
 
 
+WIDE_SEGMENTS = 6      # tiles a 64-edge chunk may span in the wide descriptor format
+WIDE_MIN_SHARE = 0.01  # a set whose chunks span > 2 tiles more often than this gets wide descriptors
+
+
+def wide_descriptors(sptr: np.ndarray, jpos_flat: np.ndarray, seg: np.ndarray, chunk_ptr: np.ndarray,
+                     first_edge: np.ndarray, chunk_end: np.ndarray, t0: np.ndarray, J: int):
+    """Descriptors for sets with small tiles: int32 [n_chunks, 8] per 64-edge chunk of the slice-major order,
+        base_0 .. base_5,  start_1 | start_2 << 8 | start_3 << 16 | start_4 << 24,  start_5 | multi << 8 | j0 << 9
+    Segment k = the chunk's lanes [start_k, start_k+1) (start_0 = 0, unused segments start at 64) lies in one
+    tile and maps to block-major slots base_k + lane.  ``multi``: more than 6 tiles - the lanes walk the tile
+    tables from block j0.  Returns (desc, segments per chunk)."""
+    n_chunks = len(first_edge)
+    E = int(sptr[-1])
+    tile_len = np.diff(sptr)
+    starts_all = sptr[:-1][tile_len > 0]                     # slice-major position where each non-empty tile begins
+    tile_ids = np.flatnonzero(tile_len > 0)
+    # tile beginnings strictly inside a chunk are its segment boundaries
+    lo = np.searchsorted(starts_all, first_edge, side="right")      # first boundary > first_edge
+    hi = np.searchsorted(starts_all, chunk_end, side="left")        # boundaries < chunk_end
+    nseg = 1 + (hi - lo)
+    desc = np.zeros((n_chunks, 8), dtype=np.int64)
+    desc[:, 0] = jpos_flat[t0] + (first_edge - sptr[t0])
+    starts = np.full((n_chunks, WIDE_SEGMENTS - 1), 64, dtype=np.int64)
+    for k in range(1, WIDE_SEGMENTS):
+        has = nseg > k
+        b = np.minimum(lo + (k - 1), len(starts_all) - 1) if len(starts_all) else np.zeros(n_chunks, np.int64)
+        pos = starts_all[b] if len(starts_all) else np.zeros(n_chunks, np.int64)
+        st = np.where(has, pos - first_edge, 64)
+        base = np.where(has, jpos_flat[tile_ids[b]] - st, 0) if len(starts_all) else np.zeros(n_chunks, np.int64)
+        desc[:, k] = base
+        starts[:, k - 1] = st
+    multi = nseg > WIDE_SEGMENTS
+    j0 = t0 - np.repeat(np.arange(len(chunk_ptr) - 1) * J, np.diff(chunk_ptr))
+    desc[:, 6] = starts[:, 0] | (starts[:, 1] << 8) | (starts[:, 2] << 16) | (starts[:, 3] << 24)
+    desc[:, 7] = starts[:, 4] | (multi.astype(np.int64) << 8) | (j0 << 9)
+    if len(j0) and int(j0.max()) >= (1 << 22):
+        raise ValueError("too many venue blocks for the wide descriptor's j0 field")
+    return desc.astype(np.uint32).view(np.int32), nseg
+
+
 def build_tiled(name: str, agent_index, venue_index, n_venues: int, v_pcontact: np.ndarray,
                 n_slices: int, slice_agents: int, agent_class: Optional[np.ndarray] = None,
-                sv_max: int = SV_MAX, eb_target: int = EB_TARGET) -> TiledEdgeSet:
+                sv_max: int = SV_MAX, eb_target: int = EB_TARGET, wide: Optional[bool] = None) -> TiledEdgeSet:
     agent = np.asarray(agent_index, dtype=np.int64).ravel()
     venue = np.asarray(venue_index, dtype=np.int64).ravel()
     E = len(agent)
@@ -184,13 +225,17 @@ def build_tiled(name: str, agent_index, venue_index, n_venues: int, v_pcontact: 
     multi = two & (sptr[t1 + 1] < chunk_end)
     chunk_desc = np.stack([slot0, slot1, split + (multi.astype(np.int64) << 16),
                            t0 - np.repeat(np.arange(S) * J, n_chunks)], axis=1).astype(np.int32)
+    if wide is None:
+        wide = bool(len(multi)) and float(multi.mean()) > WIDE_MIN_SHARE
+    if wide:
+        chunk_desc, _ = wide_descriptors(sptr, jpos_sj.reshape(-1), seg, chunk_ptr, first_edge, chunk_end, t0, J)
     return TiledEdgeSet(
         name=name, n_venues=n_venues, n_edges=E, n_slices=S, n_blocks=J,
         blk_v0=blk_v0.astype(np.int32), blk_e0=blk_start.astype(np.int32),
         e_lv=e_lv, e_cls=e_cls, a_la=a_la,
         tile_sptr=sptr.astype(np.int32), tile_jpos=jpos_sj.reshape(-1).astype(np.int32),
         v_pcontact=np.asarray(v_pcontact, dtype=np.float32), n_slots=n_slots,
-        chunk_ptr=chunk_ptr.astype(np.int32), chunk_desc=np.ascontiguousarray(chunk_desc))
+        chunk_ptr=chunk_ptr.astype(np.int32), chunk_desc=np.ascontiguousarray(chunk_desc), desc_wide=bool(wide))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -113,6 +113,8 @@ typedef struct gj_long_row {
 typedef struct gj_tiled_set {
   int32_t n_blocks;          /* J: venue blocks of this set                                  */
   int32_t max_block_venues;  /* largest block of this set (sizes the LDS of phases B/C)      */
+  int32_t desc_wide;         /* 0: chunk_desc holds 4, 1: 8 int32 per chunk (see chunk_desc)  */
+  int32_t _pad;
   const int32_t* blk_v0;     /* device [J+1]   venue range of block j                        */
   const int32_t* blk_e0;     /* device [J+1]   block-major SLOT range of block j; every block is
                                                padded to a multiple of 8 slots (16-byte accesses) */
@@ -127,7 +129,12 @@ typedef struct gj_tiled_set {
   const int32_t* chunk_desc; /* device [4*chunks] per 64-edge chunk: slot0, slot1, split|multi<<16, j0:
                                 the first `split` edges map to block-major slots slot0.., the rest
                                 (next non-empty tile) to slot1..; multi: spans > 2 tiles, lanes
-                                resolve through tile_sptr/tile_jpos starting at block j0        */
+                                resolve through tile_sptr/tile_jpos starting at block j0.
+                                desc_wide (sets with small tiles): [8*chunks], base_0..base_5,
+                                start_1|start_2<<8|start_3<<16|start_4<<24, start_5|multi<<8|j0<<9:
+                                lanes [start_k, start_k+1) lie in one tile and map to slots
+                                base_k + lane (start_0 = 0, unused segments start at 64);
+                                multi: more than 6 tiles                                        */
   float* val;                /* device [slots] workspace: per-edge value (phase A->B, C->D)  */
 } gj_tiled_set;
 

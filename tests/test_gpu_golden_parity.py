@@ -22,9 +22,12 @@ RTOL = 2e-5
 
 # every parity case runs on both device layouts: "csr" (deterministic CSR kernels) and "tiled"
 # (LDS-tiled fast path; small tiles/blocks forced so that multi-slice / multi-block paths run)
-LAYOUTS = [("csr", {}), ("tiled", {}), ("tiled", dict(sv_max=64, eb_target=512, slices="small")),
+LAYOUTS = [("csr", {}), ("tiled", {}), ("tiled", dict(sv_max=64, eb_target=512, slices="small", desc_wide=False)),
+           ("tiled", dict(sv_max=64, eb_target=512, slices="small", desc_wide=True)),
+           ("tiled", dict(sv_max=16, eb_target=64, slices="small", desc_wide=True)),
            ("tiled", dict(split_epilogue=True))]
-LAYOUT_IDS = ["csr", "tiled", "tiled-small-tiles", "tiled-split-epilogue"]
+LAYOUT_IDS = ["csr", "tiled", "tiled-small-tiles", "tiled-small-tiles-wide-desc", "tiled-tiny-tiles-wide-desc",
+              "tiled-split-epilogue"]
 
 
 def engine_for(world, tables, device, layout):

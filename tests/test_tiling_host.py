@@ -15,14 +15,17 @@ def random_set(rng, A, V, E, big=None):
 
 
 @pytest.mark.parametrize("A,V,E,sa,svmax,eb", [(5000, 700, 20000, 512, 128, 3000), (300, 5, 4000, 64, 65536, 1 << 30),
-                                               (10000, 9000, 15000, 1024, 4096, 2000), (64, 1, 10, 64, 16, 16)])
-def test_layout_and_emulation(A, V, E, sa, svmax, eb):
+                                               (10000, 9000, 15000, 1024, 4096, 2000), (64, 1, 10, 64, 16, 16),
+                                               (2000, 3000, 6000, 64, 16, 16), (3000, 600, 30000, 128, 32, 600)])
+@pytest.mark.parametrize("wide", [False, True], ids=["narrow-desc", "wide-desc"])
+def test_layout_and_emulation(A, V, E, sa, svmax, eb, wide):
     rng = np.random.default_rng(A + V)
     agent, venue = random_set(rng, A, V, E, big=E // 3)
     S = -(-A // sa)
     pc = rng.random(V).astype(np.float32)
     cls = rng.integers(0, 200, A).astype(np.uint8)
-    t = build_tiled("x", agent, venue, V, pc, S, sa, agent_class=cls, sv_max=svmax, eb_target=eb)
+    t = build_tiled("x", agent, venue, V, pc, S, sa, agent_class=cls, sv_max=svmax, eb_target=eb, wide=wide)
+    assert t.desc_wide == wide and t.chunk_desc.shape[1] == (8 if wide else 4)
     J = t.n_blocks
     assert t.blk_v0[0] == 0 and t.blk_v0[-1] == V and t.blk_e0[-1] == t.n_slots and t.tile_sptr[-1] == E
     assert (np.diff(t.blk_v0) <= svmax).all() and (np.diff(t.blk_v0) > 0).all()
@@ -39,6 +42,24 @@ def test_layout_and_emulation(A, V, E, sa, svmax, eb):
         for c in range(t.chunk_ptr[sl], t.chunk_ptr[sl + 1]):
             i0 = seg[sl] + 64 * (c - t.chunk_ptr[sl])
             n = min(64, seg[sl + 1] - i0)
+            if wide:
+                d = [int(x) for x in t.chunk_desc[c]]
+                starts = [0] + [(d[6] >> (8 * k)) & 0xFF for k in range(4)] + [d[7] & 0xFF]
+                multi, j0 = (d[7] >> 8) & 1, (d[7] & 0xFFFFFFFF) >> 9
+                assert t.tile_sptr[sl * J + j0] <= i0 < t.tile_sptr[sl * J + j0 + 1]
+                assert starts == sorted(starts) and all(0 < st <= 64 for st in starts[1:])
+                lane = np.arange(n)
+                seg_of = sum((lane >= st).astype(int) for st in starts[1:])
+                got = np.array(d[:6])[seg_of] + lane
+                n_tiles = len(np.unique(tile_of_pos[i0:i0 + n]))
+                assert multi == (n_tiles > 6)
+                if multi:
+                    n_multi += 1
+                    ok = lane < starts[5]            # the first five segments are still exact
+                    assert np.array_equal(got[ok], slot_ref[i0:i0 + n][ok])
+                else:
+                    assert np.array_equal(got, slot_ref[i0:i0 + n])
+                continue
             slot0, slot1, sm, j0 = (int(x) for x in t.chunk_desc[c])
             split, multi = sm & 0xFFFF, sm >> 16
             assert t.tile_sptr[sl * J + j0] <= i0 < t.tile_sptr[sl * J + j0 + 1] and 1 <= split <= n

@@ -51,7 +51,8 @@ def main():
         for sa in [int(x) for x in os.environ.get("GJ_SA", "19584").split(",")]:
             for eb in [int(x) for x in os.environ.get("GJ_EB", "131072").split(",")]:
                 for sv in [int(x) for x in os.environ.get("GJ_SV", "16384").split(",")]:
-                    run(f"SA={sa} EB={eb} SV={sv}", slices=sl(sa), eb_target=eb, sv_max=sv)
+                    for wide in [{"auto": None, "0": False, "1": True}[x] for x in os.environ.get("GJ_WIDE", "auto").split(",")]:
+                        run(f"SA={sa} EB={eb} SV={sv} wide={wide}", slices=sl(sa), eb_target=eb, sv_max=sv, desc_wide=wide)
         return
     if os.environ.get("GJ_SWEEP", "geometry") == "geometry":
         run("default")
