@@ -101,50 +101,48 @@ __device__ __noinline__ int chunk_slot_walk(const TSetA& T, int row, int i, int 
   return T.tile_jpos[row + j] + (i - T.tile_sptr[row + j]);
 }
 
-// One batch of chunks of a set: the block-major slot of this lane's edge in each of them.  Straight-line
-// (clamped, unconditional loads) so that the whole batch is in flight; a wave-uniform branch takes the
-// table walk for batches that contain a chunk the descriptor cannot express.
+// One batch of chunks of a set: the block-major slot of this lane's edge in each of them.  The batch's
+// descriptors are consecutive in memory, so ONE coalesced load brings them in (lane l holds dword l of
+// the batch); each chunk's words are then broadcast with v_readlane into scalars.  Straight-line, so the
+// whole batch is in flight; a wave-uniform branch takes the table walk for batches that contain a chunk
+// the descriptor cannot express.
 template <bool WIDE, int U>
 __device__ __forceinline__ void batch_slots(const TSetA& T, int row, int seg0, int seg1, int c_base, int n_chunks,
                                             int c0, int lane, int (&slot)[U]) {
-  if (!WIDE) {
-    int4 d[U];
-    int multi = 0;
+  constexpr int W = WIDE ? 8 : 4;                       // dwords per descriptor
+  static_assert(U * W <= kWave, "a batch's descriptors must fit one wave-wide load");
+  const int32_t* desc = reinterpret_cast<const int32_t*>(T.chunk_desc);
+  const int u_l = min(lane / W, U - 1), k_l = lane % W;
+  const int word = desc[(int64_t)(c_base + min(c0 + u_l, n_chunks - 1)) * W + k_l];
+  const bool flag = WIDE ? (k_l == 7 && (word & 0x100)) : (k_l == 2 && (word >> 16));
+  const bool any_multi = __builtin_amdgcn_ballot_w64(flag) != 0ull;
+#define GJ_DW(u, k) __builtin_amdgcn_readlane(word, (u) * W + (k))
+  if (!any_multi) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      d[u] = T.chunk_desc[c_base + min(c0 + u, n_chunks - 1)];
-      multi |= d[u].z;
-    }
-    if (__builtin_amdgcn_readfirstlane(multi >> 16) == 0) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) slot[u] = chunk_slot_fast(d[u], lane);
-    } else {
-      for (int u = 0; u < U; ++u) {
-        const int i = min(seg0 + (c0 + u) * kWave + lane, seg1 - 1);
-        slot[u] = (d[u].z >> 16) ? chunk_slot_slow(T, d[u], row, i, lane) : chunk_slot_fast(d[u], lane);
+      if (!WIDE) {
+        slot[u] = chunk_slot_fast(make_int4(GJ_DW(u, 0), GJ_DW(u, 1), GJ_DW(u, 2), 0), lane);
+      } else {
+        slot[u] = chunk_slot_wide(make_int4(GJ_DW(u, 0), GJ_DW(u, 1), GJ_DW(u, 2), GJ_DW(u, 3)),
+                                  make_int4(GJ_DW(u, 4), GJ_DW(u, 5), GJ_DW(u, 6), GJ_DW(u, 7)), lane);
       }
     }
   } else {
-    int4 d0[U], d1[U];
-    int multi = 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int c = c_base + min(c0 + u, n_chunks - 1);
-      d0[u] = T.chunk_desc[2 * c];
-      d1[u] = T.chunk_desc[2 * c + 1];
-      multi |= d1[u].w;
-    }
-    if (__builtin_amdgcn_readfirstlane(multi & 0x100) == 0) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) slot[u] = chunk_slot_wide(d0[u], d1[u], lane);
-    } else {
-      for (int u = 0; u < U; ++u) {
-        const int i = min(seg0 + (c0 + u) * kWave + lane, seg1 - 1);
-        slot[u] = (d1[u].w & 0x100) ? chunk_slot_walk(T, row, i, (int)((unsigned)d1[u].w >> 9))
-                                    : chunk_slot_wide(d0[u], d1[u], lane);
+      const int i = min(seg0 + (c0 + u) * kWave + lane, seg1 - 1);
+      if (!WIDE) {
+        const int4 d = make_int4(GJ_DW(u, 0), GJ_DW(u, 1), GJ_DW(u, 2), GJ_DW(u, 3));
+        slot[u] = (d.z >> 16) ? chunk_slot_slow(T, d, row, i, lane) : chunk_slot_fast(d, lane);
+      } else {
+        const int4 d0 = make_int4(GJ_DW(u, 0), GJ_DW(u, 1), GJ_DW(u, 2), GJ_DW(u, 3));
+        const int4 d1 = make_int4(GJ_DW(u, 4), GJ_DW(u, 5), GJ_DW(u, 6), GJ_DW(u, 7));
+        slot[u] = (d1.w & 0x100) ? chunk_slot_walk(T, row, i, (int)((unsigned)d1.w >> 9))
+                                 : chunk_slot_wide(d0, d1, lane);
       }
     }
   }
+#undef GJ_DW
 }
 
 template <bool WIDE>
