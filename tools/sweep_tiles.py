@@ -54,6 +54,47 @@ def main():
                     for wide in [{"auto": None, "0": False, "1": True}[x] for x in os.environ.get("GJ_WIDE", "auto").split(",")]:
                         run(f"SA={sa} EB={eb} SV={sv} wide={wide}", slices=sl(sa), eb_target=eb, sv_max=sv, desc_wide=wide)
         return
+    if os.environ.get("GJ_SWEEP", "geometry") == "perset":
+        # does running A, B, C set by set keep each set's val workspace in the 256 MiB Infinity Cache?
+        from grad_june_amd.synthetic import edge_set_of
+
+        r = SingleGpuHotPath(world, specs, betas, dev, seed=1, layout="tiled")
+        e = r.engine
+        groups = {}
+        for n in r.networks:
+            groups.setdefault(edge_set_of(n), []).append(n)
+
+        def p_of(nets):
+            return e.params(now=1.0 + r.t, delta_time=1.0, day_type=0, active=nets, betas=r.betas, seed=r.seed, step=r.t)
+
+        def step_all():
+            p = p_of(r.networks)
+            for ph in (0, 1, 2, 3):
+                e.step_phase(r.bufs, p, r.io, ph)
+            r.t += 1
+
+        def step_perset(k=1):
+            p = p_of(r.networks)
+            e.step_phase(r.bufs, p, r.io, 0)
+            names = list(groups)
+            for i in range(0, len(names), k):
+                nets = [n for g in names[i:i + k] for n in groups[g]]
+                e.step_phase(r.bufs, p_of(nets), r.io, 8)
+            e.step_phase(r.bufs, p, r.io, 3)
+            r.t += 1
+
+        for tag, fn in (("all sets per phase", step_all), ("set by set", lambda: step_perset(1)),
+                        ("two sets at a time", lambda: step_perset(2)), ("three sets at a time", lambda: step_perset(3)),
+                        ("all sets per phase", step_all)):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(40):
+                fn()
+            torch.cuda.synchronize()
+            print(tag, "ms/step %.3f" % ((time.perf_counter() - t0) / 40 * 1e3), flush=True)
+        return
     if os.environ.get("GJ_SWEEP", "geometry") == "geometry":
         run("default")
         run("split epilogue", split_epilogue=True)
