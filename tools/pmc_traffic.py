@@ -1,0 +1,81 @@
+"""Turn the two rocprofv3 PMC passes into profiles/pmc_traffic.json (+ a compact per-dispatch CSV).
+
+On the GPU box (separate passes, kernel-trace only - never combined with sys-trace):
+
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_FETCH_SIZE -- \
+        python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_WRITE_SIZE -- \
+        python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline
+
+then here:  python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE <tag>
+
+Both counters are in KiB.  On gfx950 FETCH_SIZE reports half of the streamed read bytes
+(MI355X_MICROARCH.md, HBM / rocprofv3 section), so reads are doubled; the corrected figures are checked
+against the known read volume of k_transmission (24 B per agent).
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNELS = {"k_transmission": "transmission", "k_tile_scatter": "tile_scatter", "k_tile_venues": "tile_venues",
+           "k_tile_agents": "tile_agents"}
+
+
+def read_pass(directory, counter):
+    rows = []
+    for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        with open(path, newline="") as f:
+            for r in csv.DictReader(f):
+                if r["Counter_Name"] != counter:
+                    continue
+                for k in KERNELS:
+                    if k in r["Kernel_Name"]:
+                        rows.append((k, int(r["Dispatch_Id"]), float(r["Counter_Value"]),
+                                     int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    return rows
+
+
+def main():
+    fetch_dir, write_dir = sys.argv[1], sys.argv[2]
+    tag = sys.argv[3] if len(sys.argv) > 3 else "r01"
+    n_agents = int(sys.argv[4]) if len(sys.argv) > 4 else 10_000_000
+    per = {}
+    lines = ["counter,kernel,dispatch_id,counter_value_KB,duration_ns"]
+    for counter, d in (("FETCH_SIZE", fetch_dir), ("WRITE_SIZE", write_dir)):
+        rows = read_pass(d, counter)
+        if not rows:
+            raise SystemExit(f"no {counter} rows under {d}")
+        for k, disp, v, dur in rows:
+            lines.append(f"{counter},{k},{disp},{v:.6f},{dur}")
+        for k, name in KERNELS.items():
+            vals = [v for kk, _, v, _ in rows if kk == k][-8:]           # the timed steps (after warm-up)
+            if vals:
+                per.setdefault(name, {})[counter] = sum(vals) / len(vals) * 1024.0
+    out = {"workload": {"preset": "c3", "n_agents": n_agents, "layout": "tiled"},
+           "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), mean over the last "
+                     "8 dispatches; bytes = KiB*1024; FETCH_SIZE doubled (gfx950 reports 1/2 of streamed reads, "
+                     "MI355X_MICROARCH.md HBM section; checked against k_transmission's known 24 B/agent of reads)",
+           "per_launch_bytes": {}}
+    total = 0.0
+    for name, c in per.items():
+        rd, wr = 2.0 * c.get("FETCH_SIZE", 0.0), c.get("WRITE_SIZE", 0.0)
+        out["per_launch_bytes"][name] = {"read_corrected": rd, "read_raw_counter": c.get("FETCH_SIZE", 0.0),
+                                         "write": wr, "total": rd + wr}
+        total += rd + wr
+    out["per_step_total_bytes"] = total
+    known = 24.0 * n_agents
+    got = out["per_launch_bytes"].get("transmission", {}).get("read_corrected", 0.0)
+    out["check_transmission_reads"] = {"expected_bytes": known, "corrected_counter_bytes": got,
+                                       "ratio": got / known if known else None}
+    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_counters.csv"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
