@@ -16,6 +16,10 @@ namespace gj {
 constexpr int kTileThreads = 1024;  // 16 waves: one workgroup per CU when the slice fills LDS
 constexpr int kTileWaves = kTileThreads / kWave;
 constexpr int kUnroll = 8;          // 64-edge chunks a wave keeps in flight (phases A and D)
+#ifndef GJ_VENUE_UNROLL
+#define GJ_VENUE_UNROLL 2
+#endif
+constexpr int kVenueUnroll = GJ_VENUE_UNROLL;  // 8-slot groups a lane keeps in flight (phases B and C)
 
 // LDS float atomics run at 0.33 lanes/clk/CU on gfx950 (measured, tools/microbench/lds_atomics.hip)
 // against 4.9 for ds_add_u64 and 7.3 for ds_add_u32, so the per-venue and per-agent sums are kept
@@ -283,11 +287,9 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
   if (B.mode != 2) {
     for (int i = tid; i < nk * nv; i += kTileThreads) sums[i] = 0;
     __syncthreads();
-    // B: each lane takes 8 consecutive slots (48 bytes in flight), merges runs of one venue in
-    // registers and adds each run to the block's LDS sums
-    for (int g = g0 + tid; g < g1; g += kTileThreads) {
-      const uint4 raw = lv8[g];
-      const float4 xa = val4[2 * g], xb = val4[2 * g + 1];
+    // B: each lane takes 8 consecutive slots (48 bytes), merges runs of one venue in registers and adds
+    // each run to the block's LDS sums; kVenueUnroll such groups are loaded before the first is used
+    auto add_group = [&](const uint4 raw, const float4 xa, const float4 xb, const uint2 craw) {
       const Slots8 L{{raw.x, raw.y, raw.z, raw.w}};
       const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
       if (!T.leisure) {
@@ -306,7 +308,6 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
         }
         if (cur != 0xFFFF) atomicAdd(&sums[cur], to_fx<kFxVenue>(acc));
       } else {
-        const uint2 craw = cls8[g];
         const uint32_t cw[2] = {craw.x, craw.y};
         for (int k = 0; k < nk; ++k) {
           const float* tk = tabs + k * 200;
@@ -327,6 +328,22 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
           if (cur != 0xFFFF) atomicAdd(&sums[k * nv + cur], to_fx<kFxVenue>(acc));
         }
       }
+    };
+    for (int g = g0 + tid; g < g1; g += kVenueUnroll * kTileThreads) {
+      uint4 raw[kVenueUnroll];
+      float4 xa[kVenueUnroll], xb[kVenueUnroll];
+      uint2 craw[kVenueUnroll];
+#pragma unroll
+      for (int u = 0; u < kVenueUnroll; ++u) {     // clamped, unconditional: all loads in flight together
+        const int gu = min(g + u * kTileThreads, g1 - 1);
+        raw[u] = lv8[gu];
+        xa[u] = val4[2 * gu];
+        xb[u] = val4[2 * gu + 1];
+        craw[u] = T.leisure ? cls8[gu] : make_uint2(0u, 0u);
+      }
+#pragma unroll
+      for (int u = 0; u < kVenueUnroll; ++u)
+        if (g + u * kTileThreads < g1) add_group(raw[u], xa[u], xb[u], craw[u]);
     }
     __syncthreads();
     for (int k = 0; k < nk; ++k) {
@@ -345,31 +362,42 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
   }
   __syncthreads();
   // C: per slot, the venue's cum (leisure: weighted over the set's networks by the agent's class)
-  for (int g = g0 + tid; g < g1; g += kTileThreads) {
-    const uint4 raw = lv8[g];
-    const Slots8 L{{raw.x, raw.y, raw.z, raw.w}};
-    float r[8];
-    if (!T.leisure) {
+  for (int g = g0 + tid; g < g1; g += kVenueUnroll * kTileThreads) {
+    uint4 raw[kVenueUnroll];
+    uint2 craw[kVenueUnroll];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int lv = L.lv(q);
-        r[q] = (lv != 0xFFFF) ? cumf[2 * lv] : 0.0f;
-      }
-    } else {
-      const uint2 craw = cls8[g];
-      const uint32_t cw[2] = {craw.x, craw.y};
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int lv = L.lv(q);
-        const int c = (cw[q >> 2] >> ((q & 3) * 8)) & 0xFF;
-        float a = 0.0f;
-        if (lv != 0xFFFF)
-          for (int k = 0; k < nk; ++k) a += tabs[nk * 200 + k * 200 + c] * cumf[2 * (k * nv + lv)];
-        r[q] = a;
-      }
+    for (int u = 0; u < kVenueUnroll; ++u) {
+      const int gu = min(g + u * kTileThreads, g1 - 1);
+      raw[u] = lv8[gu];
+      craw[u] = T.leisure ? cls8[gu] : make_uint2(0u, 0u);
     }
-    val4[2 * g] = make_float4(r[0], r[1], r[2], r[3]);
-    val4[2 * g + 1] = make_float4(r[4], r[5], r[6], r[7]);
+#pragma unroll
+    for (int u = 0; u < kVenueUnroll; ++u) {
+      const int gu = g + u * kTileThreads;
+      if (gu >= g1) continue;
+      const Slots8 L{{raw[u].x, raw[u].y, raw[u].z, raw[u].w}};
+      float r[8];
+      if (!T.leisure) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int lv = L.lv(q);
+          r[q] = (lv != 0xFFFF) ? cumf[2 * lv] : 0.0f;
+        }
+      } else {
+        const uint32_t cw[2] = {craw[u].x, craw[u].y};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int lv = L.lv(q);
+          const int c = (cw[q >> 2] >> ((q & 3) * 8)) & 0xFF;
+          float a = 0.0f;
+          if (lv != 0xFFFF)
+            for (int k = 0; k < nk; ++k) a += tabs[nk * 200 + k * 200 + c] * cumf[2 * (k * nv + lv)];
+          r[q] = a;
+        }
+      }
+      val4[2 * gu] = make_float4(r[0], r[1], r[2], r[3]);
+      val4[2 * gu + 1] = make_float4(r[4], r[5], r[6], r[7]);
+    }
   }
 }
 

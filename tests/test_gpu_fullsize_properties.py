@@ -151,3 +151,40 @@ def test_c2_full_size_against_the_oracle(device):
         assert abs(int(dec.sum()) - int(dref.sum())) <= bad.sum()
         assert dref.sum() > 1000
         assert np.allclose(r.state["transmission"].cpu().numpy(), ref["transmission"].numpy(), rtol=2e-5, atol=1e-9)
+
+
+def test_step_is_capturable_in_a_hip_graph(device):
+    """gj_step is four plain launches on the caller's stream (no host synchronisation, no allocation), so it
+    can be captured in a hipGraph and replayed: a replay equals the eager step bit for bit."""
+    world = make_world("c3", n_agents=300_000, seed=7, infected_fraction=0.05)
+    specs, betas = B.network_specs(world), B.betas_of(world)
+    r = SingleGpuHotPath(world, specs, betas, device, seed=5, layout="tiled")
+    keys = ("is_infected", "susceptibility", "infection_time")
+    start = {k: r.state[k].clone() for k in keys}
+    r.step()                                              # eager step 0
+    torch.cuda.synchronize()
+    eager = {k: r.state[k].clone() for k in keys}
+    eager_new = r.new_infected.clone()
+    assert eager_new.sum().item() > 0
+    for k in keys:
+        r.state[k].copy_(start[k])
+    r.t = 0
+    p = r.params()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                         # warm-up on the capture stream
+        r.engine.step(r.bufs, p, r.io)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        r.engine.step(r.bufs, p, r.io)
+    for _ in range(2):                                    # replay twice from the same start state
+        for k in keys:
+            r.state[k].copy_(start[k])
+        r.new_infected.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        for k in keys:
+            assert torch.equal(r.state[k], eager[k]), k
+        assert torch.equal(r.new_infected, eager_new)
