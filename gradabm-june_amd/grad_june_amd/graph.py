@@ -338,3 +338,53 @@ def load_world(path_or_file) -> HeteroData:
 def save_world(data: HeteroData, path) -> None:
     with open(path, "wb") as f:
         pickle.dump(data, f, protocol=4)
+
+
+def locality_order(data: HeteroData, by: str = "household"):
+    """Graph-compile-time locality permutation: renumber the agents so that the members
+    of one venue of type ``by`` are consecutive (ordered by their first such venue; agents without one keep
+    their relative order at the end).  Tiles of that edge set then sit on the slice/block diagonal, and a
+    contiguous multi-GPU partition keeps most such venues rank-local.
+
+    Returns ``(data, original)``: the same container with every per-agent attribute (tensors, numpy arrays,
+    and the tensors inside dict attributes such as ``symptoms`` / ``infection_parameters``) and every agent
+    row of an ``edge_index`` renumbered; ``original[new] = old`` index, so a per-agent result ``r`` of a run
+    on the reordered world is reported in the original order as ``out[original] = r``.  ``agent.id`` keeps
+    the original identifiers (it is permuted like any other attribute)."""
+    import numpy as np
+
+    agent = data["agent"]
+    A = len(agent["id"])
+    key = None
+    for k, _ in data.edge_items():
+        if k[0] == "agent" and k[1] == "attends_" + by:
+            key = k
+    if key is None:
+        raise KeyError(f"no ('agent', 'attends_{by}', ...) edge type in the world")
+    ei = data[key].edge_index
+    dev = ei.device
+    first = torch.full((A,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=dev)
+    first.scatter_reduce_(0, ei[0].long(), ei[1].long(), reduce="amin")
+    original = torch.argsort(first, stable=True)                 # new position -> old index
+    new_of = torch.empty(A, dtype=torch.int64, device=dev)
+    new_of[original] = torch.arange(A, device=dev)
+    orig_np = original.cpu().numpy()
+
+    def permute(v):
+        if isinstance(v, torch.Tensor) and v.dim() >= 1 and v.shape[0] == A:
+            return v[original.to(v.device)]
+        if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == A:
+            return v[orig_np]
+        if isinstance(v, dict):
+            return {k: permute(x) for k, x in v.items()}
+        return v
+
+    for name in list(agent.keys()):
+        agent[name] = permute(agent[name])
+    for k, store in data.edge_items():
+        if "edge_index" not in store:
+            continue
+        e = store.edge_index
+        rows = [new_of.to(e.device)[e[i].long()].to(e.dtype) if k[2 * i] == "agent" else e[i] for i in (0, 1)]
+        store.edge_index = torch.stack(rows)
+    return data, original

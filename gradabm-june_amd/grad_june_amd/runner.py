@@ -93,6 +93,15 @@ class Runner(torch.nn.Module):
         device = require_hip(params["system"]["device"])
         path = read_path(params["data_path"])
         data = world_from_npz(path) if str(path).endswith(".npz") else load_world(path)
+        # optional (not a reference key): ``system.locality_order: household`` renumbers the agents venue-major
+        # at load time (graph.locality_order); the per-agent result of ``runner()`` is reported in the
+        # file's original order
+        by = params["system"].get("locality_order")
+        if by:
+            from .graph import locality_order
+
+            data, original = locality_order(data, by=by)
+            data["agent"].original_index = original
         data = data.to(device)
         n = len(data["agent"]["id"])
         values = TransmissionSampler.from_parameters(params)(n)
@@ -212,7 +221,12 @@ class Runner(torch.nn.Module):
         }
         for i, key in enumerate(self.age_bins[1:]):
             results[f"cases_by_age_{int(key):02d}"] = series[:, 1 + i]
-        return results, data["agent"].is_infected
+        is_infected = data["agent"].is_infected
+        if "original_index" in data["agent"]:
+            out = torch.empty_like(is_infected)
+            out[data["agent"].original_index.to(out.device)] = is_infected
+            is_infected = out
+        return results, is_infected
 
     def save_results(self, results, is_infected):
         import pandas as pd

@@ -365,3 +365,35 @@ def test_c_abi_from_plain_c(device, tmp_path):
                     f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True, capture_output=True)
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
     assert "ok" in out and "ABI version 1" in out
+
+
+def test_locality_order_gives_the_same_probabilities(G, device):
+    """system.locality_order renumbers the agents household-major at load time: the infection probabilities
+    of every agent are those of the original numbering ("results reported in original
+    agent order"), and runner() returns its per-agent result in the file's order."""
+    torch.manual_seed(3)
+    plain = G.Runner.from_parameters(params_on(device, days=3))
+    p2 = params_on(device, days=3)
+    p2["system"]["locality_order"] = "household"
+    torch.manual_seed(3)
+    local = G.Runner.from_parameters(p2)
+    original = local.data["agent"].original_index.to(device)
+    assert not torch.equal(original, torch.arange(len(original), device=device))
+    assert torch.equal(local.data["agent"].age, plain.data["agent"].age[original])
+    # same epidemic state in both numberings
+    n = plain.n_agents
+    g = torch.Generator().manual_seed(1)
+    trans = torch.rand(n, generator=g).to(device) * (torch.rand(n, generator=g).to(device) < 0.2)
+    susc = (torch.rand(n, generator=g).to(device) < 0.7).float()
+    for r, idx in ((plain, None), (local, original)):
+        ag = r.data["agent"]
+        ag.transmission = trans if idx is None else trans[idx].contiguous()
+        ag.susceptibility = susc if idx is None else susc[idx].contiguous()
+    next(plain.timer), next(local.timer)
+    pa = plain.model.infection_networks(data=plain.data, timer=plain.timer, policies=plain.model.policies)
+    pb = local.model.infection_networks(data=local.data, timer=local.timer, policies=local.model.policies)
+    assert torch.allclose(pb, pa[original], rtol=2e-6, atol=1e-9)
+    with torch.no_grad():
+        _, is_infected = local()
+    assert is_infected.shape[0] == n
+    assert torch.equal(is_infected[original], local.data["agent"].is_infected)

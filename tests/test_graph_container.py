@@ -66,3 +66,47 @@ def test_unpickles_pyg_class_paths():
 
     for key, cls in _WorldUnpickler._MAP.items():
         assert _WorldUnpickler(io.BytesIO(b"")).find_class(*key) is cls
+
+
+def test_locality_order_is_a_pure_renumbering():
+    """graph.locality_order: household members become consecutive; the graph is the same graph under the
+    returned permutation; dict attributes and numpy attributes follow."""
+    import numpy as np
+
+    from grad_june_amd.graph import HeteroData, ToUndirected, locality_order
+
+    g = torch.Generator().manual_seed(0)
+    A, H, S = 200, 70, 5
+    d = HeteroData()
+    d["agent"].id = torch.arange(A) + 1000
+    d["agent"].age = torch.randint(0, 100, (A,), generator=g)
+    d["agent"].area = np.array([f"a{i}" for i in range(A)])
+    d["agent"].symptoms = {"current_stage": torch.arange(A).float()}
+    hh = torch.randint(0, H, (A,), generator=g)
+    hh[:5] = -1                                                   # five agents without a household
+    members = torch.nonzero(hh >= 0).squeeze(1)
+    d["agent", "attends_household", "household"].edge_index = torch.stack((members, hh[members]))
+    d["household"].people = torch.bincount(hh[members], minlength=H)
+    sch = torch.randint(0, S, (A,), generator=g)
+    d["agent", "attends_school", "school"].edge_index = torch.stack((torch.arange(A), sch))
+    d = ToUndirected()(d)
+    before = {k: s.edge_index.clone() for k, s in d.edge_items()}
+    age0, id0 = d["agent"].age.clone(), d["agent"].id.clone()
+    d, original = locality_order(d, by="household")
+    assert sorted(original.tolist()) == list(range(A))
+    assert torch.equal(d["agent"].id, id0[original]) and torch.equal(d["agent"].age, age0[original])
+    assert d["agent"].area[0] == f"a{int(original[0])}"
+    assert torch.equal(d["agent"].symptoms["current_stage"], original.float())
+    new_of = torch.empty(A, dtype=torch.long)
+    new_of[original] = torch.arange(A)
+    for k, e0 in before.items():
+        e1 = d[k].edge_index
+        for row in (0, 1):
+            want = new_of[e0[row]] if k[2 * row] == "agent" else e0[row]
+            assert torch.equal(e1[row], want), (k, row)
+    # household members are consecutive, households in increasing order, the homeless last
+    ei = d["agent", "attends_household", "household"].edge_index
+    hh_new = torch.full((A,), H, dtype=torch.long)
+    hh_new[ei[0]] = ei[1]
+    assert torch.equal(hh_new, torch.sort(hh_new).values)
+    assert torch.equal(d["household", "rev_attends_household", "agent"].edge_index, ei.flip(0))
