@@ -100,17 +100,22 @@ __global__ __launch_bounds__(kThreads) void k_transmission(
   const int64_t n4 = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    const float4 a = reinterpret_cast<const float4*>(mx)[i];
-    const float4 b = reinterpret_cast<const float4*>(shp)[i];
-    const float4 c = reinterpret_cast<const float4*>(rt)[i];
-    const float4 d = reinterpret_cast<const float4*>(sh)[i];
-    const float4 e = reinterpret_cast<const float4*>(t_inf)[i];
     const float4 f = reinterpret_cast<const float4*>(inf)[i];
-    float4 r;
-    r.x = transmission_value(a.x, b.x, c.x, d.x, e.x, f.x, now);
-    r.y = transmission_value(a.y, b.y, c.y, d.y, e.y, f.y, now);
-    r.z = transmission_value(a.z, b.z, c.z, d.z, e.z, f.z, now);
-    r.w = transmission_value(a.w, b.w, c.w, d.w, e.w, f.w, now);
+    float4 r = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    // is_infected == 0 makes the product 0 whatever the profile (finite for every agent the reference gives a
+    // finite value for), so the five parameter streams are only read where someone is infected: early in an
+    // epidemic most 128-byte lines of them are never touched
+    if (f.x != 0.0f || f.y != 0.0f || f.z != 0.0f || f.w != 0.0f) {
+      const float4 a = reinterpret_cast<const float4*>(mx)[i];
+      const float4 b = reinterpret_cast<const float4*>(shp)[i];
+      const float4 c = reinterpret_cast<const float4*>(rt)[i];
+      const float4 d = reinterpret_cast<const float4*>(sh)[i];
+      const float4 e = reinterpret_cast<const float4*>(t_inf)[i];
+      r.x = f.x != 0.0f ? transmission_value(a.x, b.x, c.x, d.x, e.x, f.x, now) : 0.0f;
+      r.y = f.y != 0.0f ? transmission_value(a.y, b.y, c.y, d.y, e.y, f.y, now) : 0.0f;
+      r.z = f.z != 0.0f ? transmission_value(a.z, b.z, c.z, d.z, e.z, f.z, now) : 0.0f;
+      r.w = f.w != 0.0f ? transmission_value(a.w, b.w, c.w, d.w, e.w, f.w, now) : 0.0f;
+    }
     reinterpret_cast<float4*>(trans)[i] = r;
     if (has_q) {
       const float4 s = reinterpret_cast<const float4*>(stage)[i];
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(kThreads) void k_transmission(
   if (blockIdx.x == 0) {
     const int64_t i = (n4 << 2) + threadIdx.x;
     if (threadIdx.x < (n & 3)) {
-      const float r = transmission_value(mx[i], shp[i], rt[i], sh[i], t_inf[i], inf[i], now);
+      const float r = inf[i] != 0.0f ? transmission_value(mx[i], shp[i], rt[i], sh[i], t_inf[i], inf[i], now) : 0.0f;
       trans[i] = r;
       if (has_q) qtrans[i] = (stage[i] < q_thr ? 1.0f : 0.0f) * r;
     }
