@@ -241,3 +241,64 @@ def O_sample(p, noise):
     import gj_oracle as O
 
     return O.sample_infected(p, noise)
+
+
+@pytest.mark.parametrize("layout", LAYOUTS[:2], ids=LAYOUT_IDS[:2])
+def test_argument_errors_are_reported_not_launched(device, layout):
+    """The ABI's error contract on a live plan: negative codes for bad arguments, nothing is written."""
+    import ctypes as C
+
+    from grad_june_amd import _native as N
+    from grad_june_amd.engine import AgentBuffers
+
+    lib = N.load()
+    npz = L.load_npz("c100.npz")
+    world = L.world_from(npz)
+    eng = engine_for(world, None, device, layout)
+    rec = L.step_record(npz, "plain_t3/")
+    st = L.device_state(L.pre_state(rec), device)
+    bufs = AgentBuffers(eng.plan, max_infectiousness=st["max_infectiousness"], shape=st["shape"], rate=st["rate"],
+                        shift=st["shift"], infection_time=st["infection_time"], is_infected=st["is_infected"],
+                        susceptibility=st["susceptibility"], transmission=st["transmission"])
+    probs, new = torch.full((100,), -7.0, device=device), torch.full((100,), -7.0, device=device)
+    io = eng.io(not_infected_probs=probs, new_infected=new)
+    names = list(eng.plan.networks)
+    betas = {n: 1.0 for n in names}
+
+    def call(p, state=bufs.c, io_=io):
+        return lib.gj_step(C.byref(eng.plan.c), C.byref(state) if state is not None else None, C.byref(p),
+                           C.byref(io_), N.current_stream())
+
+    good = eng.params(now=3.0, delta_time=1.0, day_type=0, active=names, betas=betas)
+    p = eng.params(now=3.0, delta_time=1.0, day_type=0, active=names, betas=betas)
+    p.n_nets = N.GJ_MAX_NETS + 1
+    assert call(p) == -2                                            # GJ_E_RANGE
+    p = eng.params(now=3.0, delta_time=1.0, day_type=2, active=names, betas=betas)
+    assert call(p) == -2
+    p = eng.params(now=3.0, delta_time=1.0, day_type=0, active=names, betas=betas)
+    p.nets[0].set = 99
+    assert call(p) == -2
+    p = eng.params(now=3.0, delta_time=1.0, day_type=0, active=names, betas=betas)
+    p.nets[0].mask_kind = 17
+    assert call(p) == -2
+    if len(names) >= 3:                                             # networks of one set must be adjacent
+        p = eng.params(now=3.0, delta_time=1.0, day_type=0, active=names[:3], betas=betas)
+        p.nets[2].set = p.nets[0].set
+        assert call(p) == -3                                        # GJ_E_PLAN
+    p = eng.params(now=3.0, delta_time=1.0, day_type=0, active=names, betas=betas)
+    p.nets[0].mask_kind = N.MASK_QL                                 # a leisure mask without a table
+    p.nets[0].table = -1
+    assert call(p) == -3
+    assert call(good, state=None) == -1                             # GJ_E_NULL
+    broken = N.AgentState()
+    C.memmove(C.byref(broken), C.byref(bufs.c), C.sizeof(N.AgentState))
+    broken.susceptibility = None
+    assert call(good, state=broken) == -1
+    p = eng.params(now=3.0, delta_time=1.0, day_type=0, active=names, betas=betas, has_quarantine=True, q_threshold=4.0)
+    assert call(p) == -1                                            # quarantine without stage / q_transmission
+    torch.cuda.synchronize()
+    assert (probs == -7.0).all() and (new == -7.0).all()            # no launch wrote anything
+    assert N.load().gj_error_string(-3).decode() != ""
+    assert call(good) == 0
+    torch.cuda.synchronize()
+    assert (probs > 0).all() and (probs <= 1).all()
