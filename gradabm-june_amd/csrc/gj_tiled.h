@@ -111,13 +111,19 @@ __device__ __noinline__ int chunk_slot_walk(const TSetA& T, int row, int i, int 
 // whole batch is in flight; a wave-uniform branch takes the table walk for batches that contain a chunk
 // the descriptor cannot express.
 template <bool WIDE, int U>
-__device__ __forceinline__ void batch_slots(const TSetA& T, int row, int seg0, int seg1, int c_base, int n_chunks,
-                                            int c0, int lane, int (&slot)[U]) {
+__device__ __forceinline__ int batch_desc_load(const TSetA& T, int c_base, int n_chunks, int c0, int lane) {
   constexpr int W = WIDE ? 8 : 4;                       // dwords per descriptor
   static_assert(U * W <= kWave, "a batch's descriptors must fit one wave-wide load");
   const int32_t* desc = reinterpret_cast<const int32_t*>(T.chunk_desc);
   const int u_l = min(lane / W, U - 1), k_l = lane % W;
-  const int word = desc[(int64_t)(c_base + min(c0 + u_l, n_chunks - 1)) * W + k_l];
+  return desc[(int64_t)(c_base + min(c0 + u_l, n_chunks - 1)) * W + k_l];
+}
+
+template <bool WIDE, int U>
+__device__ __forceinline__ void batch_slots(const TSetA& T, const int word, int row, int seg0, int seg1, int c0,
+                                            int lane, int (&slot)[U]) {
+  constexpr int W = WIDE ? 8 : 4;
+  const int k_l = lane % W;
   const bool flag = WIDE ? (k_l == 7 && (word & 0x100)) : (k_l == 2 && (word >> 16));
   const bool any_multi = __builtin_amdgcn_ballot_w64(flag) != 0ull;
 #define GJ_DW(u, k) __builtin_amdgcn_readlane(word, (u) * W + (k))
@@ -157,10 +163,11 @@ __device__ __forceinline__ void scatter_set(const TSetA& T, const float* lds_x, 
   const int n_chunks = T.chunk_ptr[s + 1] - c_base;
   for (int c0 = wave * kUnroll; c0 < n_chunks; c0 += kTileWaves * kUnroll) {
     int la[kUnroll], slot[kUnroll];
+    const int word = batch_desc_load<WIDE, kUnroll>(T, c_base, n_chunks, c0, lane);   // first: the slots wait on it
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u)    // unconditional (clamped) loads: straight-line, all in flight
       la[u] = T.a_la[min(seg0 + (c0 + u) * kWave + lane, seg1 - 1)];
-    batch_slots<WIDE, kUnroll>(T, row, seg0, seg1, c_base, n_chunks, c0, lane, slot);
+    batch_slots<WIDE, kUnroll>(T, word, row, seg0, seg1, c0, lane, slot);
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
       const int i = seg0 + (c0 + u) * kWave + lane;
@@ -178,10 +185,11 @@ __device__ __forceinline__ void gather_set(const TSetA& T, fx_t* lds_acc, int s,
   for (int c0 = wave * kUnroll; c0 < n_chunks; c0 += kTileWaves * kUnroll) {
     int la[kUnroll], slot[kUnroll];
     float v[kUnroll];
+    const int word = batch_desc_load<WIDE, kUnroll>(T, c_base, n_chunks, c0, lane);   // first: the val loads wait on it
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u)    // unconditional (clamped) loads: straight-line, all in flight
       la[u] = T.a_la[min(seg0 + (c0 + u) * kWave + lane, seg1 - 1)];
-    batch_slots<WIDE, kUnroll>(T, row, seg0, seg1, c_base, n_chunks, c0, lane, slot);
+    batch_slots<WIDE, kUnroll>(T, word, row, seg0, seg1, c0, lane, slot);
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {  // the slot depends on the position only: these loads overlap the ones above
       const int i = seg0 + (c0 + u) * kWave + lane;
