@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--sv-max", type=int, default=None)
     ap.add_argument("--eb-target", type=int, default=None)
     ap.add_argument("--slice-agents", type=int, default=None, help="tiled: agents per slice (multiple of 64)")
+    ap.add_argument("--tune", default="auto", choices=["auto", "on", "off"],
+                    help="measure candidate tile geometries at set-up and keep the fastest "
+                         "(auto: single-GPU worlds of at most 4e7 set-edges, where compiling takes seconds)")
     ap.add_argument("--reorder", default="auto", choices=["auto", "none", "household"],
                     help="graph-compile-time agent renumbering for locality (results map back through original_id); "
                          "auto = household-major when the world is partitioned over several GPUs (halves the halo)")
@@ -253,9 +256,19 @@ def main():
             runner = PartitionedHotPath(world, specs, betas, dev, parts, seed=args.seed, progress=progress)
             extra = {"partitions_on_one_gpu": parts}
         else:
-            runner = SingleGpuHotPath(world, specs, betas, dev, seed=args.seed, layout=args.layout,
-                                      quarantine_threshold=args.quarantine, progress=progress, **kw)
-            extra = {}
+            set_edges = sum(len(v["agent"]) for v in world["edge_sets"].values())
+            tune = args.tune == "on" or (args.tune == "auto" and args.layout == "tiled" and not kw
+                                         and set_edges <= 40_000_000)
+            if tune:      # small worlds compile in seconds: measure the candidate tile geometries, keep the best
+                from grad_june_amd.benchrun import tune_geometry
+
+                runner, seen = tune_geometry(world, specs, betas, dev, seed=args.seed, layout=args.layout,
+                                             quarantine_threshold=args.quarantine, progress=progress)
+                extra = {"geometry_tuning_ms": seen}
+            else:
+                runner = SingleGpuHotPath(world, specs, betas, dev, seed=args.seed, layout=args.layout,
+                                          quarantine_threshold=args.quarantine, progress=progress, **kw)
+                extra = {}
     t_setup = time.time() - t0
 
     def sync():

@@ -130,3 +130,47 @@ class SingleGpuHotPath:
 
     def kernel_ms(self) -> Dict[str, float]:
         return {k: float(np.mean(v)) for k, v in self.log.spans().items()}
+
+    def time_stateless(self, steps: int = 10) -> float:
+        """ms per pass of transmission + both sparse passes + probabilities (no decision, no state update):
+        what ``tune_geometry`` compares.  Leaves the epidemic state untouched."""
+        import time
+
+        p = self.params()
+        phases = (0, 1, 2, 4) if self.layout == "tiled" else (0, 1, 4)
+        for _ in range(2):
+            for ph in phases:
+                self.engine.step_phase(self.bufs, p, self.io, ph)
+        torch.cuda.synchronize(self.device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            for ph in phases:
+                self.engine.step_phase(self.bufs, p, self.io, ph)
+        torch.cuda.synchronize(self.device)
+        return 1e3 * (time.perf_counter() - t0) / steps
+
+
+#: tile geometries tried by tune_geometry: {} = the size-based defaults of tiling.py
+GEOMETRY_CANDIDATES = ({}, {"eb_target": 131072, "sv_max": 16384}, {"eb_target": 65536, "sv_max": 16384})
+
+
+def tune_geometry(world: dict, specs, betas, device, candidates=GEOMETRY_CANDIDATES, progress=None, **kw):
+    """Compile the world under each candidate geometry, time the stateless part of the step on the device
+    and return ``(best SingleGpuHotPath, {label: ms})``.  The size-based defaults are right for the worlds
+    they were measured on (1.5 memberships per agent and edge set); worlds with much denser membership
+    (BASELINE's C2: 5 per agent and set) prefer larger tiles - measuring is cheaper than modelling, and
+    compiling a world of a few 10^7 edges takes seconds."""
+    best, best_ms, seen = None, float("inf"), {}
+    for cand in candidates:
+        r = SingleGpuHotPath(world, specs, betas, device, progress=None, **{**kw, **cand})
+        ms = r.time_stateless()
+        label = ",".join(f"{k}={v}" for k, v in cand.items()) or "default"
+        seen[label] = ms
+        if progress:
+            progress(f"geometry {label}: {ms:.3f} ms")
+        if ms < best_ms:
+            best, best_ms = r, ms
+        else:
+            del r
+            torch.cuda.empty_cache()
+    return best, seen
