@@ -29,6 +29,69 @@ from . import _native as N
 from .engine import AgentBuffers
 
 
+def _forward_sums(engine, p, bufs, acc, nets, compute_transmission: bool):
+    """Forward of the two sparse passes with susceptibility = 1 in ``bufs``: fills ``acc`` with
+    sum_n w_n * (L_n (m_n trans)) and returns {edge set: clone of its per-venue sums}."""
+    plan = engine.plan
+    io = engine.io(trans_susc=acc)
+    p.transpose = 0
+    if compute_transmission:
+        engine.step_phase(bufs, p, io, 0)                      # transmission (+ q * transmission)
+    else:
+        engine.quarantine_transmission(bufs, p)                # the caller supplied the transmissions
+    for phase in (1, 5):
+        engine.step_phase(bufs, p, io, phase)
+    cum_fwd = {}
+    for net in nets:
+        es = plan.networks[net.name].edge_set
+        if es not in cum_fwd:
+            cum_fwd[es] = plan.cum_of(es).clone()
+    for phase in (6, 4):
+        engine.step_phase(bufs, p, io, phase)
+    return cum_fwd
+
+
+def _transposed_passes(engine, p, bufs, scratch, x, nets, betas, cum_fwd):
+    """The transposed pipeline on x = susceptibility * ts_bar: returns (d loss / d transmission,
+    [d loss / d log_beta per network of ``nets``]).  ``scratch`` is the transmission buffer of ``bufs``."""
+    plan = engine.plan
+    n = plan.host.n_agents
+    scratch[:n].copy_(x)
+    tbar = torch.empty(n, dtype=torch.float32, device=plan.device)
+    io_t = engine.io(trans_susc=tbar)
+    p.transpose = 1
+    try:
+        engine.quarantine_transmission(bufs, p)                # q * x for the masked sets
+        for phase in (1, 5):
+            engine.step_phase(bufs, p, io_t, phase)
+        grads: List[torch.Tensor] = []
+        per_set_k = {}
+        for net in nets:
+            es = plan.networks[net.name].edge_set
+            k = per_set_k.get(es, 0)
+            per_set_k[es] = k + 1
+            i = plan.host.set_index[es]
+            pc = plan.keep[i]["v_pc"].double()
+            beta = float(betas[net.name])
+            prod = cum_fwd[es][:, k].double() * plan.cum_of(es)[:, k].double()
+            dot = (torch.where(pc > 0, prod / (beta * pc), torch.zeros_like(prod)).sum() if beta != 0.0
+                   else prod.sum() * 0)
+            grads.append((dot * math.log(10.0)).to(torch.float32))
+        for phase in (6, 4):
+            engine.step_phase(bufs, p, io_t, phase)            # tbar = d loss / d transmission
+    finally:
+        p.transpose = 0
+    return tbar, grads
+
+
+def _param_grads(nets, grads):
+    out = []
+    for net, g in zip(nets, grads):
+        lb = net.log_beta
+        out.append(g.to(lb.device).reshape(lb.shape) if isinstance(lb, torch.Tensor) and lb.requires_grad else None)
+    return out
+
+
 class HotPathStep(torch.autograd.Function):
     """(susceptibility, is_infected, infection_time, *log_betas) -> (susceptibility', is_infected',
     infection_time', new_infected)."""
@@ -72,19 +135,8 @@ class HotPathStep(torch.autograd.Function):
         # ---- recompute the forward of the two passes from the saved pre-state ----------------------------
         bufs = AgentBuffers(plan, **fixed, infection_time=time0, is_infected=inf0, susceptibility=ones,
                             transmission=scratch, current_stage=stage)
-        io = engine.io(trans_susc=acc)
         p = params
-        p.transpose = 0
-        for phase in (0, 1, 5):
-            engine.step_phase(bufs, p, io, phase)
-        names = [net.name for net in nets]
-        cum_fwd = {}
-        for name in names:
-            es = plan.networks[name].edge_set
-            if es not in cum_fwd:
-                cum_fwd[es] = plan.cum_of(es).clone()
-        for phase in (6, 4):
-            engine.step_phase(bufs, p, io, phase)                 # acc = sum_n w_n * (L_n (m_n trans))
+        cum_fwd = _forward_sums(engine, p, bufs, acc, nets, compute_transmission=True)
         # ---- elementwise adjoint of epilogue + sampler + infect_people ------------------------------------
         x = torch.empty(n, dtype=torch.float32, device=dev)
         grad_susc = torch.empty(n, dtype=torch.float32, device=dev)
@@ -94,28 +146,7 @@ class HotPathStep(torch.autograd.Function):
                                       N.ptr(g_susc), N.ptr(g_inf), N.ptr(g_time), N.ptr(g_new), N.ptr(x),
                                       N.ptr(grad_susc), N.ptr(grad_time), N.current_stream()), "gj_adjoint_sample")
         # ---- transposed passes on x = susc0 * ts_bar --------------------------------------------------------
-        scratch[:n].copy_(x)
-        tbar = torch.empty(n, dtype=torch.float32, device=dev)
-        io_t = engine.io(trans_susc=tbar)
-        p.transpose = 1
-        engine.quarantine_transmission(bufs, p)                    # q * x for the masked sets
-        for phase in (1, 5):
-            engine.step_phase(bufs, p, io_t, phase)
-        grads: List[torch.Tensor] = []
-        per_set_k = {}
-        for net in nets:
-            es = plan.networks[net.name].edge_set
-            k = per_set_k.get(es, 0)
-            per_set_k[es] = k + 1
-            i = plan.host.set_index[es]
-            pc = plan.keep[i]["v_pc"].double()
-            beta = float(env["betas"][net.name])
-            prod = cum_fwd[es][:, k].double() * plan.cum_of(es)[:, k].double()
-            dot = torch.where(pc > 0, prod / (beta * pc), torch.zeros_like(prod)).sum() if beta != 0.0 else prod.sum() * 0
-            grads.append((dot * math.log(10.0)).to(torch.float32))
-        for phase in (6, 4):
-            engine.step_phase(bufs, p, io_t, phase)                # tbar = d loss / d transmission
-        p.transpose = 0
+        tbar, grads = _transposed_passes(engine, p, bufs, scratch, x, nets, env["betas"], cum_fwd)
         # ---- through the transmission profile ------------------------------------------------------------------
         grad_inf = torch.empty(n, dtype=torch.float32, device=dev)
         st0 = AgentBuffers(plan, **fixed, infection_time=time0, is_infected=inf0, susceptibility=ones,
@@ -123,11 +154,61 @@ class HotPathStep(torch.autograd.Function):
         N.check(lib.gj_adjoint_transmission(n, C.byref(st0.c), float(p.now), N.ptr(tbar), N.ptr(g_inf),
                                             N.ptr(grad_inf), N.ptr(grad_time), N.current_stream()),
                 "gj_adjoint_transmission")
-        out_grads = []
-        for net, g in zip(nets, grads):
-            lb = net.log_beta
-            out_grads.append(g.to(lb.device).reshape(lb.shape) if isinstance(lb, torch.Tensor) and lb.requires_grad else None)
-        return (None, grad_susc, grad_inf, grad_time, *out_grads)
+        return (None, grad_susc, grad_inf, grad_time, *_param_grads(nets, grads))
+
+
+class NetworksForward(torch.autograd.Function):
+    """The stand-alone ``InfectionNetworks.forward`` / ``InfectionNetwork.forward`` (base.py:61-84,118-141) as
+    an autograd node: (transmission, susceptibility, *log_betas) -> not_infected_probs (or one network's
+    trans_susc), differentiable w.r.t. all of them.  Same machinery as HotPathStep without the sampler."""
+
+    @staticmethod
+    def forward(ctx, env, transmission, susceptibility, *log_betas):
+        engine, p, want = env["engine"], env["params"], env["want"]
+        plan = engine.plan
+        n = plan.host.n_agents
+        dev = plan.device
+        trans = torch.zeros(plan.host.n_ext_agents, dtype=torch.float32, device=dev)
+        trans[:n].copy_(transmission.detach())
+        susc = susceptibility.detach().to(device=dev, dtype=torch.float32).contiguous()
+        bufs = AgentBuffers(plan, susceptibility=susc, transmission=trans, current_stage=env["stage"])
+        out = torch.empty(n, dtype=torch.float32, device=dev)
+        engine.quarantine_transmission(bufs, p)
+        engine.venue_reduce(bufs, p)
+        engine.agent_gather(bufs, p, engine.io(not_infected_probs=out) if want == "probs" else engine.io(trans_susc=out),
+                            sample=False)
+        snap = N.StepParams()
+        C.memmove(C.byref(snap), C.byref(p), C.sizeof(N.StepParams))
+        ctx.env = dict(env, params=snap)
+        ctx.save_for_backward(trans, susc)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        env = ctx.env
+        engine, p, nets, want = env["engine"], env["params"], env["nets"], env["want"]
+        trans, susc = ctx.saved_tensors
+        plan, dev = engine.plan, engine.plan.device
+        n = plan.host.n_agents
+        if plan.c.tiled is None or not bool(plan.c.tiled):
+            raise NotImplementedError("the backward pass runs on the tiled layout")
+        g = g_out.detach().to(torch.float32).contiguous()
+        ones = torch.ones(n, dtype=torch.float32, device=dev)
+        scratch = trans.clone()
+        acc = torch.empty(n, dtype=torch.float32, device=dev)
+        bufs = AgentBuffers(plan, susceptibility=ones, transmission=scratch, current_stage=env["stage"])
+        cum_fwd = _forward_sums(engine, p, bufs, acc, nets, compute_transmission=False)
+        if want == "probs":                                       # clamp(exp(-clamp(ts, 1e-6, 100) * dt), 0, 1)
+            ts = susc * acc
+            inside = (ts >= 1e-6) & (ts <= 100.0)
+            prob = torch.exp(-torch.clamp(ts, 1e-6, 100.0) * float(p.delta_time))
+            ts_bar = torch.where(inside, g * (-float(p.delta_time)) * prob, torch.zeros_like(g))
+        else:
+            ts_bar = g
+        grad_susc = ts_bar * acc
+        tbar, grads = _transposed_passes(engine, p, bufs, scratch, (susc * ts_bar).contiguous(), nets, env["betas"],
+                                         cum_fwd)
+        return (None, tbar, grad_susc, *_param_grads(nets, grads))
 
 
 class SymptomsStep(torch.autograd.Function):

@@ -27,17 +27,6 @@ from .utils import parse_age_probabilities
 from .world import agent_buffers, engine_for, require_hip
 
 
-def _check_no_grad(networks):
-    if torch.is_grad_enabled():
-        for net in networks:
-            if isinstance(net.log_beta, torch.Tensor) and net.log_beta.requires_grad:
-                raise NotImplementedError(
-                    f"network '{net.name}': log_beta requires grad, but the HIP infection path is forward-only "
-                    "in this release (differentiable mode is SURVEY section 8 row f3). Wrap the call in "
-                    "torch.no_grad() for forward simulation."
-                )
-
-
 class InfectionNetwork(torch.nn.Module):
     mask_kind = N.MASK_Q
 
@@ -226,10 +215,24 @@ def _step_inputs(active_networks, all_networks, data, timer, policies, device):
 
 def _run_networks(active_networks, data, timer, policies, device, want="probs", all_networks=None):
     device = require_hip(device)
-    _check_no_grad(active_networks)
     if hasattr(policies, "apply"):
         policies.apply(timer=timer, data=data)
     engine, params, has_q = _step_inputs(active_networks, all_networks or active_networks, data, timer, policies, device)
+    ag = data["agent"]
+    if torch.is_grad_enabled() and (
+            any(isinstance(n.log_beta, torch.Tensor) and n.log_beta.requires_grad for n in active_networks)
+            or any(isinstance(ag.get(k), torch.Tensor) and ag[k].requires_grad for k in ("transmission", "susceptibility"))):
+        # row f3: the stand-alone forward as an autograd node (gradients w.r.t. log_beta, transmission, susceptibility)
+        from .autograd import NetworksForward
+
+        stage = None
+        if has_q:
+            stage = ag["symptoms"]["current_stage"].detach().to(device=device, dtype=torch.float32).contiguous()
+        env = {"engine": engine, "params": params, "want": want, "nets": list(active_networks), "stage": stage,
+               "betas": {n.name: float(params.nets[i].beta) for i, n in enumerate(active_networks)}}
+        f = lambda t: t if t.dtype == torch.float32 else t.to(torch.float32)
+        return NetworksForward.apply(env, f(ag["transmission"]).to(device), f(ag["susceptibility"]).to(device),
+                                     *[n.log_beta for n in active_networks])
     bufs = agent_buffers(engine, data, need_params=False, need_stage=has_q, need_infection_state=False)
     n = engine.plan.host.n_agents
     out = torch.empty(n, dtype=torch.float32, device=device)

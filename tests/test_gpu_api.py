@@ -228,13 +228,55 @@ def test_is_infected_sampler_statistics(G, device):
     assert torch.equal(sampler(p, exp_noise=noise).cpu() > 0.5, O.sample_infected(p.cpu(), noise) > 0.5)
 
 
-def test_standalone_probabilities_are_forward_only(G, device):
-    """Gradients flow through GradJune / Runner (row f3); the stand-alone InfectionNetworks call, which
-    returns probabilities only, says so instead of silently dropping them."""
-    d = conftest_world(G, device)
-    nets = nets_of(G, device, company=torch.nn.Parameter(torch.tensor(0.5)))
-    with pytest.raises(NotImplementedError, match="forward-only"):
-        nets(data=d, timer=day_timer(G, ["company"]), policies=G.Policies())
+def test_standalone_probabilities_are_differentiable(G, device):
+    """The stand-alone InfectionNetworks.forward (base.py:118-141) in grad mode: gradients w.r.t. every log_beta,
+    the transmissions and the susceptibilities equal autograd through the oracle's op-for-op restatement; with a
+    quarantine policy active too; and one network's trans_susc (InfectionNetwork.forward, base.py:61-84)."""
+    from grad_june_amd.policies import Quarantine
+
+    for quarantine in (False, True):
+        d = conftest_world(G, device)
+        n = 100
+        g = torch.Generator().manual_seed(4)
+        trans0 = torch.rand(n, generator=g) * (torch.rand(n, generator=g) < 0.4)
+        susc0 = torch.rand(n, generator=g)
+        stage = torch.randint(1, 7, (n,), generator=g)
+        d["agent"].symptoms["current_stage"] = stage.to(device)
+        w = torch.rand(n, generator=g)
+        log_betas = {"school": 0.3, "company": 0.5, "household": 0.2}
+        names = ["school", "company", "household"]
+        policies = G.Policies.from_policy_list(
+            [Quarantine(stage_threshold=4, start_date="2022-01-01", end_date="2022-12-01")] if quarantine else [])
+        nets = nets_of(G, device, **{k: torch.nn.Parameter(torch.tensor(v)) for k, v in log_betas.items()})
+        tr = trans0.clone().to(device).requires_grad_()
+        su = susc0.clone().to(device).requires_grad_()
+        d["agent"].transmission, d["agent"].susceptibility = tr, su
+        timer = day_timer(G, names)
+        p = nets(data=d, timer=timer, policies=policies)
+        assert p.requires_grad
+        loss = (p * w.to(device)).sum()
+        got = torch.autograd.grad(loss, [tr, su] + [nets[k].log_beta for k in names])
+        # oracle: the same computation with autograd on the CPU
+        lb = {k: torch.tensor(v, requires_grad=True) for k, v in log_betas.items()}
+        tr_c, su_c = trans0.clone().requires_grad_(), susc0.clone().requires_grad_()
+        qmask = O.quarantine_mask(stage.float(), [4.0]) if quarantine else 1.0
+        ts = []
+        for k in names:
+            ei = d["attends_" + k].edge_index.cpu()
+            ts.append(O.infection_network(kind="household" if k == "household" else "plain", beta=10.0 ** lb[k],
+                                          people=d[k].people.cpu(), agent_index=ei[0], venue_index=ei[1],
+                                          transmission=tr_c, susceptibility=su_c, qmask=qmask))
+        p_ref = O.not_infected_probabilities(ts, n, 1.0)
+        assert torch.allclose(p.detach().cpu(), p_ref.detach(), rtol=2e-5, atol=1e-9)
+        ref = torch.autograd.grad((p_ref * w).sum(), [tr_c, su_c] + [lb[k] for k in names])
+        for a, b, what in zip(got, ref, ["transmission", "susceptibility"] + names):
+            assert torch.allclose(a.cpu(), b, rtol=2e-3, atol=1e-6), (quarantine, what, a, b)
+        # a single network's term
+        t1 = nets["company"](data=d, timer=timer, policies=policies)
+        g1 = torch.autograd.grad(t1.sum(), [tr, nets["company"].log_beta])
+        r1 = torch.autograd.grad(ts[1].sum(), [tr_c, lb["company"]], retain_graph=True)
+        for a, b in zip(g1, r1):
+            assert torch.allclose(a.cpu(), b, rtol=2e-3, atol=1e-6)
 
 
 def test_run_model_script_flow_with_gradients(G, device):
