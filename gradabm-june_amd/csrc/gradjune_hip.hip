@@ -1246,7 +1246,7 @@ int gj_step_phase(const gj_plan* plan, const gj_agent_state* state, const gj_ste
   gj::Groups G;
   rc = gj::group_networks(plan, params, &G);
   if (rc) return rc;
-  rc = gj::check_state(plan, state, params);
+  rc = gj::check_state(plan, state, params, /*full=*/phase == 0 || phase == 3);   // only a1 / a9 touch the infection state
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   switch (phase) {
