@@ -268,7 +268,7 @@ def test_standalone_probabilities_are_differentiable(G, device):
                                           transmission=tr_c, susceptibility=su_c, qmask=qmask))
         p_ref = O.not_infected_probabilities(ts, n, 1.0)
         assert torch.allclose(p.detach().cpu(), p_ref.detach(), rtol=2e-5, atol=1e-9)
-        ref = torch.autograd.grad((p_ref * w).sum(), [tr_c, su_c] + [lb[k] for k in names])
+        ref = torch.autograd.grad((p_ref * w).sum(), [tr_c, su_c] + [lb[k] for k in names], retain_graph=True)
         for a, b, what in zip(got, ref, ["transmission", "susceptibility"] + names):
             assert torch.allclose(a.cpu(), b, rtol=2e-3, atol=1e-6), (quarantine, what, a, b)
         # a single network's term
