@@ -228,6 +228,27 @@ def test_is_infected_sampler_statistics(G, device):
     assert torch.equal(sampler(p, exp_noise=noise).cpu() > 0.5, O.sample_infected(p.cpu(), noise) > 0.5)
 
 
+def test_is_infected_sampler_straight_through_gradient(G, device):
+    """IsInfectedSampler in grad mode = F.gumbel_softmax(tau=0.1, hard=True) (infection.py:13-18): same hard
+    decisions and the same straight-through gradient as the oracle's autograd for the same noise."""
+    sampler = G.IsInfectedSampler()
+    g = torch.Generator().manual_seed(8)
+    n = 5000
+    p0 = torch.rand(n, generator=g) * 0.98 + 0.01
+    noise = O.draw_exp_noise(n)
+    w = torch.rand(n, generator=g)
+    p_dev = p0.clone().to(device).requires_grad_()
+    out = sampler(p_dev, exp_noise=noise)
+    assert out.requires_grad and set(np.unique(out.detach().cpu().numpy().round(6)).tolist()) <= {0.0, 1.0}
+    got, = torch.autograd.grad((out * w.to(device)).sum(), p_dev)
+    p_ref = p0.clone().requires_grad_()
+    ref_out = O.sample_infected(p_ref, noise)
+    assert torch.equal(out.detach().cpu() > 0.5, ref_out.detach() > 0.5)
+    ref, = torch.autograd.grad((ref_out * w).sum(), p_ref)
+    assert torch.allclose(got.cpu(), ref, rtol=1e-3, atol=1e-5)
+    assert sampler(p_dev).requires_grad                                    # own noise: still on the graph
+
+
 def test_standalone_probabilities_are_differentiable(G, device):
     """The stand-alone InfectionNetworks.forward (base.py:118-141) in grad mode: gradients w.r.t. every log_beta,
     the transmissions and the susceptibilities equal autograd through the oracle's op-for-op restatement; with a
