@@ -217,7 +217,7 @@ class DistributedHotPath:
 
     def __init__(self, world: dict, specs, betas: Dict[str, float], device, rank: int, world_size: int,
                  seed: int = 0, group=None, modes: Optional[Dict[str, str]] = None, collectives: bool = True,
-                 progress=None, min_group_floats: int = 1 << 16):
+                 progress=None, min_group_floats: int = 1 << 16, production_at_one_rank: bool = False):
         from . import _native as N
         from .benchrun import EventLog
         from .engine import AgentBuffers, InfectionEngine
@@ -262,7 +262,9 @@ class DistributedHotPath:
             N.check(lib.gj_pack_f32(index.numel(), N.ptr(index), N.ptr(src), N.ptr(out), N.current_stream()),
                     "gj_pack_f32")
 
-        self.halo = HaloExchange(rw, self.device, group=group, pack=pack) if (world_size > 1 and collectives) else None
+        # production_at_one_rank: diagnostics - take the overlapped multi-rank step with a single rank
+        self.halo = (HaloExchange(rw, self.device, group=group, pack=pack)
+                     if (collectives and (world_size > 1 or production_at_one_rank)) else None)
         self.a0 = a0
         self.t = 0
         self.log = EventLog()

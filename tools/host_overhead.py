@@ -33,7 +33,11 @@ def main():
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     modes = {k: ("partial" if k != "household" else "local") for k in choose_modes(world, 1)}
     runners = {"single": SingleGpuHotPath(world, specs, betas, dev, seed=1, layout="tiled"),
-               "distributed(1 rank)": DistributedHotPath(world, specs, betas, dev, 0, 1, seed=1, modes=modes)}
+               "distributed(1 rank), sequential form": DistributedHotPath(world, specs, betas, dev, 0, 1, seed=1, modes=modes),
+               "distributed(1 rank), production form, one all-reduce": DistributedHotPath(
+                   world, specs, betas, dev, 0, 1, seed=1, modes=modes, production_at_one_rank=True),
+               "distributed(1 rank), production form, two all-reduces": DistributedHotPath(
+                   world, specs, betas, dev, 0, 1, seed=1, modes=modes, production_at_one_rank=True, min_group_floats=1)}
     for name, r in runners.items():
         for _ in range(20):
             r.step()
