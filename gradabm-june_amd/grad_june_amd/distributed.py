@@ -28,6 +28,7 @@ import torch
 from . import tiling as TL
 
 HALO_MAX_MEAN_DEGREE = 8.0     # sets whose venues average more attendees use partial sums
+PIPELINE_MIN_EDGES = 20_000_000  # set-edges per rank from which the largest partial-sum set gets its own all-reduce
 
 
 def reduce_groups(floats: Dict[str, int], min_floats: int = 1 << 16) -> List[List[str]]:
@@ -233,7 +234,12 @@ class DistributedHotPath:
             nets_on[sp.edge_set] = nets_on.get(sp.edge_set, 0) + 1
         floats = {n: max(1, len(es["people"])) * max(1, nets_on.get(n, 1))
                   for n, es in rw.edge_sets.items() if rw.modes[n] == "partial"}
-        self.reduce_groups = reduce_groups(floats, min_group_floats)                     # same on every rank (global sizes)
+        # A second all-reduce costs ~45 us of host time per step (tools/host_overhead.py): worth it only while
+        # the rank's kernels take several times that, i.e. for shares of >= ~2e7 set-edges (global count / ranks,
+        # so every rank takes the same decision)
+        total_edges = sum(len(es["agent"]) for es in world["edge_sets"].values())
+        pipelined = total_edges / max(1, world_size) >= PIPELINE_MIN_EDGES or min_group_floats <= 1
+        self.reduce_groups = reduce_groups(floats, min_group_floats if pipelined else 1 << 62)
         partial = [n for g in self.reduce_groups for n in g]
         self.engine = InfectionEngine(DevicePlan(host, specs, self.device, flat_cum_sets=partial))
         self.flat_cum = self.engine.plan.flat_cum
