@@ -15,7 +15,11 @@ namespace gj {
 
 constexpr int kTileThreads = 1024;  // 16 waves: one workgroup per CU when the slice fills LDS
 constexpr int kTileWaves = kTileThreads / kWave;
-constexpr int kUnroll = 8;          // 64-edge chunks a wave keeps in flight (phases A and D)
+constexpr int kUnroll = 8;          // 64-edge chunks a wave keeps in flight (phases A and D), wide descriptors
+#ifndef GJ_UNROLL_NARROW
+#define GJ_UNROLL_NARROW 16
+#endif
+constexpr int kUnrollNarrow = GJ_UNROLL_NARROW;   // same with 16-byte descriptors (16 of them = one wave-wide load)
 #ifndef GJ_VENUE_UNROLL
 #define GJ_VENUE_UNROLL 2
 #endif
@@ -182,15 +186,16 @@ __device__ __forceinline__ void scatter_set(const TSetA& T, const float* lds_x, 
   const int seg0 = T.tile_sptr[row], seg1 = T.tile_sptr[row + T.J];
   const int c_base = T.chunk_ptr[s];
   const int n_chunks = T.chunk_ptr[s + 1] - c_base;
-  for (int c0 = wave * kUnroll; c0 < n_chunks; c0 += kTileWaves * kUnroll) {
-    int la[kUnroll], slot[kUnroll];
-    const int word = batch_desc_load<WIDE, kUnroll>(T, c_base, n_chunks, c0, lane);   // first: the slots wait on it
+  constexpr int kU = WIDE ? kUnroll : kUnrollNarrow;
+  for (int c0 = wave * kU; c0 < n_chunks; c0 += kTileWaves * kU) {
+    int la[kU], slot[kU];
+    const int word = batch_desc_load<WIDE, kU>(T, c_base, n_chunks, c0, lane);   // first: the slots wait on it
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u)    // unconditional (clamped) loads: straight-line, all in flight
+    for (int u = 0; u < kU; ++u)    // unconditional (clamped) loads: straight-line, all in flight
       la[u] = T.a_la[min(seg0 + (c0 + u) * kWave + lane, seg1 - 1)];
-    batch_slots<WIDE, kUnroll>(T, word, row, seg0, seg1, c0, lane, slot);
+    batch_slots<WIDE, kU>(T, word, row, seg0, seg1, c0, lane, slot);
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
+    for (int u = 0; u < kU; ++u) {
       const int i = seg0 + (c0 + u) * kWave + lane;
       if ((c0 + u < n_chunks) && (i < seg1)) T.val[slot[u]] = lds_x[la[u]];
     }
@@ -203,22 +208,23 @@ __device__ __forceinline__ void gather_set(const TSetA& T, fx_t* lds_acc, int s,
   const int seg0 = T.tile_sptr[row], seg1 = T.tile_sptr[row + T.J];
   const int c_base = T.chunk_ptr[s];
   const int n_chunks = T.chunk_ptr[s + 1] - c_base;
-  for (int c0 = wave * kUnroll; c0 < n_chunks; c0 += kTileWaves * kUnroll) {
-    int la[kUnroll], slot[kUnroll];
-    float v[kUnroll];
-    const int word = batch_desc_load<WIDE, kUnroll>(T, c_base, n_chunks, c0, lane);   // first: the val loads wait on it
+  constexpr int kU = WIDE ? kUnroll : kUnrollNarrow;
+  for (int c0 = wave * kU; c0 < n_chunks; c0 += kTileWaves * kU) {
+    int la[kU], slot[kU];
+    float v[kU];
+    const int word = batch_desc_load<WIDE, kU>(T, c_base, n_chunks, c0, lane);   // first: the val loads wait on it
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u)    // unconditional (clamped) loads: straight-line, all in flight
+    for (int u = 0; u < kU; ++u)    // unconditional (clamped) loads: straight-line, all in flight
       la[u] = T.a_la[min(seg0 + (c0 + u) * kWave + lane, seg1 - 1)];
-    batch_slots<WIDE, kUnroll>(T, word, row, seg0, seg1, c0, lane, slot);
+    batch_slots<WIDE, kU>(T, word, row, seg0, seg1, c0, lane, slot);
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {  // the slot depends on the position only: these loads overlap the ones above
+    for (int u = 0; u < kU; ++u) {  // the slot depends on the position only: these loads overlap the ones above
       const int i = seg0 + (c0 + u) * kWave + lane;
       const bool ok = (c0 + u < n_chunks) && (i < seg1);
       v[u] = T.val[ok ? slot[u] : 0];
     }
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
+    for (int u = 0; u < kU; ++u) {
       const int i = seg0 + (c0 + u) * kWave + lane;
       if ((c0 + u < n_chunks) && (i < seg1)) atomicAdd(&lds_acc[la[u]], to_fx<kFxAgent>(v[u]));
     }
