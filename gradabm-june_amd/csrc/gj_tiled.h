@@ -15,11 +15,12 @@ namespace gj {
 
 constexpr int kTileThreads = 1024;  // 16 waves: one workgroup per CU when the slice fills LDS
 constexpr int kTileWaves = kTileThreads / kWave;
-constexpr int kUnroll = 8;          // 64-edge chunks a wave keeps in flight (phases A and D), wide descriptors
+constexpr int kUnroll = 8;          // 64-edge chunks a wave keeps in flight: phase D, and phase A with wide descriptors
 #ifndef GJ_UNROLL_NARROW
 #define GJ_UNROLL_NARROW 16
 #endif
-constexpr int kUnrollNarrow = GJ_UNROLL_NARROW;   // same with 16-byte descriptors (16 of them = one wave-wide load)
+constexpr int kUnrollNarrow = GJ_UNROLL_NARROW;   // phase A with 16-byte descriptors (16 of them = one wave-wide load):
+                                                  // 0.182 -> 0.149 ms on C3 against 8 (phase A is bound by loads in flight)
 #ifndef GJ_VENUE_UNROLL
 #define GJ_VENUE_UNROLL 2
 #endif
@@ -202,62 +203,35 @@ __device__ __forceinline__ void scatter_set(const TSetA& T, const float* lds_x, 
   }
 }
 
-// Phase D's inner loop for one set.  A batch needs two dependent memory round trips (descriptors -> slots ->
-// the edges' values), so the loop is software-pipelined: the index and descriptor loads of batch k+1 are issued
-// behind the value loads of batch k and stay in flight while batch k's values are waited for (vmcnt counts in
-// order) and added.  Two register sets (A, B) alternate so that nothing is copied.
-#ifndef GJ_GATHER_UNROLL_NARROW
-#define GJ_GATHER_UNROLL_NARROW 8
-#endif
+// Phase D's inner loop for one set.  (Measured, not adopted: software-pipelining this loop - the next batch's
+// index / descriptor loads issued behind the current value loads - and 16 instead of 8 chunks per batch both
+// left the kernel at 0.25 ms on C3: it is bound by the ~0.5 KB granularity of the per-tile value reads.)
 template <bool WIDE>
 __device__ __forceinline__ void gather_set(const TSetA& T, fx_t* lds_acc, int s, int wave, int lane) {
   const int row = s * T.J;
   const int seg0 = T.tile_sptr[row], seg1 = T.tile_sptr[row + T.J];
   const int c_base = T.chunk_ptr[s];
   const int n_chunks = T.chunk_ptr[s + 1] - c_base;
-  constexpr int kU = WIDE ? kUnroll : GJ_GATHER_UNROLL_NARROW;
-  constexpr int kStride = kTileWaves * kU;
-  int c0 = wave * kU;
-  if (c0 >= n_chunks) return;
-  int laA[kU], laB[kU];
-  int wordA, wordB;
-  auto stage1 = [&](int c, int& word, int (&la)[kU]) {        // descriptors + local agent indices of batch c
-    const int cc = min(c, n_chunks - 1);                      // past the end: a harmless re-load of the last chunk
-    word = batch_desc_load<WIDE, kU>(T, c_base, n_chunks, cc, lane);
+  constexpr int kU = kUnroll;
+  for (int c0 = wave * kU; c0 < n_chunks; c0 += kTileWaves * kU) {
+    int la[kU], slot[kU];
+    float v[kU];
+    const int word = batch_desc_load<WIDE, kU>(T, c_base, n_chunks, c0, lane);   // first: the val loads wait on it
 #pragma unroll
-    for (int u = 0; u < kU; ++u) la[u] = T.a_la[min(seg0 + (cc + u) * kWave + lane, seg1 - 1)];
-  };
-  auto stage2_issue = [&](int c, int word, float (&v)[kU]) {  // slots, then the edges' values
-    int slot[kU];
-    batch_slots<WIDE, kU>(T, word, row, seg0, seg1, c, lane, slot);
+    for (int u = 0; u < kU; ++u)    // unconditional (clamped) loads: straight-line, all in flight
+      la[u] = T.a_la[min(seg0 + (c0 + u) * kWave + lane, seg1 - 1)];
+    batch_slots<WIDE, kU>(T, word, row, seg0, seg1, c0, lane, slot);
 #pragma unroll
-    for (int u = 0; u < kU; ++u) {
-      const int i = seg0 + (c + u) * kWave + lane;
-      const bool ok = (c + u < n_chunks) && (i < seg1);
+    for (int u = 0; u < kU; ++u) {  // the slot depends on the position only: these loads overlap the ones above
+      const int i = seg0 + (c0 + u) * kWave + lane;
+      const bool ok = (c0 + u < n_chunks) && (i < seg1);
       v[u] = T.val[ok ? slot[u] : 0];
     }
-  };
-  auto stage3 = [&](int c, const int (&la)[kU], const float (&v)[kU]) {
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
-      const int i = seg0 + (c + u) * kWave + lane;
-      if ((c + u < n_chunks) && (i < seg1)) atomicAdd(&lds_acc[la[u]], to_fx<kFxAgent>(v[u]));
+      const int i = seg0 + (c0 + u) * kWave + lane;
+      if ((c0 + u < n_chunks) && (i < seg1)) atomicAdd(&lds_acc[la[u]], to_fx<kFxAgent>(v[u]));
     }
-  };
-  stage1(c0, wordA, laA);
-  while (true) {
-    float v[kU];
-    stage2_issue(c0, wordA, v);
-    const int c1 = c0 + kStride;
-    stage1(c1, wordB, laB);               // in flight behind batch c0's value loads
-    stage3(c0, laA, v);
-    if (c1 >= n_chunks) break;
-    stage2_issue(c1, wordB, v);
-    const int c2 = c1 + kStride;
-    stage1(c2, wordA, laA);
-    stage3(c1, laB, v);
-    if (c2 >= n_chunks) break;
-    c0 = c2;
   }
 }
 
