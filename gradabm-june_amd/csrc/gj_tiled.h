@@ -181,6 +181,13 @@ __device__ __forceinline__ void batch_slots(const TSetA& T, const int word, int 
 #undef GJ_DW
 }
 
+// Phase A's inner loop for one set.  The kernel is bound by loads in flight (one workgroup of 16 waves per CU),
+// so besides the 16-chunk batches the loop is software-pipelined: batch k+1's index / descriptor loads are
+// issued before batch k's values are read from LDS and stored (vmcnt counts in order, so waiting for batch k
+// leaves them in flight).  Two register sets alternate so that nothing is copied.
+#ifndef GJ_SCATTER_PIPELINE
+#define GJ_SCATTER_PIPELINE 1
+#endif
 template <bool WIDE>
 __device__ __forceinline__ void scatter_set(const TSetA& T, const float* lds_x, int s, int wave, int lane) {
   const int row = s * T.J;
@@ -188,19 +195,45 @@ __device__ __forceinline__ void scatter_set(const TSetA& T, const float* lds_x, 
   const int c_base = T.chunk_ptr[s];
   const int n_chunks = T.chunk_ptr[s + 1] - c_base;
   constexpr int kU = WIDE ? kUnroll : kUnrollNarrow;
-  for (int c0 = wave * kU; c0 < n_chunks; c0 += kTileWaves * kU) {
-    int la[kU], slot[kU];
-    const int word = batch_desc_load<WIDE, kU>(T, c_base, n_chunks, c0, lane);   // first: the slots wait on it
+  constexpr int kStride = kTileWaves * kU;
+  auto stage1 = [&](int c, int& word, int (&la)[kU]) {        // descriptors + local agent indices of batch c
+    const int cc = min(c, n_chunks - 1);                      // past the end: a harmless re-load of the last chunk
+    word = batch_desc_load<WIDE, kU>(T, c_base, n_chunks, cc, lane);   // first: the slots wait on it
 #pragma unroll
-    for (int u = 0; u < kU; ++u)    // unconditional (clamped) loads: straight-line, all in flight
-      la[u] = T.a_la[min(seg0 + (c0 + u) * kWave + lane, seg1 - 1)];
-    batch_slots<WIDE, kU>(T, word, row, seg0, seg1, c0, lane, slot);
+    for (int u = 0; u < kU; ++u) la[u] = T.a_la[min(seg0 + (cc + u) * kWave + lane, seg1 - 1)];
+  };
+  auto stage2 = [&](int c, int word, const int (&la)[kU]) {
+    int slot[kU];
+    batch_slots<WIDE, kU>(T, word, row, seg0, seg1, c, lane, slot);
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
-      const int i = seg0 + (c0 + u) * kWave + lane;
-      if ((c0 + u < n_chunks) && (i < seg1)) T.val[slot[u]] = lds_x[la[u]];
+      const int i = seg0 + (c + u) * kWave + lane;
+      if ((c + u < n_chunks) && (i < seg1)) T.val[slot[u]] = lds_x[la[u]];
     }
+  };
+  int c0 = wave * kU;
+  if (c0 >= n_chunks) return;
+  int laA[kU], wordA;
+#if GJ_SCATTER_PIPELINE
+  int laB[kU], wordB;
+  stage1(c0, wordA, laA);
+  while (true) {
+    const int c1 = c0 + kStride;
+    stage1(c1, wordB, laB);
+    stage2(c0, wordA, laA);
+    if (c1 >= n_chunks) break;
+    const int c2 = c1 + kStride;
+    stage1(c2, wordA, laA);
+    stage2(c1, wordB, laB);
+    if (c2 >= n_chunks) break;
+    c0 = c2;
   }
+#else
+  for (; c0 < n_chunks; c0 += kStride) {
+    stage1(c0, wordA, laA);
+    stage2(c0, wordA, laA);
+  }
+#endif
 }
 
 // Phase D's inner loop for one set.  (Measured, not adopted: software-pipelining this loop - the next batch's
