@@ -80,6 +80,15 @@ __device__ __forceinline__ float gumbel_new_infected(float p, float e0, float e1
   return 1.0f - ret0;
 }
 
+// The same decision when the noise is the library's own Philox stream (no reference draw to reproduce):
+// argmax of the two Gumbel-perturbed logits, log(1-p) - log(e1) > log(p) - log(e0), is (1-p)*e0 > p*e1 -
+// a monotone transform, so the same (e0, e1) give the same outcome (up to rounding at exact ties) at a third
+// of the transcendental work.  p = 1 never infects, p = 0 always does, as in the reference.  The backward
+// pass (k_adjoint_sample) replays this rule from the same draws.
+__device__ __forceinline__ float ratio_new_infected(float p, float e0, float e1) {
+  return ((1.0f - p) * e0 > p * e1) ? 1.0f : 0.0f;
+}
+
 // a9: GradJune.infect_people (reference grad_june/model.py:103-110)
 __device__ __forceinline__ void infect(float nw, float now, float& susc, float& inf, float& t_inf) {
   susc = fmaxf(0.0f, susc - nw);

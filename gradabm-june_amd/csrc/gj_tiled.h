@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256) void k_tile_epilogue(const TileDArgs D) {
   } else {
     exp_pair(D.seed, D.step, D.agent_offset + a, e0, e1);
   }
-  const float nw = gumbel_new_infected(p, e0, e1);
+  const float nw = D.exp_noise ? gumbel_new_infected(p, e0, e1) : ratio_new_infected(p, e0, e1);
   if (D.new_infected) D.new_infected[a] = nw;
   if (nw != 0.0f) {
     float inf = D.is_infected[a], t_inf = D.infection_time[a];
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
       if (!D.sample) continue;
       float e0 = e0_b[u], e1 = e1_b[u];
       if (!D.exp_noise) exp_pair(D.seed, D.step, D.agent_offset + a, e0, e1);
-      const float nw = gumbel_new_infected(p, e0, e1);
+      const float nw = D.exp_noise ? gumbel_new_infected(p, e0, e1) : ratio_new_infected(p, e0, e1);
       if (D.new_infected) D.new_infected[a] = nw;
       if (nw != 0.0f) {
         float inf = D.is_infected[a], t_inf = D.infection_time[a];
