@@ -19,8 +19,8 @@ __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
-// ---- Philox4x32-10 (Salmon et al., SC'11), counter = (agent lo, agent hi, step lo, step hi),
-// key = seed.  One call yields the two Exponential(1) draws an agent needs.
+// ---- Philox4x32-10 (Salmon et al., SC'11), counter = (pair lo, pair hi, step lo, step hi), key = seed.
+// One call yields the two Exponential(1) draws of each agent of a pair (see exp_pair).
 __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
   const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]);
   const uint32_t lo0 = 0xD2511F53u * c[0];
@@ -54,11 +54,17 @@ __device__ __forceinline__ void philox4x32_10(uint64_t ctr_lo, uint64_t ctr_hi, 
 // 24 random bits -> uniform in (0,1), every value exactly representable, never 0 or 1.
 __device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * 5.9604644775390625e-8f; }
 
+// One Philox block serves the agent pair (2k, 2k+1) of GLOBAL agent ids: counter = agent >> 1, the even agent
+// takes words 0-1, the odd one words 2-3 (the integer multiplies of the ten rounds are the expensive part of
+// the sampler; the fused tiled epilogue computes one block per pair, every other caller one per agent).
+__device__ __forceinline__ void exp_from_block(const uint32_t (&r)[4], int half, float& e0, float& e1) {
+  e0 = -logf(u01(half ? r[2] : r[0]));
+  e1 = -logf(u01(half ? r[3] : r[1]));
+}
 __device__ __forceinline__ void exp_pair(uint64_t seed, uint64_t step, int64_t agent, float& e0, float& e1) {
   uint32_t r[4];
-  philox4x32_10((uint64_t)agent, step, seed, r);
-  e0 = -logf(u01(r[0]));
-  e1 = -logf(u01(r[1]));
+  philox4x32_10((uint64_t)agent >> 1, step, seed, r);
+  exp_from_block(r, (int)(agent & 1), e0, e1);
 }
 
 // a8: IsInfectedSampler.forward = F.gumbel_softmax(vstack(p, 1-p).log(), tau=0.1, hard=True, dim=0)

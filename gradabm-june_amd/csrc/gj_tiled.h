@@ -555,40 +555,58 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
     for (int i = tid; i < n_local; i += kTileThreads) D.acc_scratch[base + i] = from_fx<kFxAgent>(lds_acc[i]);
     return;
   }
-  constexpr int kEp = 4;   // agents per lane whose loads are issued together
-  for (int i0 = tid; i0 < n_local; i0 += kEp * kTileThreads) {
-    float susc_b[kEp], e0_b[kEp], e1_b[kEp];
+  // Epilogue: each lane takes adjacent agent pairs (2j, 2j+1), kPairs of them per iteration with their loads
+  // issued together; in Philox mode one block serves both agents of a pair.
+  constexpr int kPairs = 2;
+  const bool pair_aligned = ((D.agent_offset + base) & 1) == 0;   // local pairs are global pairs (else: per agent)
+  for (int j0 = tid; 2 * j0 < n_local; j0 += kPairs * kTileThreads) {
+    float susc_b[2 * kPairs], e0_b[2 * kPairs], e1_b[2 * kPairs];
 #pragma unroll
-    for (int u = 0; u < kEp; ++u) {
-      const int i = i0 + u * kTileThreads;
-      const bool ok = i < n_local;
-      susc_b[u] = ok ? D.susceptibility[base + i] : 0.0f;
-      e0_b[u] = (ok && D.sample && D.exp_noise) ? D.exp_noise[base + i] : 1.0f;
-      e1_b[u] = (ok && D.sample && D.exp_noise) ? D.exp_noise[D.n_agents + base + i] : 1.0f;
+    for (int u = 0; u < kPairs; ++u) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int i = 2 * (j0 + u * kTileThreads) + h;
+        const bool ok = i < n_local;
+        susc_b[2 * u + h] = ok ? D.susceptibility[base + i] : 0.0f;
+        e0_b[2 * u + h] = (ok && D.sample && D.exp_noise) ? D.exp_noise[base + i] : 1.0f;
+        e1_b[2 * u + h] = (ok && D.sample && D.exp_noise) ? D.exp_noise[D.n_agents + base + i] : 1.0f;
+      }
     }
 #pragma unroll
-    for (int u = 0; u < kEp; ++u) {
-      const int i = i0 + u * kTileThreads;
-      if (i >= n_local) continue;
-      const int64_t a = base + i;
-      float susc = susc_b[u];
-      float ts = susc * from_fx<kFxAgent>(lds_acc[i]);
-      if (D.trans_susc) D.trans_susc[a] = ts;
-      ts = fminf(fmaxf(ts, 1e-6f), 100.0f);
-      float p = expf(-ts * D.dt);
-      p = fminf(fmaxf(p, 0.0f), 1.0f);
-      if (D.not_infected_probs) D.not_infected_probs[a] = p;
-      if (!D.sample) continue;
-      float e0 = e0_b[u], e1 = e1_b[u];
-      if (!D.exp_noise) exp_pair(D.seed, D.step, D.agent_offset + a, e0, e1);
-      const float nw = D.exp_noise ? gumbel_new_infected(p, e0, e1) : ratio_new_infected(p, e0, e1);
-      if (D.new_infected) D.new_infected[a] = nw;
-      if (nw != 0.0f) {
-        float inf = D.is_infected[a], t_inf = D.infection_time[a];
-        infect(nw, D.now, susc, inf, t_inf);
-        D.susceptibility[a] = susc;
-        D.is_infected[a] = inf;
-        D.infection_time[a] = t_inf;
+    for (int u = 0; u < kPairs; ++u) {
+      const int i_pair = 2 * (j0 + u * kTileThreads);
+      if (i_pair >= n_local) continue;
+      uint32_t r[4] = {0u, 0u, 0u, 0u};
+      const bool block = D.sample && !D.exp_noise && pair_aligned;
+      if (block) philox4x32_10((uint64_t)(D.agent_offset + base + i_pair) >> 1, D.step, D.seed, r);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int i = i_pair + h;
+        if (i >= n_local) continue;
+        const int64_t a = base + i;
+        float susc = susc_b[2 * u + h];
+        float ts = susc * from_fx<kFxAgent>(lds_acc[i]);
+        if (D.trans_susc) D.trans_susc[a] = ts;
+        ts = fminf(fmaxf(ts, 1e-6f), 100.0f);
+        float p = expf(-ts * D.dt);
+        p = fminf(fmaxf(p, 0.0f), 1.0f);
+        if (D.not_infected_probs) D.not_infected_probs[a] = p;
+        if (!D.sample) continue;
+        float e0 = e0_b[2 * u + h], e1 = e1_b[2 * u + h];
+        if (block) {
+          exp_from_block(r, h, e0, e1);
+        } else if (!D.exp_noise) {
+          exp_pair(D.seed, D.step, D.agent_offset + a, e0, e1);
+        }
+        const float nw = D.exp_noise ? gumbel_new_infected(p, e0, e1) : ratio_new_infected(p, e0, e1);
+        if (D.new_infected) D.new_infected[a] = nw;
+        if (nw != 0.0f) {
+          float inf = D.is_infected[a], t_inf = D.infection_time[a];
+          infect(nw, D.now, susc, inf, t_inf);
+          D.susceptibility[a] = susc;
+          D.is_infected[a] = inf;
+          D.infection_time[a] = t_inf;
+        }
       }
     }
   }
