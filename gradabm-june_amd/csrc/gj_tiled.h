@@ -188,13 +188,12 @@ __device__ __forceinline__ void batch_slots(const TSetA& T, const int word, int 
 #ifndef GJ_SCATTER_PIPELINE
 #define GJ_SCATTER_PIPELINE 1
 #endif
-template <bool WIDE>
-__device__ __forceinline__ void scatter_set(const TSetA& T, const float* lds_x, int s, int wave, int lane) {
+template <bool WIDE, int kU>
+__device__ __forceinline__ void scatter_batches(const TSetA& T, const float* lds_x, int s, int wave, int lane) {
   const int row = s * T.J;
   const int seg0 = T.tile_sptr[row], seg1 = T.tile_sptr[row + T.J];
   const int c_base = T.chunk_ptr[s];
   const int n_chunks = T.chunk_ptr[s + 1] - c_base;
-  constexpr int kU = WIDE ? kUnroll : kUnrollNarrow;
   constexpr int kStride = kTileWaves * kU;
   auto stage1 = [&](int c, int& word, int (&la)[kU]) {        // descriptors + local agent indices of batch c
     const int cc = min(c, n_chunks - 1);                      // past the end: a harmless re-load of the last chunk
@@ -234,6 +233,20 @@ __device__ __forceinline__ void scatter_set(const TSetA& T, const float* lds_x, 
     stage2(c0, wordA, laA);
   }
 #endif
+}
+
+// 16-chunk batches pay off when a slice has several hundred chunks of the set to stream (C3 at 10 M agents: 459,
+// phase A 0.182 -> 0.149 ms); on short segments they lose (C2, 309 chunks: 0.041 -> 0.071 ms), so the batch size
+// is chosen per slice and set (wave-uniform).
+constexpr int kLongSegmentChunks = 384;
+template <bool WIDE>
+__device__ __forceinline__ void scatter_set(const TSetA& T, const float* lds_x, int s, int wave, int lane) {
+  const int n_chunks = T.chunk_ptr[s + 1] - T.chunk_ptr[s];
+  if (!WIDE && kUnrollNarrow != kUnroll && n_chunks >= kLongSegmentChunks) {
+    scatter_batches<WIDE, WIDE ? kUnroll : kUnrollNarrow>(T, lds_x, s, wave, lane);
+  } else {
+    scatter_batches<WIDE, kUnroll>(T, lds_x, s, wave, lane);
+  }
 }
 
 // Phase D's inner loop for one set.  (Measured, not adopted: software-pipelining this loop - the next batch's
