@@ -438,3 +438,34 @@ class PartitionedHotPath:
 
     def kernel_ms(self) -> Dict[str, float]:
         return {k: float(np.mean(v)) for k, v in self.log.spans().items()}
+
+
+def world_from_data(data, model=None, networks: Optional[Sequence[str]] = None) -> dict:
+    """A world in the reference's graph format (``HeteroData`` as ``Runner.get_data`` leaves it) -> the neutral
+    description ``build_rank_world`` / ``DistributedHotPath`` partition: ``n_agents``, ``age``, ``sex``, the COO
+    edge sets with their ``people`` counts, the per-agent state, and ``networks`` = the infection networks of
+    ``model`` (a ``GradJune``) or the given names, restricted to the edge sets the world has."""
+    from .synthetic import edge_set_of
+
+    ag = data["agent"]
+    n = len(ag["id"])
+    np_ = lambda t: t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+    world = {"preset": "data", "n_agents": n, "age": np_(ag["age"]).astype(np.int64),
+             "sex": (np_(ag["sex"]) if "sex" in ag else np.zeros(n)).astype(np.int64), "edge_sets": {}}
+    for key, store in data.edge_items():
+        src, rel, dst = key
+        if src != "agent" or not rel.startswith("attends_") or "edge_index" not in store:
+            continue
+        ei = np_(store.edge_index).astype(np.int64)
+        people = np_(data[dst]["people"]).astype(np.int64)
+        world["edge_sets"][rel[len("attends_"):]] = {"agent": ei[0], "venue": ei[1], "people": people}
+    if networks is None:
+        networks = list(model.infection_networks.networks.keys()) if model is not None else list(world["edge_sets"])
+    world["networks"] = [name for name in networks if edge_set_of(name) in world["edge_sets"]]
+    f32 = lambda t: np_(t).astype(np.float32)
+    ip = ag["infection_parameters"]
+    world["state"] = {k: f32(ip[k]) for k in ("max_infectiousness", "shape", "rate", "shift")}
+    for k in ("is_infected", "susceptibility", "infection_time"):
+        world["state"][k] = f32(ag[k])
+    world["state"]["current_stage"] = f32(ag["symptoms"]["current_stage"])
+    return world

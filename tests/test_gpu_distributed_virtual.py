@@ -31,10 +31,28 @@ class VirtualRank(DistributedHotPath):
         self.t += 1
 
 
-@pytest.mark.parametrize("R", [2, 4])
-def test_virtual_ranks_match_single_rank(device, R):
-    world = make_world("c3", n_agents=40_000, seed=3, infected_fraction=0.05)
+def reference_world(device):
+    """The reference's 769-agent world through the drop-in API (Runner.get_data + seeding), as the neutral
+    description the partitioner takes (distributed.world_from_data); 11 networks incl. care_visit."""
+    import grad_june_amd as G
+    from grad_june_amd.defaults import default_parameters
+    from grad_june_amd.distributed import world_from_data
+
+    torch.manual_seed(12)
+    params = default_parameters(str(device))
+    params["infection_seed"]["log_fraction_initial_cases"] = -1.0
+    runner = G.Runner.from_parameters(params)
+    world = world_from_data(runner.data, model=runner.model)
+    assert world["n_agents"] == 769 and len(world["networks"]) == 11 and world["state"]["is_infected"].sum() > 20
+    return world
+
+
+@pytest.mark.parametrize("R,source", [(2, "c3"), (4, "c3"), (3, "reference-769")])
+def test_virtual_ranks_match_single_rank(device, R, source):
+    world = (make_world("c3", n_agents=40_000, seed=3, infected_fraction=0.05) if source == "c3"
+             else reference_world(device))
     specs, betas = B.network_specs(world), B.betas_of(world)
+    betas = {k: 3.0 * v for k, v in betas.items()} if source != "c3" else betas
     single = SingleGpuHotPath(world, specs, betas, device, seed=7, layout="tiled")
     ranks = [VirtualRank(world, specs, betas, device, r, R, seed=7, collectives=False) for r in range(R)]
     assert {m for rk in ranks for m in rk.rw.modes.values()} == {"halo", "partial"}
