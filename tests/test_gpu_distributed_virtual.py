@@ -42,6 +42,7 @@ def reference_world(device):
     params = default_parameters(str(device))
     params["infection_seed"]["log_fraction_initial_cases"] = -1.0
     runner = G.Runner.from_parameters(params)
+    runner.set_initial_cases()
     world = world_from_data(runner.data, model=runner.model)
     assert world["n_agents"] == 769 and len(world["networks"]) == 11 and world["state"]["is_infected"].sum() > 20
     return world
