@@ -444,7 +444,8 @@ def world_from_data(data, model=None, networks: Optional[Sequence[str]] = None) 
     """A world in the reference's graph format (``HeteroData`` as ``Runner.get_data`` leaves it) -> the neutral
     description ``build_rank_world`` / ``DistributedHotPath`` partition: ``n_agents``, ``age``, ``sex``, the COO
     edge sets with their ``people`` counts, the per-agent state, and ``networks`` = the infection networks of
-    ``model`` (a ``GradJune``) or the given names, restricted to the edge sets the world has."""
+    ``model`` (a ``GradJune``) or the given names, restricted to the edge sets the world has and listed in the
+    activity-hierarchy order in which the reference accumulates them."""
     from .synthetic import edge_set_of
 
     ag = data["agent"]
@@ -461,7 +462,11 @@ def world_from_data(data, model=None, networks: Optional[Sequence[str]] = None) 
         world["edge_sets"][rel[len("attends_"):]] = {"agent": ei[0], "venue": ei[1], "people": people}
     if networks is None:
         networks = list(model.infection_networks.networks.keys()) if model is not None else list(world["edge_sets"])
-    world["networks"] = [name for name in networks if edge_set_of(name) in world["edge_sets"]]
+    from .timer import activity_hierarchy
+
+    # in the reference's accumulation order (timer.py:14-26), which also keeps the networks of one set adjacent
+    world["networks"] = sorted((name for name in networks if edge_set_of(name) in world["edge_sets"]),
+                               key=activity_hierarchy.index)
     f32 = lambda t: np_(t).astype(np.float32)
     ip = ag["infection_parameters"]
     world["state"] = {k: f32(ip[k]) for k in ("max_infectiousness", "shape", "rate", "shift")}
