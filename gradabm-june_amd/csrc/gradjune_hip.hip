@@ -587,6 +587,7 @@ struct StatsArgs {
   int32_t n_bins;
   int32_t edges[GJ_MAX_AGE_BINS + 1];
   int32_t dead;
+  int32_t vec4;     // all three arrays 16-byte (cls: 4-byte) aligned
   double* out;
 };
 
@@ -597,15 +598,30 @@ __global__ __launch_bounds__(kThreads) void k_step_stats(const StatsArgs S) {
 #pragma unroll
   for (int k = 0; k < kOut; ++k) acc[k] = 0.0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; a < S.n; a += stride) {
-    const float inf = S.inf[a];
-    const int age = S.cls[a] % 100;
+  auto take = [&](float inf, float stage, int cls) {
+    const int age = cls % 100;
     acc[0] += inf;
 #pragma unroll
     for (int b = 0; b < GJ_MAX_AGE_BINS; ++b)
       if (b < S.n_bins && age > S.edges[b] && age < S.edges[b + 1]) acc[1 + b] += inf;
-    if (S.stage[a] == (float)S.dead) acc[GJ_MAX_AGE_BINS + 1] += 1.0;
+    if (stage == (float)S.dead) acc[GJ_MAX_AGE_BINS + 1] += 1.0;
+  };
+  int64_t first_scalar = 0;
+  if (S.vec4) {   // 16-byte aligned arrays: four agents per lane and load (the scalar form is latency-bound)
+    const int64_t n4 = S.n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+      const float4 f = reinterpret_cast<const float4*>(S.inf)[i];
+      const float4 g = reinterpret_cast<const float4*>(S.stage)[i];
+      const uint32_t c = reinterpret_cast<const uint32_t*>(S.cls)[i];
+      take(f.x, g.x, (int)(c & 0xFF));
+      take(f.y, g.y, (int)((c >> 8) & 0xFF));
+      take(f.z, g.z, (int)((c >> 16) & 0xFF));
+      take(f.w, g.w, (int)(c >> 24));
+    }
+    first_scalar = n4 << 2;
   }
+  for (int64_t a = first_scalar + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; a < S.n; a += stride)
+    take(S.inf[a], S.stage[a], (int)S.cls[a]);
   const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
 #pragma unroll
   for (int k = 0; k < kOut; ++k) {
@@ -1210,8 +1226,10 @@ int gj_step_stats(int64_t n, const uint8_t* agent_class, const float* is_infecte
   for (int b = 0; b <= GJ_MAX_AGE_BINS; ++b) S.edges[b] = (b <= n_bins) ? bin_edges[b] : 0;
   S.dead = dead_stage;
   S.out = out;
-  int64_t blocks = (n + gj::kThreads - 1) / gj::kThreads;
+  S.vec4 = (((uintptr_t)is_infected | (uintptr_t)current_stage) % 16 == 0 && (uintptr_t)agent_class % 4 == 0) ? 1 : 0;
+  int64_t blocks = ((S.vec4 ? (n >> 2) + 3 : n) + gj::kThreads - 1) / gj::kThreads;
   if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(gj::k_step_stats, dim3((unsigned)blocks), dim3(gj::kThreads), 0, (hipStream_t)stream, S);
   return gj::launch_status();
 }
