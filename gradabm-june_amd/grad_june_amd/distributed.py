@@ -172,7 +172,9 @@ class HaloExchange:
         if local.numel() and (int(local.min()) < 0 or int(local.max()) >= rw.n_local):
             raise RuntimeError("halo setup: a peer asked for an agent this rank does not own")
         self.send_index = local.to(device=data_device, dtype=torch.int32).contiguous()
-        self.send_buf = torch.empty(self.send_index.numel(), dtype=torch.float32, device=data_device)
+        # one staging buffer per array exchanged in a step (0: transmission, 1: q * transmission): an asynchronous
+        # all-to-all may still be reading the first while the second is packed
+        self.send_bufs = [torch.empty(self.send_index.numel(), dtype=torch.float32, device=data_device) for _ in range(2)]
         # a collective is entered by every rank or by none: skip the per-step exchange only if NO rank has halo
         total = torch.tensor([self.send_index.numel() + rw.n_halo], dtype=torch.int64, device=self.device)
         dist.all_reduce(total, group=group)
@@ -182,24 +184,25 @@ class HaloExchange:
     def bytes_per_step(self) -> int:
         return 4 * (self.send_index.numel() + sum(self.recv_counts))
 
-    def exchange(self, x: torch.Tensor, async_op: bool = False):
+    def exchange(self, x: torch.Tensor, async_op: bool = False, which: int = 0):
         """x: float32[n_ext]; fills x[n_local_pad:] with the owners' current values.  With async_op the
         collective runs on the backend's own stream and a work handle is returned (wait() before use)."""
         import torch.distributed as dist
 
         if not self.active:
             return None
+        send_buf = self.send_bufs[which]
         if self.pack is not None:
-            self.pack(self.send_index, x, self.send_buf)
+            self.pack(self.send_index, x, send_buf)
         else:
-            torch.index_select(x, 0, self.send_index.long(), out=self.send_buf)
+            torch.index_select(x, 0, self.send_index.long(), out=send_buf)
         recv = x[self.rw.n_local_pad:self.rw.n_local_pad + self.rw.n_halo]
         if self.host_staged:
             tmp = torch.empty(self.rw.n_halo, dtype=torch.float32)
-            dist.all_to_all_single(tmp, self.send_buf.cpu(), self.recv_counts, self.send_counts, group=self.group)
+            dist.all_to_all_single(tmp, send_buf.cpu(), self.recv_counts, self.send_counts, group=self.group)
             recv.copy_(tmp)
             return None
-        return dist.all_to_all_single(recv, self.send_buf, self.recv_counts, self.send_counts, group=self.group,
+        return dist.all_to_all_single(recv, send_buf, self.recv_counts, self.send_counts, group=self.group,
                                       async_op=async_op)
 
 
@@ -218,7 +221,8 @@ class DistributedHotPath:
 
     def __init__(self, world: dict, specs, betas: Dict[str, float], device, rank: int, world_size: int,
                  seed: int = 0, group=None, modes: Optional[Dict[str, str]] = None, collectives: bool = True,
-                 progress=None, min_group_floats: int = 1 << 16, production_at_one_rank: bool = False):
+                 progress=None, min_group_floats: int = 1 << 16, production_at_one_rank: bool = False,
+                 quarantine_threshold: Optional[float] = None):
         from . import _native as N
         from .benchrun import EventLog
         from .engine import AgentBuffers, InfectionEngine
@@ -255,12 +259,22 @@ class DistributedHotPath:
         a0, a1 = int(rw.bounds[rank]), int(rw.bounds[rank + 1])
         st = {k: torch.from_numpy(np.ascontiguousarray(v[a0:a1])).to(self.device) for k, v in world["state"].items()}
         st["transmission"] = torch.zeros(rw.n_ext, dtype=torch.float32, device=self.device)
+        self.q_thr = quarantine_threshold
+        # quarantine (quarantine_policies.py:13-33): q * transmission is a second per-agent array of pass 1; its halo
+        # part travels like the transmissions' when a MASKED edge set runs in halo mode (households read raw values)
+        st["q_transmission"] = (torch.zeros(rw.n_ext, dtype=torch.float32, device=self.device)
+                                if quarantine_threshold is not None else None)
+        from . import _native as N_
+
+        self.exchange_q = quarantine_threshold is not None and any(
+            rw.modes[sp.edge_set] == "halo" and sp.mask_kind != N_.MASK_RAW for sp in specs if sp.edge_set in rw.modes)
         self.state = st
         self.new_infected = torch.empty(rw.n_local, dtype=torch.float32, device=self.device)
         self.bufs = AgentBuffers(self.engine.plan, max_infectiousness=st["max_infectiousness"], shape=st["shape"],
                                  rate=st["rate"], shift=st["shift"], infection_time=st["infection_time"],
                                  is_infected=st["is_infected"], susceptibility=st["susceptibility"],
-                                 transmission=st["transmission"], current_stage=st["current_stage"])
+                                 transmission=st["transmission"], current_stage=st["current_stage"],
+                                 q_transmission=st["q_transmission"])
         self.io = self.engine.io(new_infected=self.new_infected)
         lib = N.load()
 
@@ -290,7 +304,9 @@ class DistributedHotPath:
                 nets = [n for n in nets if self.rw.modes[edge_set_of(n)] in want]
             elif only is not None:
                 nets = [n for n in nets if edge_set_of(n) in key]
+            has_q = self.q_thr is not None
             p = self.engine.params(now=1.0, delta_time=1.0, day_type=0, active=nets, betas=self.betas,
+                                   has_quarantine=has_q, q_threshold=self.q_thr if has_q else float("inf"),
                                    seed=self.seed, step=0, agent_offset=self.a0)
             self._params_cache[key] = p
         p.now, p.step = 1.0 + self.t, self.t
@@ -324,6 +340,8 @@ class DistributedHotPath:
             mark("transmission")
             if self.halo is not None:
                 self.halo.exchange(self.state["transmission"])
+                if self.exchange_q:
+                    self.halo.exchange(self.state["q_transmission"], which=1)
                 mark("halo_all_to_all")
             e.step_phase(self.bufs, p_all, self.io, 1)
             mark("tile_scatter")
@@ -343,6 +361,7 @@ class DistributedHotPath:
         # big all-reduce is in flight while the remaining groups are still computing.
         e.step_phase(self.bufs, p_all, self.io, 0)                        # transmission
         h = self.halo.exchange(self.state["transmission"], async_op=True)  # all-to-all on the comm stream
+        hq = self.halo.exchange(self.state["q_transmission"], async_op=True, which=1) if self.exchange_q else None
         pending = []
         for g, buf in zip(self.reduce_groups, self.group_cum):
             p_g = self.params(g)
@@ -350,8 +369,9 @@ class DistributedHotPath:
                 continue
             e.step_phase(self.bufs, p_g, self.io, 7)                      # A, B of this group's sets
             pending.append((p_g, self._all_reduce(True, buf)))            # all-reduce on the comm stream
-        if h is not None:
-            h.wait()
+        for work in (h, hq):
+            if work is not None:
+                work.wait()
         p_x = self.params(self.exchange_sets)
         if p_x.n_nets:
             e.step_phase(self.bufs, p_x, self.io, 8)                      # A, B, C of the halo / local sets

@@ -48,14 +48,24 @@ def reference_world(device):
     return world
 
 
-@pytest.mark.parametrize("R,source", [(2, "c3"), (4, "c3"), (3, "reference-769")])
+@pytest.mark.parametrize("R,source", [(2, "c3"), (4, "c3"), (3, "reference-769"), (3, "c3-quarantine")])
 def test_virtual_ranks_match_single_rank(device, R, source):
-    world = (make_world("c3", n_agents=40_000, seed=3, infected_fraction=0.05) if source == "c3"
-             else reference_world(device))
+    world = (reference_world(device) if source == "reference-769"
+             else make_world("c3", n_agents=40_000, seed=3, infected_fraction=0.05))
     specs, betas = B.network_specs(world), B.betas_of(world)
-    betas = {k: 3.0 * v for k, v in betas.items()} if source != "c3" else betas
-    single = SingleGpuHotPath(world, specs, betas, device, seed=7, layout="tiled")
-    ranks = [VirtualRank(world, specs, betas, device, r, R, seed=7, collectives=False) for r in range(R)]
+    betas = {k: 3.0 * v for k, v in betas.items()} if source == "reference-769" else betas
+    kw, modes = {}, None
+    if source == "c3-quarantine":
+        # an active quarantine policy, with a MASKED set (care homes) forced into halo mode: its halo agents'
+        # q * transmission must travel too
+        from grad_june_amd.distributed import choose_modes
+
+        kw = {"quarantine_threshold": 4.0}
+        modes = dict(choose_modes(world, R), care_home="halo")
+    single = SingleGpuHotPath(world, specs, betas, device, seed=7, layout="tiled", **kw)
+    ranks = [VirtualRank(world, specs, betas, device, r, R, seed=7, collectives=False, modes=modes, **kw)
+             for r in range(R)]
+    assert all(rk.exchange_q == (source == "c3-quarantine") for rk in ranks)
     assert {m for rk in ranks for m in rk.rw.modes.values()} == {"halo", "partial"}
     b = partition_bounds(world["n_agents"], R)
     for step in range(3):
@@ -63,10 +73,11 @@ def test_virtual_ranks_match_single_rank(device, R, source):
         for rk in ranks:
             rk.step_until_exchange()
         # halo all-to-all stand-in: every rank's halo slots <- the owners' fresh transmissions
-        glob = torch.cat([rk.state["transmission"][: rk.rw.n_local] for rk in ranks])
-        for rk in ranks:
-            idx = torch.from_numpy(rk.rw.halo_global).to(device)
-            rk.state["transmission"][rk.rw.n_local_pad:rk.rw.n_local_pad + rk.rw.n_halo] = glob[idx]
+        for key in ("transmission",) + (("q_transmission",) if ranks[0].exchange_q else ()):
+            glob = torch.cat([rk.state[key][: rk.rw.n_local] for rk in ranks])
+            for rk in ranks:
+                idx = torch.from_numpy(rk.rw.halo_global).to(device)
+                rk.state[key][rk.rw.n_local_pad:rk.rw.n_local_pad + rk.rw.n_halo] = glob[idx]
         for rk in ranks:
             rk.step_after_halo()
         # all-reduce stand-in over the flat partial-sum buffers
