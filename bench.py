@@ -232,7 +232,7 @@ def main():
             modes = {k: ("partial" if v == "local" and k != "household" else v)
                      for k, v in choose_modes(world, 1).items()}
         runner = DistributedHotPath(world, specs, betas, dev, rank, world_size, seed=args.seed, modes=modes,
-                                    progress=progress)
+                                    progress=progress, quarantine_threshold=args.quarantine)
         extra = {"exchange": {"modes": runner.rw.modes, "halo_agents_rank0": int(runner.rw.n_halo),
                               "halo_bytes_per_step_rank0": runner.halo.bytes_per_step if runner.halo else 0,
                               "partial_sum_floats": int(runner.flat_cum.numel()) if runner.flat_cum is not None else 0}}
