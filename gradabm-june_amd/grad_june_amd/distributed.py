@@ -326,61 +326,67 @@ class DistributedHotPath:
         return dist.all_reduce(buf, group=self.group, async_op=async_op)
 
     def step(self, timed: bool = False):
-        """One step.  Untimed (production) form overlaps the collectives with the phases that do not
-        depend on them: the halo all-to-all runs under phases A+B of the partial-sum sets, the
-        partial-sum all-reduces (one per group of ``reduce_groups``) under the later groups' A+B and the
-        halo sets' A+B+C.  The timed form runs everything in sequence, with a single all-reduce, so that
-        every launch and collective can be bracketed by events."""
+        """One step of the benchmark's fixed schedule (all networks, constant betas)."""
+        self.run_step(self.bufs, self.io, self.params, timed=timed)
+        self.t += 1
+
+    def run_step(self, bufs, io, params_of, timed: bool = False):
+        """The multi-rank launch sequence for one step.  ``params_of(None)`` gives the launch parameters of every
+        active network, ``params_of(edge set names)`` those of the networks on these sets (the phase entry points
+        take any subset); ``bufs`` must carry this object's extended ``transmission`` / ``q_transmission`` arrays.
+
+        Untimed (production) form overlaps the collectives with the phases that do not depend on them: the halo
+        all-to-all runs under phases A+B of the partial-sum sets, the partial-sum all-reduces (one per group of
+        ``reduce_groups``) under the later groups' A+B and the halo sets' A+B+C.  The timed form runs everything
+        in sequence, with a single all-reduce, so that every launch and collective can be bracketed by events."""
         e = self.engine
-        p_all = self.params()
+        p_all = params_of(None)
         if timed or self.halo is None:
             mark = self.log.mark if timed else (lambda label: None)
             mark("begin")
-            e.step_phase(self.bufs, p_all, self.io, 0)
+            e.step_phase(bufs, p_all, io, 0)
             mark("transmission")
             if self.halo is not None:
                 self.halo.exchange(self.state["transmission"])
-                if self.exchange_q:
+                if self.exchange_q and p_all.has_quarantine:
                     self.halo.exchange(self.state["q_transmission"], which=1)
                 mark("halo_all_to_all")
-            e.step_phase(self.bufs, p_all, self.io, 1)
+            e.step_phase(bufs, p_all, io, 1)
             mark("tile_scatter")
-            e.step_phase(self.bufs, p_all, self.io, 5)
+            e.step_phase(bufs, p_all, io, 5)
             mark("tile_venues_B")
-            if self._all_reduce(False) is None and timed:
-                pass
+            self._all_reduce(False)
             mark("partial_all_reduce")
-            e.step_phase(self.bufs, p_all, self.io, 6)
+            e.step_phase(bufs, p_all, io, 6)
             mark("tile_venues_C")
-            e.step_phase(self.bufs, p_all, self.io, 3)
+            e.step_phase(bufs, p_all, io, 3)
             mark("tile_agents")
-            self.t += 1
             return
         # Production form.  Sets that need no partial sums ("halo" / "local") run A, B, C under the
         # all-reduces; the partial-sum sets go group by group (largest cum buffer first) so that the
         # big all-reduce is in flight while the remaining groups are still computing.
-        e.step_phase(self.bufs, p_all, self.io, 0)                        # transmission
+        e.step_phase(bufs, p_all, io, 0)                                  # transmission
         h = self.halo.exchange(self.state["transmission"], async_op=True)  # all-to-all on the comm stream
-        hq = self.halo.exchange(self.state["q_transmission"], async_op=True, which=1) if self.exchange_q else None
+        hq = (self.halo.exchange(self.state["q_transmission"], async_op=True, which=1)
+              if (self.exchange_q and p_all.has_quarantine) else None)
         pending = []
         for g, buf in zip(self.reduce_groups, self.group_cum):
-            p_g = self.params(g)
-            if not p_g.n_nets:                                            # no active network on these sets
+            p_g = params_of(g)
+            if not p_g.n_nets:      # no active network on these sets this step (the same decision on every rank)
                 continue
-            e.step_phase(self.bufs, p_g, self.io, 7)                      # A, B of this group's sets
+            e.step_phase(bufs, p_g, io, 7)                                # A, B of this group's sets
             pending.append((p_g, self._all_reduce(True, buf)))            # all-reduce on the comm stream
         for work in (h, hq):
             if work is not None:
                 work.wait()
-        p_x = self.params(self.exchange_sets)
+        p_x = params_of(self.exchange_sets)
         if p_x.n_nets:
-            e.step_phase(self.bufs, p_x, self.io, 8)                      # A, B, C of the halo / local sets
+            e.step_phase(bufs, p_x, io, 8)                                # A, B, C of the halo / local sets
         for p_g, r in pending:
             if r is not None:
                 r.wait()
-            e.step_phase(self.bufs, p_g, self.io, 6)                      # C of the group
-        e.step_phase(self.bufs, p_all, self.io, 3)                        # D + epilogue: all sets
-        self.t += 1
+            e.step_phase(bufs, p_g, io, 6)                                # C of the group
+        e.step_phase(bufs, p_all, io, 3)                                  # D + epilogue: all sets
 
     def reset_timers(self):
         self.log.clear()
