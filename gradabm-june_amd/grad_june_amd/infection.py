@@ -15,14 +15,14 @@ from .world import require_hip
 _philox_step = itertools.count(1 << 40)   # sampler calls outside GradJune.forward get their own streams
 
 
-def _launch_sample(p, exp_noise, new_inf, now=0.0, state=(None, None, None), seed=None, step=None):
+def _launch_sample(p, exp_noise, new_inf, now=0.0, state=(None, None, None), seed=None, step=None, agent_offset=0):
     lib = N.load()
     if seed is None:
         seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
     if step is None:
         step = next(_philox_step)
     s, i, t = state
-    N.check(lib.gj_sample_infect(p.numel(), N.ptr(p), N.ptr(exp_noise), int(seed), int(step), 0, float(now),
+    N.check(lib.gj_sample_infect(p.numel(), N.ptr(p), N.ptr(exp_noise), int(seed), int(step), int(agent_offset), float(now),
                                  N.ptr(new_inf), N.ptr(s), N.ptr(i), N.ptr(t), N.current_stream()),
             "gj_sample_infect")
 
@@ -76,8 +76,9 @@ def infect_people(data, timer, new_infected):
     ag.infection_time = ag.infection_time + nw * (timer.now - ag.infection_time)
 
 
-def infect_fraction_of_people(data, timer, symptoms_updater, fraction, device, exp_noise=None):
-    """Seed: every agent infected independently with probability ``fraction`` (a8+a9 fused launch)."""
+def infect_fraction_of_people(data, timer, symptoms_updater, fraction, device, exp_noise=None, agent_offset=0):
+    """Seed: every agent infected independently with probability ``fraction`` (a8+a9 fused launch).
+    ``agent_offset``: global id of local agent 0 when ``data`` is one rank's part of a partitioned world."""
     device = require_hip(device)
     ag = data["agent"]
     n = ag.id.shape[0]
@@ -88,7 +89,7 @@ def infect_fraction_of_people(data, timer, symptoms_updater, fraction, device, e
     if exp_noise is not None:
         exp_noise = exp_noise.to(device=device, dtype=torch.float32).contiguous()
     _launch_sample(probs, exp_noise, new_inf, now=timer.now,
-                   state=(ag.susceptibility, ag.is_infected, ag.infection_time))
+                   state=(ag.susceptibility, ag.is_infected, ag.infection_time), agent_offset=agent_offset)
     return new_inf
 
 

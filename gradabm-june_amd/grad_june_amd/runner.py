@@ -138,7 +138,8 @@ class Runner(torch.nn.Module):
     def set_initial_cases(self):
         new_infected = infect_fraction_of_people(
             data=self.data, timer=self.timer, symptoms_updater=self.model.symptoms_updater,
-            device=self.device, fraction=10.0 ** self.log_fraction_initial_cases)
+            device=self.device, fraction=10.0 ** self.log_fraction_initial_cases,
+            agent_offset=getattr(self, "agent_offset", 0))
         self.model.symptoms_updater(data=self.data, timer=self.timer, new_infected=new_infected)
 
     # per-step result reductions: one fused pass (gj_step_stats) into a preallocated series ------------
@@ -207,6 +208,7 @@ class Runner(torch.nn.Module):
             row += 1
             record(row)
             dates.append(timer.date)
+        self._finalize_series(row + 1)
         series = self._series[: row + 1].to(torch.float32)
         if differentiable:
             series = torch.stack(diff_rows).to(torch.float32)
@@ -227,6 +229,9 @@ class Runner(torch.nn.Module):
             out[data["agent"].original_index.to(out.device)] = is_infected
             is_infected = out
         return results, is_infected
+
+    def _finalize_series(self, n_rows: int) -> None:
+        """Hook: a partitioned run sums the ranks' per-step reductions here (distributed_api.DistributedRunner)."""
 
     def save_results(self, results, is_infected):
         import pandas as pd

@@ -146,7 +146,8 @@ class SymptomsUpdater(torch.nn.Module):
         if getattr(self, "rng_seed", None) is None:
             self.rng_seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
         self.n_calls = getattr(self, "n_calls", 0) + 1
-        p.seed, p.step, p.agent_offset = self.rng_seed, self.n_calls, 0
+        # agent_offset: global id of local agent 0 (a rank of a partitioned run sets it; the Philox key is the global id)
+        p.seed, p.step, p.agent_offset = self.rng_seed, self.n_calls, int(getattr(self, "agent_offset", 0))
         if (progresses is None) != (dwell is None):
             raise ValueError("inject both progresses and dwell, or neither")
         if progresses is not None:

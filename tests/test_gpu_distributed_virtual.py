@@ -176,3 +176,68 @@ def test_pack_unpack_kernels(device):
     ref[idx.long()] = out
     assert torch.equal(dst, ref)
     assert lib.gj_pack_f32(0, None, None, None, None) == 0 and lib.gj_pack_f32(5, None, None, None, None) == -1
+
+
+def _api_worker(rank, R, port, out):
+    """The API-level run of one rank: DistributedRunner on the reference's 769-agent world, default.yaml."""
+    import itertools
+    import os
+
+    import torch.distributed as dist
+
+    import grad_june_amd as G
+    from grad_june_amd import infection
+    from grad_june_amd.defaults import default_parameters
+    from grad_june_amd.distributed_api import DistributedRunner
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=R)
+    try:
+        def params():
+            p = default_parameters("cuda:0")
+            p["timer"]["total_days"] = 10
+            p["infection_seed"]["log_fraction_initial_cases"] = -1.5
+            for n in p["networks"]:
+                p["networks"][n]["log_beta"] += 0.5
+            p["policies"]["quarantine"] = {
+                "quarantine": {1: {"start_date": "2022-02-03", "end_date": "2022-02-20", "stage_threshold": 4}}}
+            return p
+
+        torch.manual_seed(21)
+        runner = DistributedRunner.from_parameters(params())
+        assert runner.n_agents_total == 769 and 0 < runner.n_agents < 769
+        with torch.no_grad():
+            results, local_inf = runner()
+        a0, a1 = runner.model.agent_range
+        assert local_inf.shape[0] == a1 - a0
+        parts = [torch.empty(int(runner.model._hp.rw.bounds[r + 1] - runner.model._hp.rw.bounds[r])) for r in range(R)]
+        sizes = {p_.numel() for p_ in parts}
+        gathered = [None] * R
+        dist.all_gather_object(gathered, local_inf.cpu())
+        if rank == 0:
+            torch.manual_seed(21)
+            infection._philox_step = itertools.count(1 << 40)        # the seeding stream of a fresh process
+            single = G.Runner.from_parameters(params())
+            with torch.no_grad():
+                ref, ref_inf = single()
+            for key in ("cases_per_timestep", "deaths_per_timestep", "cases_by_age_18", "cases_by_age_65", "cases_by_age_100"):
+                assert torch.equal(results[key].cpu(), ref[key].cpu()), key
+            assert torch.equal(torch.cat(gathered), ref_inf.cpu())
+            assert ref["cases_per_timestep"][-1] > ref["cases_per_timestep"][0] > 0
+            out[0] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_api_runner_two_processes_match_single_gpu(device):
+    """DistributedRunner (model / runner API across ranks; two processes sharing the GPU, gloo) reproduces the
+    single-GPU Runner's series and final per-agent state for the same seed: timer, policies incl. a quarantine
+    window, 11 networks, symptoms, seeding - everything the reference's run() does."""
+    import os
+
+    import torch.multiprocessing as mp
+
+    R = 2
+    out = mp.get_context("spawn").Array("i", [0])
+    mp.spawn(_api_worker, args=(R, 29900 + os.getpid() % 90, out), nprocs=R, join=True)
+    assert out[0] == 1
