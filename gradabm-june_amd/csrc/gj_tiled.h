@@ -129,27 +129,6 @@ __device__ __forceinline__ void batch_slots(const TSetA& T, const int word, int 
                                             int lane, int (&slot)[U]) {
   constexpr int W = WIDE ? 8 : 4;
   const int k_l = lane % W;
-#ifdef GJ_DESC_UNIFORM_LOADS   // experiment: every lane loads the (wave-uniform) descriptors itself
-  if (!WIDE) {
-    int4 d[U];
-    int multi = 0;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      d[u] = T.chunk_desc[T.chunk_ptr[row / T.J] + min(c0 + u, (T.chunk_ptr[row / T.J + 1] - T.chunk_ptr[row / T.J]) - 1)];
-      multi |= d[u].z;
-    }
-    if (__builtin_amdgcn_readfirstlane(multi >> 16) == 0) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) slot[u] = chunk_slot_fast(d[u], lane);
-    } else {
-      for (int u = 0; u < U; ++u) {
-        const int i = min(seg0 + (c0 + u) * kWave + lane, seg1 - 1);
-        slot[u] = (d[u].z >> 16) ? chunk_slot_slow(T, d[u], row, i, lane) : chunk_slot_fast(d[u], lane);
-      }
-    }
-    return;
-  }
-#endif
   const bool flag = WIDE ? (k_l == 7 && (word & 0x100)) : (k_l == 2 && (word >> 16));
   const bool any_multi = __builtin_amdgcn_ballot_w64(flag) != 0ull;
 #define GJ_DW(u, k) __builtin_amdgcn_readlane(word, (u) * W + (k))
