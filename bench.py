@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--sv-max", type=int, default=None)
     ap.add_argument("--eb-target", type=int, default=None)
     ap.add_argument("--slice-agents", type=int, default=None, help="tiled: agents per slice (multiple of 64)")
+    ap.add_argument("--device-compile", action="store_true",
+                    help="compile the contact graph on the GPU (torch ops) instead of numpy on the host")
     ap.add_argument("--tune", default="auto", choices=["auto", "on", "off"],
                     help="measure candidate tile geometries at set-up and keep the fastest "
                          "(auto: single-GPU worlds of at most 4e7 set-edges, where compiling takes seconds)")
@@ -240,6 +242,8 @@ def main():
         from grad_june_amd.benchrun import SingleGpuHotPath
 
         kw = {}
+        if args.device_compile and args.layout == "tiled":
+            kw["device_compile"] = True
         if args.layout == "tiled":
             if args.sv_max:
                 kw["sv_max"] = args.sv_max
@@ -257,7 +261,7 @@ def main():
             extra = {"partitions_on_one_gpu": parts}
         else:
             set_edges = sum(len(v["agent"]) for v in world["edge_sets"].values())
-            tune = args.tune == "on" or (args.tune == "auto" and args.layout == "tiled" and not kw
+            tune = args.tune == "on" or (args.tune == "auto" and args.layout == "tiled" and not (set(kw) - {"device_compile"})
                                          and set_edges <= 40_000_000)
             if tune:      # small worlds compile in seconds: measure the candidate tile geometries, keep the best
                 from grad_june_amd.benchrun import tune_geometry

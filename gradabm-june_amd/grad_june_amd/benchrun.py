@@ -49,9 +49,11 @@ class SingleGpuHotPath:
 
     def __init__(self, world: dict, specs: Sequence[NetworkSpec], betas: Dict[str, float], device,
                  seed: int = 0, quarantine_threshold=None, exp_noise=None, layout: str = "tiled", progress=None,
-                 split_epilogue: bool = False, **plan_kw):
+                 split_epilogue: bool = False, device_compile: bool = False, **plan_kw):
         self.device = torch.device(device)
         self.layout = layout
+        if device_compile:           # build the tiled arrays on the GPU (tiling_device), not with numpy on the host
+            plan_kw["device"] = self.device
         host = compile_plan(world["n_agents"], world["edge_sets"], age=world["age"], sex=world["sex"],
                             layout=layout, progress=progress, **plan_kw)
         self.engine = InfectionEngine(DevicePlan(host, specs, self.device, split_epilogue=split_epilogue))

@@ -88,6 +88,32 @@ def compile_edge_set(name: str, agent_index, venue_index, people, n_agents: int,
     return HostEdgeSet(name, n_venues, E, v_rowptr, v_agent, p_contact(people), a_rowptr, a_venue)
 
 
+def _host(a) -> np.ndarray:
+    """numpy view of an array that may be a torch tensor (possibly on a device)."""
+    if hasattr(a, "detach"):
+        return a.detach().cpu().numpy()
+    return np.asarray(a)
+
+
+def _edge_set_on_device(name: str, es: dict, n_ext: int, device) -> HostEdgeSet:
+    """compile_edge_set(csr=False) with the range checks done where the edge lists live."""
+    import torch
+
+    people = _host(es["people"])
+    n_venues = int(len(people))
+    t = lambda a: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))).to(device)
+    agent, venue = t(es["agent"]).reshape(-1), t(es["venue"]).reshape(-1)
+    E = int(agent.numel())
+    if E >= 2**31 or n_ext >= 2**31 or n_venues >= 2**31:
+        raise ValueError("edge set exceeds int32 indexing")
+    if E:
+        if int(agent.min()) < 0 or int(agent.max()) >= n_ext:
+            raise ValueError(f"{name}: agent index out of range")
+        if int(venue.min()) < 0 or int(venue.max()) >= n_venues:
+            raise ValueError(f"{name}: venue index out of range")
+    return HostEdgeSet(name, n_venues, E, None, None, p_contact(people), None, None)
+
+
 def _lanes_for(mean_degree: float) -> int:
     if mean_degree <= 6:
         return 1
@@ -184,7 +210,8 @@ def save_plan(plan: HostPlan, path) -> None:
             t = s.tiled
             for k in ("blk_v0", "blk_e0", "e_lv", "e_cls", "a_la", "tile_sptr", "tile_jpos", "chunk_ptr", "chunk_desc"):
                 if getattr(t, k) is not None:
-                    out[p + "tiled/" + k] = getattr(t, k)
+                    a = _host(getattr(t, k))
+                    out[p + "tiled/" + k] = a.view(np.uint16) if (k in ("e_lv", "a_la") and a.dtype == np.int16) else a
             out[p + "tiled/meta"] = np.array([t.n_slices, t.n_blocks, t.n_slots, int(t.desc_wide)], dtype=np.int64)
     np.savez(path, **out)
 
@@ -227,13 +254,15 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
                  layout: str = "csr", leisure_sets: Sequence[str] = ("leisure",),
                  sv_max: int = TL.SV_MAX, eb_target: Optional[int] = None, slices=None,
                  nets_per_set: Optional[Dict[str, int]] = None, progress=None,
-                 desc_wide: Optional[bool] = None) -> HostPlan:
+                 desc_wide: Optional[bool] = None, device=None) -> HostPlan:
     """edge_sets: {name: {"agent": i64[E], "venue": i64[E], "people": [V]}} (insertion order = set ids).
 
     layout: "csr" (deterministic CSR kernels), "tiled" (LDS-tiled fast path) or "both".
     nets_per_set: infection networks that may be active on a set at once (a venue block keeps one
     8-byte LDS sum per venue and network; default 1, and 6 for the leisure sets).
     desc_wide: chunk descriptor format of the tiled layout (None: per set, from its tile sizes).
+    device: build the tiled arrays with torch ops on this device (tiling_device.build_tiled_device: the
+    same arrays, born in HBM); the edge lists may then be torch tensors.  Default: numpy on the host.
     """
     if len(edge_sets) > N.GJ_MAX_SETS:
         raise ValueError(f"at most {N.GJ_MAX_SETS} edge sets")
@@ -250,16 +279,32 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
     sets, all_blocks, all_long, work = [], [], [], []
     slot = 0
     for sid, (name, es) in enumerate(edge_sets.items()):
-        hs = compile_edge_set(name, es["agent"], es["venue"], es["people"], n_agents, n_ext, csr=want_csr)
+        if device is not None and not want_csr:
+            hs = _edge_set_on_device(name, es, n_ext, device)
+        else:
+            hs = compile_edge_set(name, _host(es["agent"]), _host(es["venue"]), _host(es["people"]), n_agents, n_ext,
+                                  csr=want_csr)
         sets.append(hs)
         if want_tiled:
             k = (nets_per_set or {}).get(name, 6 if name in leisure_sets else 1)
-            hs.tiled = TL.build_tiled(name, es["agent"], es["venue"], hs.n_venues, hs.v_pcontact, S, SA,
-                                      agent_class=cls_all if (name in leisure_sets and cls_all is not None) else None,
-                                      sv_max=max(16, sv_max // max(1, k)), eb_target=eb_target, wide=desc_wide)
+            use_cls = cls_all if (name in leisure_sets and cls_all is not None) else None
+            if device is not None:
+                import torch
+
+                from .tiling_device import build_tiled_device
+
+                dev_t = lambda a: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))).to(device)
+                hs.tiled = build_tiled_device(name, dev_t(es["agent"]), dev_t(es["venue"]), hs.n_venues, hs.v_pcontact,
+                                              S, SA, agent_class=None if use_cls is None else dev_t(use_cls),
+                                              sv_max=max(16, sv_max // max(1, k)), eb_target=eb_target, wide=desc_wide)
+            else:
+                hs.tiled = TL.build_tiled(name, es["agent"], es["venue"], hs.n_venues, hs.v_pcontact, S, SA,
+                                          agent_class=use_cls, sv_max=max(16, sv_max // max(1, k)),
+                                          eb_target=eb_target, wide=desc_wide)
             t = hs.tiled
+            blk_e0, blk_v0 = _host(t.blk_e0).astype(np.int64), _host(t.blk_v0).astype(np.int64)
             for j in range(t.n_blocks):
-                work.append((int(t.blk_e0[j + 1] - t.blk_e0[j]) + int(t.blk_v0[j + 1] - t.blk_v0[j]), sid, j))
+                work.append((int(blk_e0[j + 1] - blk_e0[j]) + int(blk_v0[j + 1] - blk_v0[j]), sid, j))
         if progress:
             progress(f"compiled edge set {name}")
         if not want_csr:
@@ -303,10 +348,10 @@ class DevicePlan:
         dev = self.device
 
         def up(a, dtype=None):
-            t = torch.from_numpy(np.ascontiguousarray(a))
+            t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
             if dtype is not None:
                 t = t.to(dtype)
-            return t.to(dev)
+            return t.to(dev).contiguous()
 
         # leisure tables: one [2][200] row block per network that has one
         self.table_index: Dict[str, int] = {}
@@ -364,7 +409,7 @@ class DevicePlan:
                 if self.tiled_c is None:
                     self.tiled_c = N.Tiled()
                     self.tiled_c.n_slices, self.tiled_c.slice_agents = host.n_slices, host.slice_agents
-                u16 = lambda a: up(a.view(np.int16))
+                u16 = lambda a: up(a if isinstance(a, torch.Tensor) else a.view(np.int16))   # uint16 bit patterns
                 t.update(blk_v0=up(ts.blk_v0), blk_e0=up(ts.blk_e0), e_lv=u16(ts.e_lv), a_la=u16(ts.a_la),
                          tile_sptr=up(ts.tile_sptr), tile_jpos=up(ts.tile_jpos),
                          chunk_ptr=up(ts.chunk_ptr), chunk_desc=up(ts.chunk_desc.reshape(-1)) if len(ts.chunk_desc) else None,
@@ -373,7 +418,7 @@ class DevicePlan:
                     t["e_cls"] = up(ts.e_cls)
                 c = self.tiled_c.sets[i]
                 c.n_blocks = ts.n_blocks
-                c.max_block_venues = int(np.diff(ts.blk_v0).max()) if ts.n_blocks else 0
+                c.max_block_venues = int(np.diff(_host(ts.blk_v0)).max()) if ts.n_blocks else 0
                 c.desc_wide = 1 if ts.desc_wide else 0
                 c.blk_v0, c.blk_e0 = t["blk_v0"].data_ptr(), t["blk_e0"].data_ptr()
                 c.e_lv, c.a_la = t["e_lv"].data_ptr(), t["a_la"].data_ptr()

@@ -188,3 +188,32 @@ def test_step_is_capturable_in_a_hip_graph(device):
         for k in keys:
             assert torch.equal(r.state[k], eager[k]), k
         assert torch.equal(r.new_infected, eager_new)
+
+
+def test_device_compiled_plan_is_identical(device):
+    """The contact graph compiled on the GPU (tiling_device, row f4) equals the numpy-compiled one array for
+    array, and a step on it gives bitwise the same state."""
+    from grad_june_amd.plan import _host, compile_plan
+
+    world = make_world("c3", n_agents=500_000, seed=11, infected_fraction=0.05)
+    specs, betas = B.network_specs(world), B.betas_of(world)
+    host = compile_plan(world["n_agents"], world["edge_sets"], age=world["age"], sex=world["sex"], layout="tiled")
+    dev = compile_plan(world["n_agents"], world["edge_sets"], age=world["age"], sex=world["sex"], layout="tiled",
+                       device=device)
+    assert np.array_equal(dev.work, host.work)
+    for a, b in zip(dev.sets, host.sets):
+        assert a.tiled.e_lv.device.type == "cuda"
+        for k in ("blk_v0", "blk_e0", "e_cls", "tile_sptr", "tile_jpos", "chunk_ptr", "chunk_desc"):
+            x, y = getattr(a.tiled, k), getattr(b.tiled, k)
+            assert (x is None) == (y is None) and (x is None or np.array_equal(_host(x), y)), (a.name, k)
+        for k in ("e_lv", "a_la"):
+            assert np.array_equal(_host(getattr(a.tiled, k)).view(np.uint16), getattr(b.tiled, k)), (a.name, k)
+    r0 = SingleGpuHotPath(world, specs, betas, device, seed=2, layout="tiled")
+    r1 = SingleGpuHotPath(world, specs, betas, device, seed=2, layout="tiled", device_compile=True)
+    for _ in range(2):
+        r0.step()
+        r1.step()
+    torch.cuda.synchronize()
+    for k in ("is_infected", "susceptibility", "infection_time"):
+        assert torch.equal(r0.state[k], r1.state[k]), k
+    assert torch.equal(r0.probs, r1.probs)
