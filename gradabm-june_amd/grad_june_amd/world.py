@@ -22,6 +22,9 @@ _CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 
 #: device layout the API mirrors compile worlds into: "tiled" (LDS-tiled fast path, default) or "csr"
 DEFAULT_LAYOUT = os.environ.get("GRAD_JUNE_AMD_LAYOUT", "tiled")
+#: compile the contact graph on the GPU (tiling_device) instead of numpy on the host: worlds of 10^7+ agents
+#: then compile in about a second.  Opt-in (GRAD_JUNE_AMD_DEVICE_COMPILE=1 or set this flag); same arrays.
+DEVICE_COMPILE = os.environ.get("GRAD_JUNE_AMD_DEVICE_COMPILE", "0") == "1"
 
 
 def _np(x) -> np.ndarray:
@@ -92,8 +95,12 @@ def engine_for(data, specs: Sequence[NetworkSpec], device) -> InfectionEngine:
     sex = _np(agent["sex"]) if "sex" in agent else None
     if age is None and any(n.table is not None for n in specs):
         raise KeyError("leisure networks need data['agent'].age and .sex")
-    host = compile_plan(n_agents, {k: {kk: vv for kk, vv in v.items() if kk != "_ei"} for k, v in sets.items()},
-                        age=age, sex=sex, layout=DEFAULT_LAYOUT)
+    if DEVICE_COMPILE and DEFAULT_LAYOUT == "tiled":
+        on_dev = {k: {"agent": v["_ei"][0], "venue": v["_ei"][1], "people": v["people"]} for k, v in sets.items()}
+        host = compile_plan(n_agents, on_dev, age=age, sex=sex, layout="tiled", device=device)
+    else:
+        host = compile_plan(n_agents, {k: {kk: vv for kk, vv in v.items() if kk != "_ei"} for k, v in sets.items()},
+                            age=age, sex=sex, layout=DEFAULT_LAYOUT)
     present = [n for n in specs if n.edge_set in host.set_index]
     engine = InfectionEngine(DevicePlan(host, present, device))
     if len(per_data) >= 4:          # worlds whose edges are rebuilt repeatedly: keep the cache small

@@ -461,3 +461,28 @@ def test_locality_order_gives_the_same_probabilities(G, device):
         _, is_infected = local()
     assert is_infected.shape[0] == n
     assert torch.equal(is_infected[original], local.data["agent"].is_infected)
+
+
+def test_api_with_device_side_compile(G, device):
+    """world.DEVICE_COMPILE: the Runner's plan compiled on the GPU gives the same run as the host-compiled one."""
+    from grad_june_amd import world as W
+
+    def run():
+        import itertools
+
+        from grad_june_amd import infection
+
+        torch.manual_seed(9)
+        infection._philox_step = itertools.count(1 << 40)
+        runner = G.Runner.from_parameters(params_on(device, days=6))
+        with torch.no_grad():
+            res, inf = runner()
+        return res["cases_per_timestep"].cpu(), inf.cpu()
+
+    ref = run()
+    W.DEVICE_COMPILE = True
+    try:
+        got = run()
+    finally:
+        W.DEVICE_COMPILE = False
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and ref[0][-1] > 0
