@@ -47,24 +47,20 @@ class IsInfectedSampler(torch.nn.Module):
         _launch_sample(p, exp_noise, out)
         return out
 
-
-def _straight_through(self, p, exp_noise):
-    """Stand-alone call in grad mode: the kernel takes the hard decision, the soft sample that carries the
-    gradient (F.gumbel_softmax(..., tau=0.1, hard=True), infection.py:13-18) is formed with device tensor ops
-    from the same noise.  (Inside GradJune.forward the whole step is one autograd node instead.)"""
-    n = p.numel()
-    if exp_noise is None:
-        exp_noise = torch.empty(2, n, dtype=torch.float32, device=p.device).exponential_()
-    exp_noise = exp_noise.to(device=p.device, dtype=torch.float32).contiguous().view(2, n)
-    hard = torch.empty(n, dtype=torch.float32, device=p.device)
-    _launch_sample(p.detach().to(torch.float32).contiguous(), exp_noise, hard)
-    logits = torch.vstack((p, 1.0 - p)).log()
-    y_soft = torch.softmax((logits - exp_noise.log()) / 0.1, dim=0)
-    ret0 = (1.0 - hard) - y_soft[0].detach() + y_soft[0]
-    return 1.0 - ret0
-
-
-IsInfectedSampler._forward_straight_through = _straight_through
+    def _forward_straight_through(self, p, exp_noise):
+        """Stand-alone call in grad mode: the kernel takes the hard decision, the soft sample that carries the
+        gradient (F.gumbel_softmax(..., tau=0.1, hard=True), infection.py:13-18) is formed with device tensor ops
+        from the same noise.  (Inside GradJune.forward the whole step is one autograd node instead.)"""
+        n = p.numel()
+        if exp_noise is None:
+            exp_noise = torch.empty(2, n, dtype=torch.float32, device=p.device).exponential_()
+        exp_noise = exp_noise.to(device=p.device, dtype=torch.float32).contiguous().view(2, n)
+        hard = torch.empty(n, dtype=torch.float32, device=p.device)
+        _launch_sample(p.detach().to(torch.float32).contiguous(), exp_noise, hard)
+        logits = torch.vstack((p, 1.0 - p)).log()
+        y_soft = torch.softmax((logits - exp_noise.log()) / 0.1, dim=0)
+        ret0 = (1.0 - hard) - y_soft[0].detach() + y_soft[0]
+        return 1.0 - ret0
 
 
 def infect_people(data, timer, new_infected):
