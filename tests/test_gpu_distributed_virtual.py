@@ -241,3 +241,78 @@ def test_api_runner_two_processes_match_single_gpu(device):
     out = mp.get_context("spawn").Array("i", [0])
     mp.spawn(_api_worker, args=(R, 29900 + os.getpid() % 90, out), nprocs=R, join=True)
     assert out[0] == 1
+
+
+def _golden_chain_worker(rank, R, port, out):
+    """One rank of the reference's recorded 15-step trajectory (june769.npz), everything carried forward."""
+    import json
+    import os
+
+    import torch.distributed as dist
+
+    import gj_testlib as L
+    import grad_june_amd as G
+    from grad_june_amd.distributed_api import DistributedGradJune
+    from test_host_logic import _cpu
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=R)
+    try:
+        device = torch.device("cuda:0")
+        npz = L.load_npz("june769.npz")
+        world = L.world_from(npz)
+        params = _cpu(json.loads(str(npz["params_json"])))
+        params["system"]["device"] = str(device)
+        model = DistributedGradJune.from_parameters(params)
+        timer = G.Timer.from_parameters(params)
+        rec0 = L.step_record(npz, "step0/")
+        d = G.HeteroData()
+        ag = d["agent"]
+        A = world["n_agents"]
+        ag.id = torch.arange(A)
+        ag.age, ag.sex = world["age"], world["sex"]
+        for s, es in world["edge_sets"].items():
+            d[s].id = torch.arange(len(es["people"]))
+            d[s].people = es["people"]
+            d["agent", "attends_" + s, s].edge_index = torch.vstack((es["agent"], es["venue"]))
+        d = d.to(device)
+        pre = L.pre_state(rec0)
+        ag.infection_parameters = {k: pre[k].to(device) for k in ("max_infectiousness", "shape", "rate", "shift")}
+        for k in ("is_infected", "susceptibility", "infection_time"):
+            ag[k] = pre[k].to(device)
+        ag.transmission = torch.zeros(A, device=device)
+        ag.symptoms = {k[8:]: torch.from_numpy(v).to(device) for k, v in rec0.items() if k.startswith("sym_pre/")}
+        ag.symptoms["current_stage"] = torch.from_numpy(rec0["pre/current_stage"]).float().to(device)
+        local = model.partition(d)
+        a0, a1 = model.agent_range
+        with torch.no_grad():
+            for i in range(int(npz["n_steps"])):
+                rec = L.step_record(npz, f"step{i}/")
+                next(timer)
+                new, _ = model.hot_path(local, timer, exp_noise=torch.from_numpy(rec["exp_noise"]))
+                for k in ("susceptibility", "is_infected", "infection_time"):
+                    assert np.array_equal(local["agent"][k].cpu().numpy(), rec["post/" + k][a0:a1]), (i, k)
+                model.symptoms_updater(local, timer, new, progresses=torch.from_numpy(rec["sym/progresses"][a0:a1]),
+                                       dwell=torch.from_numpy(rec["sym/dwell"][a0:a1]))
+                for k in ("current_stage", "next_stage", "time_to_next_stage"):
+                    assert np.array_equal(local["agent"].symptoms[k].cpu().numpy(), rec["sym_post/" + k][a0:a1]), (i, k)
+        total = torch.tensor([float(local["agent"].is_infected.sum())])
+        dist.all_reduce(total)
+        assert float(total) == float(npz["cases_per_timestep"][-1])
+        out[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_reproduce_the_reference_trajectory(device):
+    """The multi-rank path against the REFERENCE itself: the recorded 15-step run of the 769-agent world (11
+    networks, policies, symptoms; reference noise injected) is reproduced exactly by two ranks - every state
+    array of every agent after every step, and the final case count."""
+    import os
+
+    import torch.multiprocessing as mp
+
+    R = 2
+    out = mp.get_context("spawn").Array("i", [0] * R)
+    mp.spawn(_golden_chain_worker, args=(R, 29700 + os.getpid() % 90, out), nprocs=R, join=True)
+    assert list(out) == [1] * R
