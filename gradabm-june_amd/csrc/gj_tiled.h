@@ -24,7 +24,11 @@ constexpr int kUnrollNarrow = GJ_UNROLL_NARROW;   // phase A with 16-byte descri
 #ifndef GJ_VENUE_UNROLL
 #define GJ_VENUE_UNROLL 2
 #endif
-constexpr int kVenueUnroll = GJ_VENUE_UNROLL;  // 8-slot groups a lane keeps in flight (phases B and C)
+constexpr int kVenueUnroll = GJ_VENUE_UNROLL;  // 8-slot groups a lane keeps in flight (phase B)
+#ifndef GJ_VENUE_UNROLL_C
+#define GJ_VENUE_UNROLL_C GJ_VENUE_UNROLL
+#endif
+constexpr int kVenueUnrollC = GJ_VENUE_UNROLL_C;  // same, phase C
 
 // LDS float atomics run at 0.33 lanes/clk/CU on gfx950 (measured, tools/microbench/lds_atomics.hip)
 // against 4.9 for ds_add_u64 and 7.3 for ds_add_u32, so the per-venue and per-agent sums are kept
@@ -426,17 +430,17 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
   }
   __syncthreads();
   // C: per slot, the venue's cum (leisure: weighted over the set's networks by the agent's class)
-  for (int g = g0 + tid; g < g1; g += kVenueUnroll * kTileThreads) {
-    uint4 raw[kVenueUnroll];
-    uint2 craw[kVenueUnroll];
+  for (int g = g0 + tid; g < g1; g += kVenueUnrollC * kTileThreads) {
+    uint4 raw[kVenueUnrollC];
+    uint2 craw[kVenueUnrollC];
 #pragma unroll
-    for (int u = 0; u < kVenueUnroll; ++u) {
+    for (int u = 0; u < kVenueUnrollC; ++u) {
       const int gu = min(g + u * kTileThreads, g1 - 1);
       raw[u] = lv8[gu];
       craw[u] = T.leisure ? cls8[gu] : make_uint2(0u, 0u);
     }
 #pragma unroll
-    for (int u = 0; u < kVenueUnroll; ++u) {
+    for (int u = 0; u < kVenueUnrollC; ++u) {
       const int gu = g + u * kTileThreads;
       if (gu >= g1) continue;
       const Slots8 L{{raw[u].x, raw[u].y, raw[u].z, raw[u].w}};
