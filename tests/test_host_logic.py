@@ -143,3 +143,27 @@ def test_no_cpu_path():
     t = Timer(weekday_activities=(("school",),), weekend_activities=(("school",),), weekday_step_duration=(24,))
     with pytest.raises(RuntimeError, match="HIP device only"):
         nets(data=data, timer=t, policies=Policies())
+
+
+def test_roofline_accounting_matches_survey_8d():
+    """bench.py's algorithmic bytes: B_step = 8*sum_sets E_s + 8*sum_n E_n + 12*sum_n V_n + (8N + 64)*A (SURVEY 8d);
+    C3's sizes give the 3.05 GB quoted there, and the per-launch shares add up to it."""
+    import bench as B
+    from grad_june_amd.synthetic import NETWORKS, algorithmic_bytes, network_edges
+
+    A = 10_000_000
+    sizes = {"n_agents": A, "edge_sets": {
+        "household": {"n_edges": 15_000_000, "n_venues": 6_000_000}, "care_home": {"n_edges": 15_000_000, "n_venues": 300_000},
+        "company": {"n_edges": 15_000_000, "n_venues": 750_000}, "school": {"n_edges": 15_000_000, "n_venues": 30_000},
+        "university": {"n_edges": 15_000_000, "n_venues": 7_500}, "leisure": {"n_edges": 15_000_000, "n_venues": 3_000}}}
+    nets = NETWORKS["c3"]
+    assert network_edges(sizes, nets) == 120_000_000
+    b = algorithmic_bytes(sizes, nets)
+    want = 8 * 90_000_000 + 8 * 120_000_000 + 12 * (6_000_000 + 300_000 + 750_000 + 30_000 + 7_500 + 3 * 3_000) + (8 * 8 + 64) * A
+    assert b == want and abs(b - 3.05e9) < 0.02e9
+    world = {"n_agents": A, "edge_sets": {k: {"agent": range(v["n_edges"]), "people": range(v["n_venues"])}
+                                          for k, v in sizes["edge_sets"].items()}}
+    kb = B.kernel_bytes(world, nets)
+    assert kb["transmission"] + kb["tile_scatter"] + kb["tile_venues"] + kb["tile_agents"] == b
+    assert kb["tile_venues_B"] + kb["tile_venues_C"] == kb["tile_venues"]
+    assert kb["transmission"] + kb["venue_reduce"] + kb["agent_gather"] == b
