@@ -57,10 +57,16 @@ def parse():
     ap.add_argument("--quarantine", type=float, default=None,
                     help="second configuration of SURVEY 8d: an active quarantine policy with this stage threshold")
     ap.add_argument("--edge-mult", type=float, default=1.0, help="experiments: memberships per agent x this")
+    ap.add_argument("--direct", default="auto", choices=["auto", "off"],
+                    help="pass 2 of sets with few venues straight from an LDS table of venue values (auto) or, like the "
+                         "other sets, through the per-edge workspace (off)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: diagnostic runs with several ranks sharing one GPU (collectives staged through the host)")
     ap.add_argument("--force-distributed", action="store_true",
                     help="diagnostic: take the torch.distributed code path even with one rank")
+    ap.add_argument("--world-cache", default=None,
+                    help="directory in which generated worlds are kept (.npz) and reloaded from: kernel experiments "
+                         "that run bench.py many times on one box skip the ~30 s of generation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
     return ap.parse_args()
@@ -169,6 +175,41 @@ def _es(n):
     return edge_set_of(n)
 
 
+def cached_world(args, progress, make_world):
+    def gen():
+        return make_world(args.preset, n_agents=args.agents, seed=args.seed, infected_fraction=args.infected,
+                          edge_mult=args.edge_mult, progress=progress)
+
+    if not args.world_cache:
+        return gen()
+    os.makedirs(args.world_cache, exist_ok=True)
+    path = os.path.join(args.world_cache, f"{args.preset}_{args.agents}_{args.seed}_{args.infected}_{args.edge_mult}.npz")
+    if not os.path.exists(path):
+        w = gen()
+        flat = {"n_agents": w["n_agents"], "age": w["age"], "sex": w["sex"], "networks": ",".join(w["networks"])}
+        for k, es in w["edge_sets"].items():
+            for kk, v in es.items():
+                flat[f"es/{k}/{kk}"] = v
+        for k, v in w["state"].items():
+            flat[f"state/{k}"] = v
+        np.savez(path + ".tmp.npz", **flat)
+        os.replace(path + ".tmp.npz", path)
+        return w
+    with np.load(path) as z:
+        w = {"preset": args.preset, "n_agents": int(z["n_agents"]), "age": z["age"], "sex": z["sex"],
+             "networks": str(z["networks"]).split(","), "edge_sets": {}, "state": {}}
+        for k in z.files:
+            if k.startswith("es/"):
+                _, name, kk = k.split("/")
+                w["edge_sets"].setdefault(name, {})[kk] = z[k]
+            elif k.startswith("state/"):
+                w["state"][k[6:]] = z[k]
+    order = [s for s in ("household", "care_home", "company", "school", "university", "leisure") if s in w["edge_sets"]]
+    w["edge_sets"] = {s: w["edge_sets"][s] for s in order}
+    progress(f"world loaded from {path}")
+    return w
+
+
 def main():
     args = parse()
     # stdout carries exactly ONE line, the JSON result: libraries that print to fd 1 (RCCL's version banner
@@ -213,8 +254,7 @@ def main():
         if rank == 0:
             print(f"[bench {time.time() - t0:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
-    world = make_world(args.preset, n_agents=args.agents, seed=args.seed, infected_fraction=args.infected,
-                       edge_mult=args.edge_mult, progress=progress)
+    world = cached_world(args, progress, make_world)
     reorder = args.reorder if args.reorder != "auto" else ("household" if world_size > 1 else "none")
     if reorder != "none":
         from grad_june_amd.synthetic import reorder_agents
@@ -245,6 +285,8 @@ def main():
         if args.device_compile and args.layout == "tiled":
             kw["device_compile"] = True
         if args.layout == "tiled":
+            if args.direct == "off":
+                kw["direct"] = False
             if args.sv_max:
                 kw["sv_max"] = args.sv_max
             if args.eb_target:
@@ -261,13 +303,13 @@ def main():
             extra = {"partitions_on_one_gpu": parts}
         else:
             set_edges = sum(len(v["agent"]) for v in world["edge_sets"].values())
-            tune = args.tune == "on" or (args.tune == "auto" and args.layout == "tiled" and not (set(kw) - {"device_compile"})
+            tune = args.tune == "on" or (args.tune == "auto" and args.layout == "tiled" and not (set(kw) - {"device_compile", "direct"})
                                          and set_edges <= 40_000_000)
             if tune:      # small worlds compile in seconds: measure the candidate tile geometries, keep the best
                 from grad_june_amd.benchrun import tune_geometry
 
                 runner, seen = tune_geometry(world, specs, betas, dev, seed=args.seed, layout=args.layout,
-                                             quarantine_threshold=args.quarantine, progress=progress)
+                                             quarantine_threshold=args.quarantine, progress=progress, **kw)
                 extra = {"geometry_tuning_ms": seen}
             else:
                 runner = SingleGpuHotPath(world, specs, betas, dev, seed=args.seed, layout=args.layout,
@@ -322,6 +364,15 @@ def main():
         full = {"steps_per_s": n_full / el, "ms_per_step": 1e3 * el / n_full, "steps": n_full,
                 "includes": "hot path a1-a9 + symptoms kernel (f1) + per-step result reductions (f2)"}
 
+    # what the timed steps computed: variants of one kernel must agree on these (tools/ab.py prints them)
+    st_ = runner.state
+    checksum = {"infected": float(st_["is_infected"].double().sum()),
+                "infection_time_sum": float(st_["infection_time"].double().sum())}
+    if getattr(runner, "stamps", None) is not None:      # GJ_DIAG_STAMPS builds: cycles since workgroup start at marked points
+        sa = runner.engine.plan.host.slice_agents
+        st = runner.stamps[: (world["n_agents"] // sa) * sa].view(-1, sa)[:, :16].cpu().numpy()
+        print("stamps (mean cycles per workgroup, slots 0-15):", np.round(st.mean(0)).tolist(), file=sys.stderr)
+        print("stamps (max):", np.round(st.max(0)).tolist(), file=sys.stderr)
     sps = args.steps / elapsed
     n_edges = network_edges(world, networks)
     b_step = algorithmic_bytes(world, networks)
@@ -357,6 +408,7 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": kb[dom] * share, "ms_per_launch": kt[dom]},
         "kernel_ms": kt,
+        "state_checksum": checksum,
         "setup_s": {"generate": t_gen, "total": t_setup},
     }
     out.update(extra)

@@ -22,10 +22,19 @@ __device__ __forceinline__ float group_sum(float v) {
 // ---- Philox4x32-10 (Salmon et al., SC'11), counter = (pair lo, pair hi, step lo, step hi), key = seed.
 // One call yields the two Exponential(1) draws of each agent of a pair (see exp_pair).
 __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#ifndef GJ_PHILOX_MULHI
+  // one 32x32->64 product per word pair (v_mad_u64_u32) instead of a mul_hi + mul_lo pair: half the quarter-rate
+  // integer multiplies, which are what the sampler costs
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+  const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+#else
   const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]);
   const uint32_t lo0 = 0xD2511F53u * c[0];
   const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]);
   const uint32_t lo1 = 0xCD9E8D57u * c[2];
+#endif
   const uint32_t n0 = hi1 ^ c[1] ^ k0;
   const uint32_t n2 = hi0 ^ c[3] ^ k1;
   c[0] = n0;

@@ -61,6 +61,8 @@ struct TSetA {            // what phases A and D need of one set
   int32_t active;         // networks active on the set in this step (0: skip)
   int32_t raw;            // 1: reads raw transmission / susceptibility weight (household)
   int32_t wide;           // chunk_desc holds two int4 per chunk (up to 6 tiles per chunk), see tiling.py
+  int32_t direct;         // pass 2 of the set is taken by phase D's direct form (TDirect): no val / a_la reads there
+  int32_t _pad;
 };
 
 struct TileAArgs {
@@ -310,7 +312,7 @@ struct TSetB {
   int32_t table[GJ_MAX_NETS_PER_SET];      // leisure table index or -1
   int32_t age75[GJ_MAX_NETS_PER_SET];      // susceptibility additionally * (age > 75)
   int32_t leisure;
-  int32_t _pad;
+  int32_t direct;                          // pass 2 runs in phase D's direct form: phase C has nothing to do
 };
 
 struct TileBArgs {
@@ -422,8 +424,9 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
         cumf[2 * (k * nv + lv)] = c;      // low half of the lane's own 8-byte slot
       }
     }
-    if (B.mode == 1) return;
+    if (B.mode == 1 || T.direct) return;
   } else {
+    if (T.direct) return;
     for (int k = 0; k < nk; ++k)
       for (int lv = tid; lv < nv; lv += kTileThreads)
         cumf[2 * (k * nv + lv)] = T.cum[(int64_t)(v0 + lv) * T.stride + k];
@@ -470,6 +473,20 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
 }
 
 // ---- phase D: per slice, accumulate the edges' values per agent in LDS; epilogue a7-a9 -----------
+constexpr int GJ_MAX_DIRECT = 6;
+constexpr int kClassWeightFloats = GJ_MAX_NETS_PER_SET * 200;
+constexpr int kMaxSliceAgents = 20480;
+struct TDirect {          // a set whose pass 2 is taken straight from the venues' cum
+  const uint16_t* ell;    // [planes][owned agents, padded to slices][K] venue ids, 0xFFFF = none
+  const float* cum;       // [V * stride]
+  int64_t plane_stride;   // elements of one plane
+  int32_t K, planes;      // K entries per agent and plane (1, or 2: a pair of columns per plane)
+  int32_t V, stride, nk, _pad;
+  int32_t raw, leisure;
+  int32_t table[GJ_MAX_NETS_PER_SET];
+  int32_t age75[GJ_MAX_NETS_PER_SET];
+};
+
 struct TileDArgs {
   TSetA sets[GJ_MAX_SETS];
   int32_t n_sets;
@@ -488,6 +505,15 @@ struct TileDArgs {
   uint64_t seed, step;
   int64_t agent_offset;
   float* acc_scratch;     // non-NULL: write the per-agent sums here and leave a7-a9 to k_tile_epilogue
+  // "direct" form of pass 2 (sets with few venues, tiling.py build_ell): no per-edge workspace
+  TDirect direct[GJ_MAX_DIRECT];
+  int32_t n_direct;
+  int32_t table_floats;   // LDS floats available for one group of venue values
+  int32_t day_type, transpose;
+  const uint8_t* cls;
+  const float* tables;
+  int32_t _pad2;
+  int32_t io_vec4;        // susceptibility and the optional per-agent outputs are 16-byte aligned
 };
 
 // a7-a9 for one agent per lane, from the per-agent sums of phase D (split form)
@@ -520,20 +546,247 @@ __global__ __launch_bounds__(256) void k_tile_epilogue(const TileDArgs D) {
   }
 }
 
+// ---- phase D, direct form (sets with few venues; tiling.py build_ell) --------------------------------------------
+// acc32[i] += sum over agent i's ELL entries of the venue's cum (leisure sets: weighted over the set's networks by the
+// agent's class).  The venues' values pass through LDS in groups of table_floats / nk venues.  No atomics: a lane owns
+// QUADS of consecutive agents, 4 * (tid + m * 1024) + 0..3, so one quad's rows are a single 8K-byte load, its classes
+// one dword and its sums one 16-byte LDS access.  A lane's quads are loaded in batches that fit its registers (K <= 2:
+// all of the slice's at once, BEFORE the table is staged, so that the two latencies overlap and a set with several
+// venue groups reads its rows once).
+constexpr int kQuadsPerLane = kMaxSliceAgents / (4 * kTileThreads);   // 5
+
+struct DirectBatch {            // a lane's five quads of one set and plane
+  uint32_t w[kQuadsPerLane][4]; // quad's ELL rows: agent j, column c = half-word 2 * j + c
+  uint32_t cls[kQuadsPerLane];  // the quad's four classes
+};
+
+__device__ __forceinline__ void direct_load(const TileDArgs& D, const TDirect& T, int64_t base, int n_local, int tid,
+                                            int plane, DirectBatch& b) {
+  const unsigned last_quad = (unsigned)(n_local - 1) >> 2;   // rows are padded to whole slices: any quad of the slice is readable
+  // wave-uniform bases + 32-bit lane offsets
+  const uint16_t* ell = T.ell + plane * T.plane_stride + base * 2;
+  const uint8_t* cls = D.cls + base;
+#pragma unroll
+  for (int u = 0; u < kQuadsPerLane; ++u) {
+    const unsigned q = min((unsigned)(tid + u * kTileThreads), last_quad);     // clamped: unconditional, all in flight
+    const uint4 r = *reinterpret_cast<const uint4*>(ell + 8u * q);
+    b.w[u][0] = r.x;
+    b.w[u][1] = r.y;
+    b.w[u][2] = r.z;
+    b.w[u][3] = r.w;
+    // the quad's four classes: one dword (agent_class is 4-byte aligned and padded to a multiple of 4 agents)
+    b.cls[u] = T.leisure ? *reinterpret_cast<const uint32_t*>(cls + 4u * q) : 0u;
+  }
+}
+
+__device__ __forceinline__ void direct_add(const TileDArgs& D, const TDirect& T, float (&acc)[kQuadsPerLane][4],
+                                           uint32_t qmask, const float* wtab, const float* tab, int v0, int nv,
+                                           int n_local, int tid, const DirectBatch& b) {
+  constexpr int K = 2;
+  const int nk = T.nk;
+#pragma unroll
+  for (int u = 0; u < kQuadsPerLane; ++u) {
+    const int q = tid + u * kTileThreads;
+    if (4 * q >= n_local) continue;
+    // quarantined agents (bit set) take nothing from masked sets
+    const uint32_t quarantined = T.raw ? 0u : (qmask >> (4 * u)) & 0xFu;
+    // branch-free: every entry reads LDS (entry 0 of the table when it is empty, another group's or quarantined),
+    // the quad's eight reads issued back to back; what does not count is zeroed afterwards
+    int idx[4][K];
+    bool ok[4][K];
+    float x[4][K];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int c = 0; c < K; ++c) {
+        const int h = j * K + c;
+        const int lv = (int)((b.w[u][h >> 1] >> (16 * (h & 1))) & 0xFFFF) - v0;
+        ok[j][c] = ((unsigned)lv < (unsigned)nv) && !((quarantined >> j) & 1u);   // not 0xFFFF, this group's
+        idx[j][c] = ok[j][c] ? lv : 0;
+      }
+    }
+    if (!T.leisure) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < K; ++c) x[j][c] = tab[idx[j][c]];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < K; ++c) x[j][c] = 0.0f;
+      for (int k = 0; k < nk; ++k) {            // per entry: sum over the set's networks, in network order
+        float w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = wtab[k * 200 + ((b.cls[u] >> (8 * j)) & 0xFF)];
+        const float* tk = tab + k * nv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int c = 0; c < K; ++c) x[j][c] += w[j] * tk[idx[j][c]];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {       // agents beyond n_local in the last quad add 0
+      float sj = 0.0f;
+#pragma unroll
+      for (int c = 0; c < K; ++c) sj += ok[j][c] ? x[j][c] : 0.0f;
+      acc[u][j] += sj;
+    }
+  }
+}
+
+// The venues [v0, v0 + nv) of a direct set into LDS as tab[k][venue] (and, with the first group of a leisure set,
+// the receiving side's class weights).  Callers bracket this with barriers.
+__device__ __forceinline__ void direct_table(const TileDArgs& D, const TDirect& T, float* wtab, float* tab, int v0,
+                                             int nv, int tid) {
+  const int nk = T.nk;
+  if (T.leisure && v0 == 0) {
+    for (int i = tid; i < nk * 200; i += kTileThreads) {
+      const int k = i / 200, c = i % 200;
+      const float l = D.tables[(int64_t)T.table[k] * GJ_TABLE_SIZE + D.day_type * 200 + c];
+      const float lw = T.age75[k] ? l * (((c % 100) > 75) ? 1.0f : 0.0f) : l;
+      wtab[i] = D.transpose ? l : lw;       // weights of the receiving side (pass 2)
+    }
+  }
+  // batches of independent (clamped, unconditional) loads: a plain copy loop waits out one L2 round trip per element
+  const float* src = T.cum + (int64_t)v0 * T.stride;
+  const int n = nv * T.stride, stride = T.stride;
+  constexpr int kLoads = 16;
+  for (int i0 = tid; i0 < n; i0 += kLoads * kTileThreads) {
+    float x[kLoads];
+#pragma unroll
+    for (int u = 0; u < kLoads; ++u) x[u] = src[min(i0 + u * kTileThreads, n - 1)];
+#pragma unroll
+    for (int u = 0; u < kLoads; ++u) {
+      const int i = i0 + u * kTileThreads;
+      if (i >= n) continue;
+      if (stride == 1) {
+        tab[i] = x[u];
+      } else {                                     // tab is [k][venue]
+        const int v = i / stride, k = i - v * stride;
+        if (k < nk) tab[k * nv + v] = x[u];
+      }
+    }
+  }
+}
+
+// All direct sets of the slice.  Work items are (set, venue group, plane) in order; the rows of item i + 1 are
+// loaded while item i is summed (a memory round trip costs ~4 us when every CU streams: nothing here waits for one
+// that was not issued a whole item earlier), `first` holds the rows of the first item, issued before the caller's
+// own LDS phase.  LDS: the class weights of a leisure set, then the venue table of the current group.
+__device__ __forceinline__ bool direct_next(const TileDArgs& D, int& t, int& v0, int& plane) {
+  const TDirect& T = D.direct[t];
+  if (plane + 1 < T.planes) {
+    ++plane;
+    return true;
+  }
+  plane = 0;
+  const int vpg = max(1, D.table_floats / T.nk);
+  if (v0 + vpg < T.V) {
+    v0 += vpg;
+    return true;
+  }
+  v0 = 0;
+  ++t;
+  return t < D.n_direct;
+}
+
+__device__ __forceinline__ void direct_sets(const TileDArgs& D, float (&acc)[kQuadsPerLane][4], uint32_t qmask,
+                                            float* lds, int64_t base, int n_local, int tid, DirectBatch& cur,
+                                            uint64_t diag_t0 = 0) {
+  float* wtab = lds;
+  float* tab = lds + kClassWeightFloats;
+  int t = 0, v0 = 0, plane = 0;
+  bool more = true;
+  while (more) {
+    const TDirect& T = D.direct[t];
+    const int nv = min(max(1, D.table_floats / T.nk), T.V - v0);
+    if (plane == 0) {                           // a new venue group: stage its values
+      __syncthreads();                          // the LDS is free: the sums are in registers, the previous table is used up
+#ifndef GJ_DIAG_NO_DIRECT_TABLE
+      direct_table(D, T, wtab, tab, v0, nv, tid);
+#endif
+      __syncthreads();
+    }
+#ifdef GJ_DIAG_STAMPS
+    if (threadIdx.x == 0 && D.trans_susc && t < 4)
+      D.trans_susc[(int64_t)blockIdx.x * D.slice_agents + 8 + 2 * t] = (float)(__builtin_amdgcn_s_memtime() - diag_t0);
+#endif
+    int tn = t, vn = v0, pn = plane;
+    more = direct_next(D, tn, vn, pn);
+    DirectBatch nxt;
+    if (more) direct_load(D, D.direct[tn], base, n_local, tid, pn, nxt);     // in flight while this item is summed
+#ifndef GJ_DIAG_NO_DIRECT_ADD
+    direct_add(D, T, acc, qmask, wtab, tab, v0, nv, n_local, tid, cur);
+#else
+    if (cur.w[0][0] == 0x12345678u && cur.cls[0] == 77u) acc[0][0] = 1.0f;     // keep the loads alive
+#endif
+#ifdef GJ_DIAG_STAMPS
+    if (threadIdx.x == 0 && D.trans_susc && t < 4)
+      D.trans_susc[(int64_t)blockIdx.x * D.slice_agents + 9 + 2 * t] = (float)(__builtin_amdgcn_s_memtime() - diag_t0);
+#endif
+    if (more) cur = nxt;
+    t = tn;
+    v0 = vn;
+    plane = pn;
+  }
+}
+
+// four consecutive per-agent values: one 16-byte access when the arrays allow it, else guarded scalars
+__device__ __forceinline__ void load_quad(const float* p, int64_t a0, int n_ok, bool vec, float (&v)[4]) {
+  if (vec && n_ok >= 4) {
+    const float4 x = *reinterpret_cast<const float4*>(p + a0);
+    v[0] = x.x;
+    v[1] = x.y;
+    v[2] = x.z;
+    v[3] = x.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (j < n_ok) ? p[a0 + j] : 0.0f;
+  }
+}
+__device__ __forceinline__ void store_quad(float* p, int64_t a0, int n_ok, bool vec, const float (&v)[4]) {
+  if (vec && n_ok >= 4) {
+    *reinterpret_cast<float4*>(p + a0) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < n_ok) p[a0 + j] = v[j];
+  }
+}
+
+// GJ_DIAG_STAMPS (timing diagnostics, tools/ab.py): lane 0 of every workgroup writes the cycles since its start at
+// marked points into trans_susc[slice base + k] (the epilogue then leaves trans_susc alone)
+#ifdef GJ_DIAG_STAMPS
+#define GJ_STAMP(k)                                                                                         \
+  do {                                                                                                      \
+    if (threadIdx.x == 0 && D.trans_susc)                                                                    \
+      D.trans_susc[(int64_t)blockIdx.x * D.slice_agents + (k)] = (float)(__builtin_amdgcn_s_memtime() - gj_t0); \
+  } while (0)
+#else
+#define GJ_STAMP(k) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D) {
   extern __shared__ __align__(16) fx_t lds_acc[];
+#ifdef GJ_DIAG_STAMPS
+  const uint64_t gj_t0 = __builtin_amdgcn_s_memtime();
+#endif
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid / kWave), lane = tid % kWave;
   const int s = blockIdx.x;
   const int64_t base = (int64_t)s * D.slice_agents;
   const int n_local = (int)min((int64_t)D.slice_agents, D.n_agents - base);
   for (int i = tid; i < n_local; i += kTileThreads) lds_acc[i] = 0;
+  DirectBatch first;                       // rows of the first direct item: their round trip hides behind the tiled sets
+  if (D.n_direct > 0) direct_load(D, D.direct[0], base, n_local, tid, 0, first);
   __syncthreads();
   // ts = susc * (q * sum over masked sets + sum over raw sets): masked sets first, scale by q, raw sets last
   for (int pass = 0; pass < 2; ++pass) {
     for (int t = 0; t < D.n_sets; ++t) {
       const TSetA& T = D.sets[t];
-      if (!T.active || T.raw != pass) continue;
+      if (!T.active || T.direct || T.raw != pass) continue;
       if (T.wide) {
         gather_set<true>(T, lds_acc, s, wave, lane);
       } else {
@@ -547,65 +800,132 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
       __syncthreads();
     }
   }
+  GJ_STAMP(1);
+  // ---- per-agent tail.  Each lane owns QUADS of consecutive agents, 4 * (tid + m * 1024) + 0..3 (m < 5): their sums
+  // leave LDS for registers, so that the whole LDS is free for the direct sets' venue tables, and the epilogue moves
+  // 16 bytes per lane and array.
+  constexpr int kQ = kQuadsPerLane;
+  float acc[kQ][4];
+#pragma unroll
+  for (int m = 0; m < kQ; ++m) {
+    const int i0 = 4 * (tid + m * kTileThreads);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[m][j] = (i0 < n_local) ? from_fx<kFxAgent>(lds_acc[i0 + j]) : 0.0f;
+  }
+  if (D.n_direct > 0) {
+    uint32_t qmask = 0u;                                  // bit 4m + j: the agent is quarantined
+    if (D.has_q) {
+      float stg[kQ][4];
+#pragma unroll
+      for (int m = 0; m < kQ; ++m) {
+        const int i0 = 4 * (tid + m * kTileThreads);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) stg[m][j] = (i0 + j < n_local) ? D.stage[base + i0 + j] : -INFINITY;
+      }
+#pragma unroll
+      for (int m = 0; m < kQ; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) qmask |= (stg[m][j] < D.q_thr) ? 0u : (1u << (4 * m + j));
+    }
+    GJ_STAMP(2);
+#ifndef GJ_DIAG_NO_DIRECT_SETS       // timing diagnostics only (tools/ab.py): what the direct sets cost in phase D
+#ifdef GJ_DIAG_STAMPS
+    direct_sets(D, acc, qmask, reinterpret_cast<float*>(lds_acc), base, n_local, tid, first, gj_t0);
+#else
+    direct_sets(D, acc, qmask, reinterpret_cast<float*>(lds_acc), base, n_local, tid, first);
+#endif
+#endif
+    GJ_STAMP(3);
+  }
+  const bool vec = D.io_vec4 != 0;
   if (D.acc_scratch) {   // split form: hand the per-agent sums to k_tile_epilogue (runs at full occupancy)
-    for (int i = tid; i < n_local; i += kTileThreads) D.acc_scratch[base + i] = from_fx<kFxAgent>(lds_acc[i]);
+#pragma unroll
+    for (int m = 0; m < kQ; ++m) {
+      const int i0 = 4 * (tid + m * kTileThreads);
+      if (i0 < n_local) store_quad(D.acc_scratch, base + i0, n_local - i0, vec, acc[m]);
+    }
     return;
   }
-  // Epilogue: each lane takes adjacent agent pairs (2j, 2j+1), kPairs of them per iteration with their loads
-  // issued together; in Philox mode one block serves both agents of a pair.
-  constexpr int kPairs = 2;
-  const bool pair_aligned = ((D.agent_offset + base) & 1) == 0;   // local pairs are global pairs (else: per agent)
-  for (int j0 = tid; 2 * j0 < n_local; j0 += kPairs * kTileThreads) {
-    float susc_b[2 * kPairs], e0_b[2 * kPairs], e1_b[2 * kPairs];
+  // The sums go back to LDS as fp32, next to the slice's susceptibilities (a lane reads back only what it wrote: no
+  // barrier after the stores): ALL of a lane's susceptibility loads are issued together - one memory round trip, not
+  // one per quad - and the epilogue is a rolled loop with four agents' worth of registers.
+  float4* acc4 = reinterpret_cast<float4*>(lds_acc);
+  float4* susc4 = acc4 + D.slice_agents / 4;
+  {
+    float sq[kQ][4];
 #pragma unroll
-    for (int u = 0; u < kPairs; ++u) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int i = 2 * (j0 + u * kTileThreads) + h;
-        const bool ok = i < n_local;
-        susc_b[2 * u + h] = ok ? D.susceptibility[base + i] : 0.0f;
-        e0_b[2 * u + h] = (ok && D.sample && D.exp_noise) ? D.exp_noise[base + i] : 1.0f;
-        e1_b[2 * u + h] = (ok && D.sample && D.exp_noise) ? D.exp_noise[D.n_agents + base + i] : 1.0f;
-      }
+    for (int m = 0; m < kQ; ++m) {
+      const int i0 = 4 * (tid + m * kTileThreads);
+      if (i0 < n_local) load_quad(D.susceptibility, base + i0, n_local - i0, vec, sq[m]);
     }
+    __syncthreads();          // every lane has its sums in registers, the last venue table has been read by every wave
 #pragma unroll
-    for (int u = 0; u < kPairs; ++u) {
-      const int i_pair = 2 * (j0 + u * kTileThreads);
-      if (i_pair >= n_local) continue;
-      uint32_t r[4] = {0u, 0u, 0u, 0u};
-      const bool block = D.sample && !D.exp_noise && pair_aligned;
-      if (block) philox4x32_10((uint64_t)(D.agent_offset + base + i_pair) >> 1, D.step, D.seed, r);
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int i = i_pair + h;
-        if (i >= n_local) continue;
-        const int64_t a = base + i;
-        float susc = susc_b[2 * u + h];
-        float ts = susc * from_fx<kFxAgent>(lds_acc[i]);
-        if (D.trans_susc) D.trans_susc[a] = ts;
-        ts = fminf(fmaxf(ts, 1e-6f), 100.0f);
-        float p = expf(-ts * D.dt);
-        p = fminf(fmaxf(p, 0.0f), 1.0f);
-        if (D.not_infected_probs) D.not_infected_probs[a] = p;
-        if (!D.sample) continue;
-        float e0 = e0_b[2 * u + h], e1 = e1_b[2 * u + h];
-        if (block) {
-          exp_from_block(r, h, e0, e1);
-        } else if (!D.exp_noise) {
-          exp_pair(D.seed, D.step, D.agent_offset + a, e0, e1);
-        }
-        const float nw = D.exp_noise ? gumbel_new_infected(p, e0, e1) : ratio_new_infected(p, e0, e1);
-        if (D.new_infected) D.new_infected[a] = nw;
-        if (nw != 0.0f) {
-          float inf = D.is_infected[a], t_inf = D.infection_time[a];
-          infect(nw, D.now, susc, inf, t_inf);
-          D.susceptibility[a] = susc;
-          D.is_infected[a] = inf;
-          D.infection_time[a] = t_inf;
-        }
+    for (int m = 0; m < kQ; ++m) {
+      const int q = tid + m * kTileThreads;
+      if (4 * q < n_local) {
+        acc4[q] = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
+        susc4[q] = make_float4(sq[m][0], sq[m][1], sq[m][2], sq[m][3]);
       }
     }
   }
+  GJ_STAMP(4);
+  // Epilogue a7-a9, a quad at a time; in Philox mode one block serves an agent pair (two blocks per quad).
+  const bool pair_aligned = ((D.agent_offset + base) & 1) == 0;   // local pairs are global pairs (else: per agent)
+  for (int q = tid; 4 * q < n_local; q += kTileThreads) {
+    const int i0 = 4 * q;
+    const float4 aq = acc4[q], sv = susc4[q];
+    const float accq[4] = {aq.x, aq.y, aq.z, aq.w};
+    const int64_t a0 = base + i0;
+    const int n_ok = n_local - i0;
+    float susc[4] = {sv.x, sv.y, sv.z, sv.w}, ts[4], p[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ts[j] = susc[j] * accq[j];
+      const float tc = fminf(fmaxf(ts[j], 1e-6f), 100.0f);
+      p[j] = fminf(fmaxf(expf(-tc * D.dt), 0.0f), 1.0f);
+    }
+#ifndef GJ_DIAG_STAMPS
+    if (D.trans_susc) store_quad(D.trans_susc, a0, n_ok, vec, ts);
+#endif
+    if (D.not_infected_probs) store_quad(D.not_infected_probs, a0, n_ok, vec, p);
+    if (!D.sample) continue;
+    float nw[4];
+    const bool block = !D.exp_noise && pair_aligned;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      uint32_t r[4] = {0u, 0u, 0u, 0u};
+      if (block) philox4x32_10((uint64_t)(D.agent_offset + a0 + 2 * h) >> 1, D.step, D.seed, r);
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int j = 2 * h + g;
+        float e0 = 1.0f, e1 = 1.0f;
+        if (D.exp_noise) {
+          if (j < n_ok) {
+            e0 = D.exp_noise[a0 + j];
+            e1 = D.exp_noise[D.n_agents + a0 + j];
+          }
+        } else if (block) {
+          exp_from_block(r, g, e0, e1);
+        } else {
+          exp_pair(D.seed, D.step, D.agent_offset + a0 + j, e0, e1);
+        }
+        nw[j] = D.exp_noise ? gumbel_new_infected(p[j], e0, e1) : ratio_new_infected(p[j], e0, e1);
+      }
+    }
+    if (D.new_infected) store_quad(D.new_infected, a0, n_ok, vec, nw);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < n_ok && nw[j] != 0.0f) {
+        const int64_t a = a0 + j;
+        float sc = susc[j], inf = D.is_infected[a], t_inf = D.infection_time[a];
+        infect(nw[j], D.now, sc, inf, t_inf);
+        D.susceptibility[a] = sc;
+        D.is_infected[a] = inf;
+        D.infection_time[a] = t_inf;
+      }
+    }
+  }
+  GJ_STAMP(5);
 }
 
 }  // namespace gj

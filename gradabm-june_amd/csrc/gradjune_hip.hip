@@ -885,6 +885,11 @@ static int check_tiled(const gj_plan* plan) {
     if (!S.blk_v0 || !S.blk_e0 || !S.tile_sptr || !S.tile_jpos || !S.chunk_ptr) return GJ_E_NULL;
     if (plan->sets[s].n_edges > 0 && (!S.e_lv || !S.a_la || !S.val || !S.chunk_desc)) return GJ_E_NULL;
     if (S.max_block_venues < 1 || S.max_block_venues > 65536) return GJ_E_PLAN;
+    if (S.ell_k) {   // direct form of pass 2: 16-bit venue ids, one 2/4/8/16-byte row per agent
+      if (S.ell_k != 2 && S.ell_k != 4 && S.ell_k != 8) return GJ_E_PLAN;
+      if (!S.ell) return GJ_E_NULL;
+      if (plan->sets[s].n_venues > 65534) return GJ_E_PLAN;
+    }
   }
   return GJ_OK;
 }
@@ -916,6 +921,7 @@ static void fill_set_a(const gj_plan* plan, const gj_step_params* p, const Group
     sets[s].active = (S.n_blocks > 0 && plan->sets[s].n_edges > 0) ? G.nk[g] : 0;
     sets[s].raw = p->nets[G.first[g]].mask_kind == GJ_MASK_RAW;
     sets[s].wide = S.desc_wide != 0;
+    sets[s].direct = S.ell_k != 0;
   }
 }
 
@@ -960,6 +966,7 @@ static int tiled_venues(const gj_plan* plan, const gj_step_params* p, const Grou
     X.cum = E.cum;
     X.stride = E.cum_stride;
     X.nk = S.n_blocks > 0 ? G.nk[g] : 0;
+    X.direct = S.ell_k != 0;
     X.leisure = 0;
     for (int k = 0; k < G.nk[g]; ++k) {
       const gj_network& N = p->nets[G.first[g] + k];
@@ -1016,10 +1023,65 @@ static int tiled_agents(const gj_plan* plan, const gj_agent_state* st, const gj_
   D.step = p->step;
   D.agent_offset = p->agent_offset;
   D.acc_scratch = T->agent_scratch;
-  const size_t lds = slice_lds(T, sizeof(fx_t));
+  size_t lds = slice_lds(T, sizeof(fx_t));
+  // direct form of pass 2: the sets whose cum is read from an LDS table behind the slice's (compacted) sums
+  D.n_direct = 0;
+  D.day_type = p->day_type;
+  D.transpose = p->transpose;
+  D.cls = plan->agent_class;
+  D.tables = plan->tables;
+  int64_t need = 0;
+  const int64_t owned_slices = (plan->n_agents + T->slice_agents - 1) / T->slice_agents;
+  for (int g = 0; g < G.n; ++g) {
+    const int s = G.set[g];
+    const gj_tiled_set& S = T->sets[s];
+    const gj_edge_set& E = plan->sets[s];
+    if (!S.ell_k || S.n_blocks == 0 || E.n_edges == 0) continue;
+    if (D.n_direct == GJ_MAX_DIRECT) return GJ_E_PLAN;
+    TDirect& X = D.direct[D.n_direct++];
+    X.ell = S.ell;
+    X.cum = E.cum;
+    X.K = 2;
+    X.planes = S.ell_k / 2;
+    X.plane_stride = owned_slices * (int64_t)T->slice_agents * 2;
+    X.V = (int32_t)E.n_venues;
+    X.stride = E.cum_stride;
+    X.nk = G.nk[g];
+    X.raw = p->nets[G.first[g]].mask_kind == GJ_MASK_RAW;
+    X.leisure = 0;
+    for (int k = 0; k < GJ_MAX_NETS_PER_SET; ++k) X.table[k] = X.age75[k] = 0;
+    for (int k = 0; k < G.nk[g]; ++k) {
+      const gj_network& N = p->nets[G.first[g] + k];
+      X.table[k] = N.mask_kind >= GJ_MASK_QL ? N.table : -1;
+      X.age75[k] = N.mask_kind == GJ_MASK_QL_AGE75;
+      if (N.mask_kind >= GJ_MASK_QL) X.leisure = 1;
+    }
+    if (X.leisure) {
+      // the direct form reads four agents' classes as one dword (see gj_plan.agent_class)
+      if (!plan->agent_class || (uintptr_t)plan->agent_class % 4 != 0) return GJ_E_PLAN;
+      for (int k = 0; k < G.nk[g]; ++k)
+        if (X.table[k] < 0) return GJ_E_PLAN;
+    } else if (G.nk[g] != 1) {
+      return GJ_E_PLAN;
+    }
+    need = need > (int64_t)X.nk * X.V ? need : (int64_t)X.nk * X.V;
+  }
+  D.table_floats = 0;
+  if (D.n_direct) {
+    const int64_t avail = 160 * 1024 / 4 - kClassWeightFloats;     // the slice's sums are in registers by then
+    D.table_floats = (int32_t)(need < avail ? need : avail);
+    if (T->direct_table_floats > 0 && T->direct_table_floats < D.table_floats) D.table_floats = T->direct_table_floats;
+    if (D.table_floats < GJ_MAX_NETS_PER_SET) D.table_floats = GJ_MAX_NETS_PER_SET;
+    const size_t direct_lds = 4 * ((size_t)kClassWeightFloats + (size_t)D.table_floats);
+    if (direct_lds > lds) lds = direct_lds;
+  }
+  {
+    uintptr_t bits = (uintptr_t)D.susceptibility | (uintptr_t)D.not_infected_probs | (uintptr_t)D.new_infected |
+                     (uintptr_t)D.trans_susc | (uintptr_t)D.acc_scratch;
+    D.io_vec4 = (bits % 16 == 0) ? 1 : 0;
+  }
   int rc = allow_lds(k_tile_agents, lds);
   if (rc) return rc;
-  const int64_t owned_slices = (plan->n_agents + T->slice_agents - 1) / T->slice_agents;
   hipLaunchKernelGGL(k_tile_agents, dim3((unsigned)owned_slices), dim3(kTileThreads), lds, stream, D);
   rc = launch_status();
   if (rc || !D.acc_scratch) return rc;

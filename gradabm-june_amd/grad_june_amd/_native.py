@@ -10,7 +10,7 @@ import ctypes as C
 import os
 from typing import Optional
 
-GJ_ABI_VERSION = 1
+GJ_ABI_VERSION = 2
 GJ_MAX_SETS = 12
 GJ_MAX_NETS = 16
 GJ_MAX_NETS_PER_SET = 8
@@ -20,7 +20,8 @@ GJ_STREAM_EDGES = 2048
 MASK_RAW, MASK_Q, MASK_QL, MASK_QL_AGE75 = 0, 1, 2, 3
 
 _LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
-LIB_PATH = os.path.join(_LIB_DIR, "libgradjune_hip.so")
+# GJ_LIB_PATH: another build of the same library (kernel experiments, tools/ab.py); never a different implementation
+LIB_PATH = os.environ.get("GJ_LIB_PATH") or os.path.join(_LIB_DIR, "libgradjune_hip.so")
 
 _vp = C.c_void_p
 
@@ -45,7 +46,7 @@ class TiledSet(C.Structure):
         ("n_blocks", C.c_int32),
         ("max_block_venues", C.c_int32),
         ("desc_wide", C.c_int32),
-        ("_pad", C.c_int32),
+        ("ell_k", C.c_int32),
         ("blk_v0", _vp),
         ("blk_e0", _vp),
         ("e_lv", _vp),
@@ -56,6 +57,7 @@ class TiledSet(C.Structure):
         ("chunk_ptr", _vp),
         ("chunk_desc", _vp),
         ("val", _vp),
+        ("ell", _vp),
     ]
 
 
@@ -63,7 +65,7 @@ class Tiled(C.Structure):
     _fields_ = [
         ("n_slices", C.c_int32),
         ("slice_agents", C.c_int32),
-        ("_pad", C.c_int32),
+        ("direct_table_floats", C.c_int32),
         ("n_work", C.c_int32),
         ("work", _vp),
         ("agent_scratch", _vp),

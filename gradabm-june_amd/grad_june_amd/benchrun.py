@@ -72,7 +72,11 @@ class SingleGpuHotPath:
                                  rate=s["rate"], shift=s["shift"], infection_time=s["infection_time"],
                                  is_infected=s["is_infected"], susceptibility=s["susceptibility"],
                                  transmission=s["transmission"], current_stage=s["current_stage"])
-        self.io = self.engine.io(not_infected_probs=self.probs, new_infected=self.new_infected, exp_noise=exp_noise)
+        import os
+
+        self.stamps = torch.zeros(A, dtype=torch.float32, device=self.device) if os.environ.get("GJ_DIAG_STAMPS") else None
+        self.io = self.engine.io(not_infected_probs=self.probs, new_infected=self.new_infected, exp_noise=exp_noise,
+                                 trans_susc=self.stamps)
         self.t = 0
         self.log = EventLog()
 

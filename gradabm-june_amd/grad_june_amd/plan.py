@@ -208,11 +208,12 @@ def save_plan(plan: HostPlan, path) -> None:
                 out[p + k] = getattr(s, k)
         if s.tiled is not None:
             t = s.tiled
-            for k in ("blk_v0", "blk_e0", "e_lv", "e_cls", "a_la", "tile_sptr", "tile_jpos", "chunk_ptr", "chunk_desc"):
+            for k in ("blk_v0", "blk_e0", "e_lv", "e_cls", "a_la", "tile_sptr", "tile_jpos", "chunk_ptr", "chunk_desc", "ell"):
                 if getattr(t, k) is not None:
                     a = _host(getattr(t, k))
-                    out[p + "tiled/" + k] = a.view(np.uint16) if (k in ("e_lv", "a_la") and a.dtype == np.int16) else a
-            out[p + "tiled/meta"] = np.array([t.n_slices, t.n_blocks, t.n_slots, int(t.desc_wide)], dtype=np.int64)
+                    out[p + "tiled/" + k] = a.view(np.uint16) if (k in ("e_lv", "a_la", "ell") and a.dtype == np.int16) else a
+            out[p + "tiled/meta"] = np.array([t.n_slices, t.n_blocks, t.n_slots, int(t.desc_wide), int(t.ell_k)],
+                                             dtype=np.int64)
     np.savez(path, **out)
 
 
@@ -227,13 +228,16 @@ def load_plan(path) -> HostPlan:
         hs = HostEdgeSet(name, int(a[p + "n_venues"]), int(a[p + "n_edges"]), a.get(p + "v_rowptr"), a.get(p + "v_agent"),
                          a[p + "v_pcontact"], a.get(p + "a_rowptr"), a.get(p + "a_venue"))
         if p + "tiled/meta" in a:
-            S, J, n_slots, wide = (int(x) for x in a[p + "tiled/meta"])
+            meta = [int(x) for x in a[p + "tiled/meta"]]
+            S, J, n_slots, wide = meta[:4]
+            ell_k = meta[4] if len(meta) > 4 else 0
             hs.tiled = TL.TiledEdgeSet(name=name, n_venues=hs.n_venues, n_edges=hs.n_edges, n_slices=S, n_blocks=J,
                                        blk_v0=a[p + "tiled/blk_v0"], blk_e0=a[p + "tiled/blk_e0"], e_lv=a[p + "tiled/e_lv"],
                                        e_cls=a.get(p + "tiled/e_cls"), a_la=a[p + "tiled/a_la"],
                                        tile_sptr=a[p + "tiled/tile_sptr"], tile_jpos=a[p + "tiled/tile_jpos"],
                                        v_pcontact=hs.v_pcontact, n_slots=n_slots, chunk_ptr=a[p + "tiled/chunk_ptr"],
-                                       chunk_desc=a[p + "tiled/chunk_desc"], desc_wide=bool(wide))
+                                       chunk_desc=a[p + "tiled/chunk_desc"], desc_wide=bool(wide),
+                                       ell=a.get(p + "tiled/ell"), ell_k=ell_k)
         sets.append(hs)
     return HostPlan(int(a["meta/n_agents"]), int(a["meta/n_ext_agents"]), sets, a["agent_class"], a["blocks"],
                     a["long_rows"], int(a["meta/n_partial_slots"]), {s.name: i for i, s in enumerate(sets)},
@@ -254,7 +258,7 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
                  layout: str = "csr", leisure_sets: Sequence[str] = ("leisure",),
                  sv_max: int = TL.SV_MAX, eb_target: Optional[int] = None, slices=None,
                  nets_per_set: Optional[Dict[str, int]] = None, progress=None,
-                 desc_wide: Optional[bool] = None, device=None) -> HostPlan:
+                 desc_wide: Optional[bool] = None, device=None, direct=None) -> HostPlan:
     """edge_sets: {name: {"agent": i64[E], "venue": i64[E], "people": [V]}} (insertion order = set ids).
 
     layout: "csr" (deterministic CSR kernels), "tiled" (LDS-tiled fast path) or "both".
@@ -263,6 +267,9 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
     desc_wide: chunk descriptor format of the tiled layout (None: per set, from its tile sizes).
     device: build the tiled arrays with torch ops on this device (tiling_device.build_tiled_device: the
     same arrays, born in HBM); the edge lists may then be torch tensors.  Default: numpy on the host.
+    direct: which sets take pass 2 in the "direct" form (tiling.build_ell: phase C skipped, phase D reads the
+    venues' cum from an LDS table).  None = every set whose sizes allow it (tiling.direct_eligible), False =
+    none, or a collection of set names (must be eligible).
     """
     if len(edge_sets) > N.GJ_MAX_SETS:
         raise ValueError(f"at most {N.GJ_MAX_SETS} edge sets")
@@ -302,6 +309,7 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
                                           agent_class=use_cls, sv_max=max(16, sv_max // max(1, k)),
                                           eb_target=eb_target, wide=desc_wide)
             t = hs.tiled
+            _attach_ell(t, es, n_agents, SA, k, direct, device)
             blk_e0, blk_v0 = _host(t.blk_e0).astype(np.int64), _host(t.blk_v0).astype(np.int64)
             for j in range(t.n_blocks):
                 work.append((int(blk_e0[j + 1] - blk_e0[j]) + int(blk_v0[j + 1] - blk_v0[j]), sid, j))
@@ -333,11 +341,42 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
                     work=work_arr if want_tiled else None)
 
 
+def _attach_ell(t: TL.TiledEdgeSet, es: dict, n_agents: int, slice_agents: int, nets: int, direct, device) -> None:
+    """Decide whether pass 2 of this set runs in the direct form and, if so, build its ELL table."""
+    if direct is False or t.n_edges == 0:
+        return
+    n_owned_slices = max(1, -(-n_agents // slice_agents))
+    if device is not None:
+        import torch
+
+        from .tiling_device import build_ell_device, ell_degree_max
+
+        dev_t = lambda a: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))).to(device)
+        agent, venue = dev_t(es["agent"]), dev_t(es["venue"])
+        e_owned, dmax = ell_degree_max(agent, n_agents)
+    else:
+        agent = np.asarray(_host(es["agent"]), dtype=np.int64).ravel()
+        venue = _host(es["venue"])
+        own = agent[agent < n_agents]
+        e_owned = int(len(own))
+        dmax = int(np.bincount(own, minlength=max(1, n_agents)).max()) if e_owned else 0
+    ok = TL.direct_eligible(t.n_venues, e_owned, n_agents, dmax, nets, slice_agents)
+    forced = direct is not None and t.name in direct
+    if forced and not ok:
+        raise ValueError(f"edge set {t.name}: not eligible for the direct form of pass 2")
+    if not ok or (direct is not None and not forced):
+        return
+    if device is not None:
+        t.ell, t.ell_k = build_ell_device(agent, venue, n_agents, n_owned_slices, slice_agents)
+    else:
+        t.ell, t.ell_k = TL.build_ell(agent, venue, n_agents, n_owned_slices, slice_agents)
+
+
 class DevicePlan:
     """The plan resident in HBM + the ctypes ``gj_plan`` that points at it."""
 
     def __init__(self, host: HostPlan, networks: Sequence[NetworkSpec], device, flat_cum_sets: Sequence[str] = (),
-                 split_epilogue: bool = False):
+                 split_epilogue: bool = False, direct_table_floats: int = 0):
         """flat_cum_sets: edge sets whose ``cum`` workspaces are carved from ONE contiguous buffer
         (``self.flat_cum``) so that a single collective can combine them across ranks."""
         self.host = host
@@ -409,6 +448,7 @@ class DevicePlan:
                 if self.tiled_c is None:
                     self.tiled_c = N.Tiled()
                     self.tiled_c.n_slices, self.tiled_c.slice_agents = host.n_slices, host.slice_agents
+                    self.tiled_c.direct_table_floats = int(direct_table_floats)
                 u16 = lambda a: up(a if isinstance(a, torch.Tensor) else a.view(np.int16))   # uint16 bit patterns
                 t.update(blk_v0=up(ts.blk_v0), blk_e0=up(ts.blk_e0), e_lv=u16(ts.e_lv), a_la=u16(ts.a_la),
                          tile_sptr=up(ts.tile_sptr), tile_jpos=up(ts.tile_jpos),
@@ -416,6 +456,8 @@ class DevicePlan:
                          val=torch.zeros(max(8, ts.n_slots), dtype=torch.float32, device=dev))
                 if ts.e_cls is not None:
                     t["e_cls"] = up(ts.e_cls)
+                if ts.ell_k:
+                    t["ell"] = u16(ts.ell).reshape(-1)
                 c = self.tiled_c.sets[i]
                 c.n_blocks = ts.n_blocks
                 c.max_block_venues = int(np.diff(_host(ts.blk_v0)).max()) if ts.n_blocks else 0
@@ -425,13 +467,16 @@ class DevicePlan:
                 c.e_cls = N.ptr(t.get("e_cls"))
                 c.tile_sptr, c.tile_jpos, c.val = t["tile_sptr"].data_ptr(), t["tile_jpos"].data_ptr(), t["val"].data_ptr()
                 c.chunk_ptr, c.chunk_desc = t["chunk_ptr"].data_ptr(), N.ptr(t["chunk_desc"])
+                c.ell_k, c.ell = int(ts.ell_k), N.ptr(t.get("ell"))
             self.keep.append(t)
             self.cum.append(cum)
         self.blocks = up(host.blocks.reshape(-1)) if len(host.blocks) else None
         self.long_rows = up(host.long_rows.reshape(-1)) if len(host.long_rows) else None
         self.partial = (torch.zeros(host.n_partial_slots * N.GJ_MAX_NETS_PER_SET, dtype=torch.float32, device=dev)
                         if host.n_partial_slots else None)
-        self.agent_class = up(host.agent_class)
+        cls_pad = np.zeros(-(-len(host.agent_class) // 4) * 4 + 4, dtype=np.uint8)   # quads of classes are one load
+        cls_pad[: len(host.agent_class)] = _host(host.agent_class)
+        self.agent_class = up(cls_pad)
         plan.n_blocks = len(host.blocks)
         plan.n_long_rows = len(host.long_rows)
         plan.n_partial_slots = host.n_partial_slots

@@ -100,6 +100,8 @@ class TiledEdgeSet:
     chunk_ptr: Optional[np.ndarray] = None   # int32 [S+1] first 64-edge chunk of slice s (slice-major)
     chunk_desc: Optional[np.ndarray] = None  # int32 [n_chunks, 4]: slot0, slot1, split | multi << 16, j0
     desc_wide: bool = False                  # chunk_desc is int32 [n_chunks, 8], see wide_descriptors()
+    ell: Optional[np.ndarray] = None         # uint16 [owned agents padded to slices, ell_k]: "direct" pass 2, see build_ell()
+    ell_k: int = 0                           # 0: pass 2 runs through phases C + D like pass 1
     # A chunk = 64 consecutive slice-major edges.  Its first `split` edges lie in one tile and map to
     # block-major slots slot0, slot0+1, ...; the rest lie in the next non-empty tile and map to slot1,
     # slot1+1, ...  `multi` flags the rare chunk that spans more than two tiles (tiny tiles): its
@@ -237,6 +239,110 @@ def build_tiled(name: str, agent_index, venue_index, n_venues: int, v_pcontact: 
         tile_sptr=sptr.astype(np.int32), tile_jpos=jpos_sj.reshape(-1).astype(np.int32),
         v_pcontact=np.asarray(v_pcontact, dtype=np.float32), n_slots=n_slots,
         chunk_ptr=chunk_ptr.astype(np.int32), chunk_desc=np.ascontiguousarray(chunk_desc), desc_wide=bool(wide))
+
+
+# ------------------------------------------------------------------------------------------------
+# "direct" pass 2 for sets with few venues
+# ------------------------------------------------------------------------------------------------
+# When a set has so few venues that its whole cum vector fits in LDS (schools, universities, leisure venues:
+# 10^3-10^4 venues against 10^7 agents), pass 2 needs no per-edge workspace at all: phase C is skipped and
+# phase D, after the tiled sets are accumulated, loads the set's cum into LDS and every lane adds up the
+# venues of ITS agents from an ELL table (K 16-bit venue ids per agent, 0xFFFF = none).  Per edge that is
+# ~2*K/deg bytes of indices instead of 12.5 (C: e_lv + val write, D: a_la + val read + descriptors), no LDS
+# atomics, and the sum of an agent is taken in its COO edge order.
+DIRECT_MAX_VENUES = 65534     # venue ids are 16-bit, 0xFFFF = pad
+DIRECT_MAX_K = 8              # ELL columns (a power of two: one 2/4/8/16-byte load per agent)
+DIRECT_TABLE_GROUPS = 4       # the venues' cum may be staged through LDS in at most this many groups
+DIRECT_MAX_PAD = 4.0          # ELL entries per edge above which the tiled form is cheaper
+LDS_BYTES = 160 * 1024
+DIRECT_WEIGHT_FLOATS = 8 * 200   # per-class weights of up to GJ_MAX_NETS_PER_SET leisure networks
+
+
+def direct_table_floats(slice_agents: int = 0) -> int:
+    """Floats of LDS for a group of venue values in phase D's direct form: by then the slice's sums are in
+    registers, so all of the LDS but the leisure class weights."""
+    return LDS_BYTES // 4 - DIRECT_WEIGHT_FLOATS
+
+
+def direct_columns(degree_max: int) -> int:
+    """ELL columns: a power of two >= 2 (the kernel takes an agent's entries in pairs)."""
+    k = 2
+    while k < degree_max:
+        k *= 2
+    return k
+
+
+def direct_eligible(n_venues: int, n_edges_owned: int, n_agents: int, degree_max: int, nets: int,
+                    slice_agents: int) -> bool:
+    """Does pass 2 of this set run in the direct form?  A function of the set's sizes only."""
+    if n_edges_owned == 0 or n_venues > DIRECT_MAX_VENUES or degree_max > DIRECT_MAX_K:
+        return False
+    if n_venues * max(1, nets) > DIRECT_TABLE_GROUPS * direct_table_floats(slice_agents):
+        return False
+    return direct_columns(degree_max) * n_agents <= DIRECT_MAX_PAD * n_edges_owned
+
+
+def ell_planes(ell_rows_by_k, K: int):
+    """[rows, K] -> the device form [planes, rows, 2]: columns in pairs, one plane per pair, so that one kernel body
+    (a pair of entries per agent) serves every K."""
+    if K <= 2:
+        return ell_rows_by_k.reshape(1, ell_rows_by_k.shape[0], K)
+    rows = ell_rows_by_k.shape[0]
+    return ell_rows_by_k.reshape(rows, K // 2, 2).transpose(1, 0, 2) if isinstance(ell_rows_by_k, np.ndarray) \
+        else ell_rows_by_k.reshape(rows, K // 2, 2).permute(1, 0, 2)
+
+
+def build_ell(agent_index, venue_index, n_agents: int, n_slices_owned: int, slice_agents: int):
+    """ELL form of the OWNED agents' edges: uint16 [planes, n_slices_owned * slice_agents, min(K, 2)]; entry
+    (c // 2, a, c % 2) = the venue of agent a's c-th edge in COO order, 0xFFFF = no edge.  Returns (ell, K)."""
+    agent = np.asarray(agent_index, dtype=np.int64).ravel()
+    venue = np.asarray(venue_index, dtype=np.int64).ravel()
+    owned = agent < n_agents
+    a, v = agent[owned], venue[owned]
+    order = np.argsort(a, kind="stable")
+    a, v = a[order], v[order]
+    deg = np.bincount(a, minlength=n_agents)
+    K = direct_columns(int(deg.max()) if len(deg) else 1)
+    rowptr = np.zeros(n_agents + 1, dtype=np.int64)
+    np.cumsum(deg, out=rowptr[1:])
+    col = np.arange(len(a), dtype=np.int64) - rowptr[a]
+    ell = np.full((n_slices_owned * slice_agents, K), 0xFFFF, dtype=np.uint16)
+    ell[a, col] = v.astype(np.uint16)
+    return np.ascontiguousarray(ell_planes(ell, K)), K
+
+
+def ell_rows(ell) -> np.ndarray:
+    """The device form [planes, rows, kp] back to [rows, K] (tests, emulation)."""
+    planes, rows, kp = ell.shape
+    return np.ascontiguousarray(np.asarray(ell).transpose(1, 0, 2).reshape(rows, planes * kp))
+
+
+def emulate_direct_pass2(ell: np.ndarray, cum: np.ndarray, n_agents: int, weights: Optional[np.ndarray] = None,
+                         agent_class: Optional[np.ndarray] = None, group_venues: Optional[int] = None):
+    """Phase D's direct form: acc[a] = sum over the agent's ELL entries of cum[v] (x weights[k][class[a]] summed
+    over the set's networks k when ``cum`` is [V, nk]), venue groups of ``group_venues`` in turn, fp32."""
+    if ell.ndim == 3:
+        ell = ell_rows(ell)
+    cum = np.asarray(cum, dtype=np.float32)
+    cum2 = cum.reshape(len(cum), -1)
+    V, nk = cum2.shape
+    gv = group_venues or max(1, V)
+    acc = np.zeros(n_agents, dtype=np.float32)
+    for v0 in range(0, max(V, 1), gv):
+        s = np.zeros(n_agents, dtype=np.float32)              # one lane's sum over its agent's entries in this group
+        for c in range(ell.shape[1]):
+            lv = ell[:n_agents, c].astype(np.int64)
+            ok = (lv != 0xFFFF) & (lv >= v0) & (lv < v0 + gv)
+            idx = np.where(ok, lv, 0)
+            if weights is None:
+                term = cum2[idx, 0]
+            else:
+                term = np.zeros(n_agents, dtype=np.float32)
+                for k in range(nk):
+                    term = term + weights[k][agent_class[:n_agents]] * cum2[idx, k]
+            s = s + np.where(ok, term, np.float32(0)).astype(np.float32)
+        acc = acc + s
+    return acc
 
 
 # ------------------------------------------------------------------------------------------------

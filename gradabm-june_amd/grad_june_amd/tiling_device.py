@@ -158,3 +158,32 @@ def build_tiled_device(name: str, agent_index: torch.Tensor, venue_index: torch.
         blk_v0=i32(blk_v0), blk_e0=i32(blk_start), e_lv=e_lv, e_cls=e_cls, a_la=a_la,
         tile_sptr=i32(sptr), tile_jpos=i32(jpos_sj), v_pcontact=v_pc.to(dev), n_slots=n_slots,
         chunk_ptr=i32(chunk_ptr), chunk_desc=chunk_desc.contiguous(), desc_wide=bool(wide))
+
+
+def ell_degree_max(agent_index: torch.Tensor, n_agents: int):
+    """(edges of owned agents, their maximum degree) - what tiling.direct_eligible needs."""
+    agent = agent_index.reshape(-1).to(torch.int64)
+    a = agent[agent < n_agents]
+    if not a.numel():
+        return 0, 0
+    return int(a.numel()), int(torch.bincount(a, minlength=n_agents).max())
+
+
+def build_ell_device(agent_index: torch.Tensor, venue_index: torch.Tensor, n_agents: int, n_slices_owned: int,
+                     slice_agents: int):
+    """tiling.build_ell with torch ops on the tensors' device: (int16 [planes, rows, min(K, 2)] holding uint16 bit patterns, K)."""
+    dev = agent_index.device
+    agent = agent_index.reshape(-1).to(torch.int64)
+    venue = venue_index.reshape(-1).to(torch.int64)
+    owned = agent < n_agents
+    a, v = agent[owned], venue[owned]
+    order = torch.argsort(a, stable=True)
+    a, v = a[order], v[order]
+    deg = torch.bincount(a, minlength=n_agents)
+    K = TL.direct_columns(int(deg.max()) if deg.numel() else 1)
+    rowptr = torch.zeros(n_agents + 1, dtype=torch.int64, device=dev)
+    rowptr[1:] = torch.cumsum(deg, 0)
+    col = torch.arange(a.numel(), dtype=torch.int64, device=dev) - rowptr[a]
+    ell = torch.full((n_slices_owned * slice_agents, K), -1, dtype=torch.int16, device=dev)   # 0xFFFF = none
+    ell[a, col] = _u16(v)
+    return TL.ell_planes(ell, K).contiguous(), K

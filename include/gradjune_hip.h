@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GJ_ABI_VERSION 1
+#define GJ_ABI_VERSION 2
 
 #define GJ_MAX_SETS 12        /* distinct agent<->venue edge sets in a world (reference: 6)   */
 #define GJ_MAX_NETS 16        /* infection networks active in one step (reference: <= 11)      */
@@ -114,7 +114,9 @@ typedef struct gj_tiled_set {
   int32_t n_blocks;          /* J: venue blocks of this set                                  */
   int32_t max_block_venues;  /* largest block of this set (sizes the LDS of phases B/C)      */
   int32_t desc_wide;         /* 0: chunk_desc holds 4, 1: 8 int32 per chunk (see chunk_desc)  */
-  int32_t _pad;
+  int32_t ell_k;             /* 0: pass 2 of this set runs through phases C + D.  2, 4 or 8: "direct"
+                                form - phase C is skipped, phase D reads the venues' cum from an LDS
+                                table through `ell` (sets with <= 65534 venues, see `ell`)        */
   const int32_t* blk_v0;     /* device [J+1]   venue range of block j                        */
   const int32_t* blk_e0;     /* device [J+1]   block-major SLOT range of block j; every block is
                                                padded to a multiple of 8 slots (16-byte accesses) */
@@ -136,12 +138,17 @@ typedef struct gj_tiled_set {
                                 base_k + lane (start_0 = 0, unused segments start at 64);
                                 multi: more than 6 tiles                                        */
   float* val;                /* device [slots] workspace: per-edge value (phase A->B, C->D)  */
+  const uint16_t* ell;       /* device [ell_k / 2 planes][owned slices * slice_agents][2] or NULL: the venue
+                                ids (whole-set numbering) of each OWNED agent's edges in COO order, columns in pairs (plane p holds an agent's edges 2p and
+                                2p + 1), 0xFFFF = none.  Replaces a_la / val / chunk_desc reads of phase D and
+                                all of phase C for this set: 2 * ell_k bytes per agent                    */
 } gj_tiled_set;
 
 typedef struct gj_tiled {
   int32_t n_slices;          /* S                                                            */
   int32_t slice_agents;      /* SA (multiple of 64, <= 20480: one slice of 8-byte sums fits LDS) */
-  int32_t _pad;
+  int32_t direct_table_floats; /* 0: the direct form of pass 2 stages as many venue values through LDS at once
+                                as fit; > 0: at most this many (tests: forces several groups)   */
   int32_t n_work;            /* entries of `work`                                            */
   const int32_t* work;       /* device [2*n_work] (set, block) pairs, heaviest first         */
   float* agent_scratch;      /* device [n_agents] workspace or NULL.  Non-NULL: phase D hands its
@@ -164,7 +171,9 @@ typedef struct gj_plan {
   const gj_block* blocks;     /* device [n_blocks]                                          */
   const gj_long_row* long_rows; /* device [n_long_rows]                                     */
   float* partial;             /* device [n_partial_slots * GJ_MAX_NETS_PER_SET] workspace   */
-  const uint8_t* agent_class; /* device [n_ext_agents]  sex*100 + age  (0..199)             */
+  const uint8_t* agent_class; /* device [n_ext_agents]  sex*100 + age  (0..199).  4-byte aligned and
+                                 readable up to the next multiple of 4 agents when a leisure set is
+                                 in the direct form (gj_tiled_set.ell): four classes are one load   */
   const float* tables;        /* device [n_tables * GJ_TABLE_SIZE] leisure tables           */
   int32_t n_tables;
   int32_t _pad;

@@ -421,6 +421,8 @@ def test_c_abi_from_plain_c(device, tmp_path):
     import os
     import subprocess
 
+    from grad_june_amd import _native as N
+
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib_dir = os.path.join(root, "gradabm-june_amd", "grad_june_amd", "lib")
     exe = str(tmp_path / "abi_demo")
@@ -428,7 +430,7 @@ def test_c_abi_from_plain_c(device, tmp_path):
                     "-I", os.path.join(root, "include"), "-L", lib_dir, "-lgradjune_hip", "-L/opt/rocm/lib", "-lamdhip64",
                     f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True, capture_output=True)
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
-    assert "ok" in out and "ABI version 1" in out
+    assert "ok" in out and f"ABI version {N.GJ_ABI_VERSION}" in out
 
 
 def test_locality_order_gives_the_same_probabilities(G, device):

@@ -22,12 +22,20 @@ RTOL = 2e-5
 
 # every parity case runs on both device layouts: "csr" (deterministic CSR kernels) and "tiled"
 # (LDS-tiled fast path; small tiles/blocks forced so that multi-slice / multi-block paths run)
-LAYOUTS = [("csr", {}), ("tiled", {}), ("tiled", dict(sv_max=64, eb_target=512, slices="small", desc_wide=False)),
-           ("tiled", dict(sv_max=64, eb_target=512, slices="small", desc_wide=True)),
-           ("tiled", dict(sv_max=16, eb_target=64, slices="small", desc_wide=True)),
-           ("tiled", dict(split_epilogue=True))]
+# and with pass 2 in its two forms: through the per-edge workspace (phases C + D, direct=False) and "direct" (venue
+# values staged through LDS, tiling.build_ell; the golden worlds are small enough for every set to qualify - a tiny
+# table forces several venue groups per set)
+LAYOUTS = [("csr", {}), ("tiled", dict(direct=False)),
+           ("tiled", dict(sv_max=64, eb_target=512, slices="small", desc_wide=False, direct=False)),
+           ("tiled", dict(sv_max=64, eb_target=512, slices="small", desc_wide=True, direct=False)),
+           ("tiled", dict(sv_max=16, eb_target=64, slices="small", desc_wide=True, direct=False)),
+           ("tiled", dict(split_epilogue=True, direct=False)),
+           ("tiled", {}), ("tiled", dict(sv_max=64, eb_target=512, slices="small", direct_table_floats=24)),
+           ("tiled", dict(split_epilogue=True, direct_table_floats=40)),
+           ("tiled", dict(slices="small", direct=("school", "leisure", "household")))]
 LAYOUT_IDS = ["csr", "tiled", "tiled-small-tiles", "tiled-small-tiles-wide-desc", "tiled-tiny-tiles-wide-desc",
-              "tiled-split-epilogue"]
+              "tiled-split-epilogue", "tiled-direct", "tiled-direct-small-tiles-venue-groups",
+              "tiled-direct-split-epilogue-venue-groups", "tiled-direct-some-sets"]
 
 
 def engine_for(world, tables, device, layout):
@@ -36,6 +44,13 @@ def engine_for(world, tables, device, layout):
     if kw.get("slices") == "small":
         sa = 64
         kw["slices"] = (-(-world["n_agents"] // sa), sa)
+    if isinstance(kw.get("direct"), tuple):      # name only the sets this world has and that qualify
+        from grad_june_amd.plan import compile_plan
+
+        es = {k: {kk: vv.numpy() for kk, vv in v.items()} for k, v in world["edge_sets"].items()}
+        auto = compile_plan(world["n_agents"], es, age=world["age"].numpy(), sex=world["sex"].numpy(), layout="tiled",
+                            slices=kw.get("slices"))
+        kw["direct"] = tuple(s.name for s in auto.sets if s.tiled.ell_k and s.name in kw["direct"])
     return L.make_engine(world, tables, device, layout=name, **kw)
 
 

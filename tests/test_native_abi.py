@@ -51,8 +51,36 @@ def test_struct_sizes_match_the_header_layout():
     assert ctypes.sizeof(N.AgentState) == 80
     assert ctypes.sizeof(N.StepIO) == 32
     assert ctypes.sizeof(N.Plan) == 16 + 16 + 72 * N.GJ_MAX_SETS + 5 * 8 + 8 + 8
-    assert ctypes.sizeof(N.TiledSet) == 16 + 10 * 8
+    assert ctypes.sizeof(N.TiledSet) == 16 + 11 * 8
     assert ctypes.sizeof(N.Tiled) == 16 + 8 + 8 + ctypes.sizeof(N.TiledSet) * N.GJ_MAX_SETS
+
+
+def test_ctypes_layout_equals_what_a_c_compiler_sees(tmp_path):
+    """Every struct of include/gradjune_hip.h: sizeof and the offset of every field, as gcc lays them out,
+    against the ctypes mirror in _native.py (a silent mismatch would shift every pointer behind it)."""
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    pairs = {"gj_edge_set": N.EdgeSet, "gj_tiled_set": N.TiledSet, "gj_tiled": N.Tiled, "gj_plan": N.Plan,
+             "gj_network": N.Network, "gj_step_params": N.StepParams, "gj_agent_state": N.AgentState,
+             "gj_step_io": N.StepIO, "gj_symptoms_params": N.SymptomsParams}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void) {"]
+    for cname, ct in pairs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for field, _ in ct._fields_:
+            lines.append(f'  printf("{cname}.{field} %zu\\n", offsetof({cname}, {field}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-o", str(exe), str(src)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, ct in pairs.items():
+        assert int(got[cname]) == ctypes.sizeof(ct), cname
+        for field, _ in ct._fields_:
+            assert int(got[f"{cname}.{field}"]) == getattr(ct, field).offset, f"{cname}.{field}"
 
 
 def test_argument_errors_do_not_need_a_gpu(lib):

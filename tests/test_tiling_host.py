@@ -129,3 +129,78 @@ def test_device_build_equals_numpy_build(A, V, E, sa, svmax, eb, wide):
     e = build_tiled_device("e", torch.zeros(0, dtype=torch.int64), torch.zeros(0, dtype=torch.int64), 0,
                            np.zeros(0, np.float32), 4, 64)
     assert e.n_blocks == 0 and e.n_edges == 0
+
+
+@pytest.mark.parametrize("A,V,E,sa,owned", [(5000, 700, 9000, 512, 5000), (300, 5, 400, 64, 300), (1000, 65534, 1500, 128, 700),
+                                            (64, 1, 64, 64, 64)])
+def test_ell_form_of_pass2(A, V, E, sa, owned):
+    """tiling.build_ell (and its torch twin) + the emulation of phase D's direct form against bincount sums:
+    agents beyond ``owned`` are halo agents and get no row; groups of venues give the same result."""
+    import torch
+
+    from grad_june_amd.tiling import build_ell, direct_columns, direct_eligible, ell_rows, emulate_direct_pass2
+    from grad_june_amd.tiling_device import build_ell_device, ell_degree_max
+
+    rng = np.random.default_rng(A + E)
+    agent = np.concatenate([np.arange(min(A, E)), rng.integers(0, A, max(0, E - A))])    # degree 1 or 2, some 3+
+    rng.shuffle(agent)
+    venue = rng.integers(0, V, len(agent))
+    S_owned = -(-owned // sa)
+    ell3, K = build_ell(agent, venue, owned, S_owned, sa)
+    deg = np.bincount(agent[agent < owned], minlength=owned)
+    assert K == direct_columns(int(deg.max())) and ell3.dtype == np.uint16
+    assert ell3.shape == (max(1, K // 2), S_owned * sa, min(K, 2)) and ell3.flags["C_CONTIGUOUS"]
+    ell = ell_rows(ell3)                       # [rows, K]: plane p holds columns 2p, 2p + 1
+    assert ((ell != 0xFFFF).sum(1)[:owned] == deg).all() and (ell[owned:] == 0xFFFF).all()
+    for a in (0, owned // 2, owned - 1):       # COO order inside a row
+        assert np.array_equal(ell[a][: deg[a]], venue[agent == a])
+    got, Kd = build_ell_device(torch.from_numpy(agent), torch.from_numpy(venue), owned, S_owned, sa)
+    assert Kd == K and np.array_equal(got.numpy().view(np.uint16), ell3)
+    assert ell_degree_max(torch.from_numpy(agent), owned) == (int((agent < owned).sum()), int(deg.max()))
+    cum = rng.random(V).astype(np.float32)
+    ref = np.bincount(agent[agent < owned], weights=cum[venue[agent < owned]].astype(np.float64), minlength=owned)
+    for gv in (None, max(1, V // 3)):
+        acc = emulate_direct_pass2(ell3 if gv else ell, cum, owned, group_venues=gv)
+        assert np.allclose(acc, ref, rtol=1e-5, atol=1e-6)
+    # per-class weights over several networks of one set (leisure)
+    cls = rng.integers(0, 200, A).astype(np.uint8)
+    w = rng.random((3, 200)).astype(np.float32)
+    cum3 = rng.random((V, 3)).astype(np.float32)
+    own = agent < owned
+    ref3 = np.bincount(agent[own], weights=(w[:, cls[agent[own]]].T.astype(np.float64) * cum3[venue[own]]).sum(1),
+                       minlength=owned)
+    assert np.allclose(emulate_direct_pass2(ell, cum3, owned, weights=w, agent_class=cls), ref3, rtol=1e-5, atol=1e-6)
+    assert direct_eligible(V, int(own.sum()), owned, int(deg.max()), 1, sa) == (int(deg.max()) <= 8 and K * owned <= 4 * own.sum())
+    assert not direct_eligible(65535, 10, 10, 1, 1, 64) and not direct_eligible(100, 0, 10, 0, 1, 64)
+    assert not direct_eligible(60000, 10**6, 10**6, 2, 6, 20480)      # 360 k table floats: more than four groups
+    assert direct_eligible(30000, 10**6, 10**6, 2, 1, 20480)
+
+
+def test_compile_plan_chooses_the_direct_form():
+    """compile_plan(direct=None) marks the sets whose sizes allow the direct form (few venues, bounded agent degree);
+    direct=False disables it; naming an ineligible set is an error; the plan round-trips through save / load."""
+    import os
+    import tempfile
+
+    from grad_june_amd.plan import compile_plan, load_plan, save_plan
+    from grad_june_amd.synthetic import make_world
+
+    w = make_world("c3", n_agents=30_000, seed=5)
+    host = compile_plan(w["n_agents"], w["edge_sets"], age=w["age"], sex=w["sex"], layout="tiled")
+    got = {s.name: s.tiled.ell_k for s in host.sets}
+    assert got["household"] in (1, 2, 4, 8) and all(got[n] == 2 for n in ("school", "university", "leisure"))   # tiny world: all fit
+    off = compile_plan(w["n_agents"], w["edge_sets"], age=w["age"], sex=w["sex"], layout="tiled", direct=False)
+    assert all(s.tiled.ell_k == 0 and s.tiled.ell is None for s in off.sets)
+    only = compile_plan(w["n_agents"], w["edge_sets"], age=w["age"], sex=w["sex"], layout="tiled", direct=("school",))
+    assert {s.name for s in only.sets if s.tiled.ell_k} == {"school"}
+    big = dict(w["edge_sets"])
+    big["household"] = dict(big["household"], people=np.ones(70_000, dtype=np.int64))     # > 65534 venues
+    with pytest.raises(ValueError):
+        compile_plan(w["n_agents"], big, age=w["age"], sex=w["sex"], layout="tiled", direct=("household",))
+    auto = compile_plan(w["n_agents"], big, age=w["age"], sex=w["sex"], layout="tiled")
+    assert {s.name: s.tiled.ell_k for s in auto.sets}["household"] == 0
+    with tempfile.TemporaryDirectory() as d:
+        save_plan(host, os.path.join(d, "p.npz"))
+        back = load_plan(os.path.join(d, "p.npz"))
+    for a, b in zip(host.sets, back.sets):
+        assert a.tiled.ell_k == b.tiled.ell_k and np.array_equal(a.tiled.ell, b.tiled.ell)
