@@ -43,8 +43,10 @@ def parse():
     ap.add_argument("--sv-max", type=int, default=None)
     ap.add_argument("--eb-target", type=int, default=None)
     ap.add_argument("--slice-agents", type=int, default=None, help="tiled: agents per slice (multiple of 64)")
-    ap.add_argument("--device-compile", action="store_true",
-                    help="compile the contact graph on the GPU (torch ops) instead of numpy on the host")
+    ap.add_argument("--device-compile", action="store_true", help="(default; kept for old command lines)")
+    ap.add_argument("--host-compile", action="store_true",
+                    help="compile the contact graph with numpy on the host instead of on the GPU (torch ops; the same "
+                         "arrays, ~13 s instead of ~1 s for the default workload)")
     ap.add_argument("--tune", default="auto", choices=["auto", "on", "off"],
                     help="measure candidate tile geometries at set-up and keep the fastest "
                          "(auto: single-GPU worlds of at most 4e7 set-edges, where compiling takes seconds)")
@@ -106,8 +108,8 @@ def kernel_bytes(world, networks):
     from grad_june_amd.synthetic import edge_set_of
 
     A = world["n_agents"]
-    E = {k: len(v["agent"]) for k, v in world["edge_sets"].items()}
-    V = {k: len(v["people"]) for k, v in world["edge_sets"].items()}
+    E = {k: (len(v["agent"]) if "agent" in v else v["n_edges"]) for k, v in world["edge_sets"].items()}
+    V = {k: (len(v["people"]) if "people" in v else v["n_venues"]) for k, v in world["edge_sets"].items()}
     sets = {edge_set_of(n) for n in networks}
     e_sets = sum(E[s] for s in sets)
     e_nets = sum(E[edge_set_of(n)] for n in networks)
@@ -254,12 +256,27 @@ def main():
         if rank == 0:
             print(f"[bench {time.time() - t0:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
-    world = cached_world(args, progress, make_world)
     reorder = args.reorder if args.reorder != "auto" else ("household" if world_size > 1 else "none")
-    if reorder != "none":
-        from grad_june_amd.synthetic import reorder_agents
+    device_compile = not args.host_compile
+    share = rw = None
+    if world_size > 1:
+        # every rank draws the world set by set from the same seeded generator and keeps only ITS share of each set
+        # (no rank ever holds the whole COO, nothing is communicated)
+        from grad_june_amd.distributed import stream_rank_share
+        from grad_june_amd.synthetic import iter_world
 
-        world = reorder_agents(world, by=reorder)
+        rw, share = stream_rank_share(
+            iter_world(args.preset, n_agents=args.agents, seed=args.seed, infected_fraction=args.infected,
+                       edge_mult=args.edge_mult, progress=progress),
+            rank, world_size, reorder=None if reorder == "none" else reorder, progress=progress)
+        world = {"n_agents": share["n_agents"], "networks": share["networks"], "state": share["state"],
+                 "edge_sets": {k: {"n_edges": e, "n_venues": v} for k, (e, v) in share["sizes"].items()}}
+    else:
+        world = cached_world(args, progress, make_world)
+        if reorder != "none":
+            from grad_june_amd.synthetic import reorder_agents
+
+            world = reorder_agents(world, by=reorder)
     networks = world["networks"]
     betas = betas_of(world)
     specs = network_specs(world)
@@ -274,7 +291,9 @@ def main():
             modes = {k: ("partial" if v == "local" and k != "household" else v)
                      for k, v in choose_modes(world, 1).items()}
         runner = DistributedHotPath(world, specs, betas, dev, rank, world_size, seed=args.seed, modes=modes,
-                                    progress=progress, quarantine_threshold=args.quarantine)
+                                    progress=progress, quarantine_threshold=args.quarantine, rank_world=rw,
+                                    total_edges=None if share is None else share["total_edges"],
+                                    device_compile=device_compile)
         extra = {"exchange": {"modes": runner.rw.modes, "halo_agents_rank0": int(runner.rw.n_halo),
                               "halo_bytes_per_step_rank0": runner.halo.bytes_per_step if runner.halo else 0,
                               "partial_sum_floats": int(runner.flat_cum.numel()) if runner.flat_cum is not None else 0}}
@@ -282,7 +301,7 @@ def main():
         from grad_june_amd.benchrun import SingleGpuHotPath
 
         kw = {}
-        if args.device_compile and args.layout == "tiled":
+        if device_compile and args.layout == "tiled":
             kw["device_compile"] = True
         if args.layout == "tiled":
             if args.direct == "off":
@@ -299,7 +318,8 @@ def main():
         if parts > 1 and args.layout == "tiled":
             from grad_june_amd.distributed import PartitionedHotPath
 
-            runner = PartitionedHotPath(world, specs, betas, dev, parts, seed=args.seed, progress=progress)
+            runner = PartitionedHotPath(world, specs, betas, dev, parts, seed=args.seed, progress=progress,
+                                        device_compile=device_compile)
             extra = {"partitions_on_one_gpu": parts}
         else:
             set_edges = sum(len(v["agent"]) for v in world["edge_sets"].values())
@@ -339,10 +359,17 @@ def main():
         for _ in range(args.steps):
             runner.step(timed=True)
         sync()
+    import resource
+
+    peak_rss_mb = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0     # this process: set-up included
+    infected_local = float(runner.state["is_infected"].double().sum())
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed, peak_rss_mb], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, peak_rss_mb = float(t[0].item()), float(t[1].item())
+        t = torch.tensor([infected_local], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        infected_local = float(t.item())
 
     if rank != 0:
         dist.destroy_process_group()
@@ -365,9 +392,7 @@ def main():
                 "includes": "hot path a1-a9 + symptoms kernel (f1) + per-step result reductions (f2)"}
 
     # what the timed steps computed: variants of one kernel must agree on these (tools/ab.py prints them)
-    st_ = runner.state
-    checksum = {"infected": float(st_["is_infected"].double().sum()),
-                "infection_time_sum": float(st_["infection_time"].double().sum())}
+    checksum = {"infected": infected_local}      # summed over the ranks
     if getattr(runner, "stamps", None) is not None:      # GJ_DIAG_STAMPS builds: cycles since workgroup start at marked points
         sa = runner.engine.plan.host.slice_agents
         st = runner.stamps[: (world["n_agents"] // sa) * sa].view(-1, sa)[:, :16].cpu().numpy()
@@ -409,6 +434,7 @@ def main():
                      "algorithmic_bytes_per_launch": kb[dom] * share, "ms_per_launch": kt[dom]},
         "kernel_ms": kt,
         "state_checksum": checksum,
+        "host_peak_rss_mb": peak_rss_mb,     # max over ranks: a rank streams the world and keeps only its share
         "setup_s": {"generate": t_gen, "total": t_setup},
     }
     out.update(extra)

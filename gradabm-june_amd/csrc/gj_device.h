@@ -60,8 +60,11 @@ __device__ __forceinline__ void philox4x32_10(uint64_t ctr_lo, uint64_t ctr_hi, 
   out[3] = c[3];
 }
 
-// 24 random bits -> uniform in (0,1), every value exactly representable, never 0 or 1.
-__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * 5.9604644775390625e-8f; }
+// 23 random bits -> uniform in (0,1): (k + 0.5) * 2^-23 for k < 2^23 is exactly representable in fp32 (24 significant
+// bits), so the result is never 0 or 1 and -log(u) is finite and positive.  (With 24 bits the largest value,
+// 16777215.5, rounds up to 2^24 and the draw becomes exactly 1: an Exponential draw of 0, once per ~1.7e7 draws -
+// about once per step of a 10 M-agent world.)
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 9) + 0.5f) * 1.1920928955078125e-7f; }
 
 // One Philox block serves the agent pair (2k, 2k+1) of GLOBAL agent ids: counter = agent >> 1, the even agent
 // takes words 0-1, the odd one words 2-3 (the integer multiplies of the ten rounds are the expensive part of

@@ -84,61 +84,159 @@ class RankWorld:
         return len(self.halo_global)
 
 
-def build_rank_world(world: dict, rank: int, world_size: int, modes: Optional[Dict[str, str]] = None,
-                     slice_agents: Optional[int] = None, progress=None) -> RankWorld:
-    A = world["n_agents"]
-    bounds = partition_bounds(A, world_size)
-    a0, a1 = int(bounds[rank]), int(bounds[rank + 1])
-    n_local = a1 - a0
-    modes = modes or choose_modes(world, world_size)
-    local_sets, halo_lists, venue_global = {}, [], {}
-    for name, es in world["edge_sets"].items():
-        agent = np.asarray(es["agent"], dtype=np.int64)
-        venue = np.asarray(es["venue"], dtype=np.int64)
-        people = np.asarray(es["people"])
-        mine = (agent >= a0) & (agent < a1)
-        if modes[name] in ("partial", "local"):
-            local_sets[name] = {"agent_global": agent[mine], "venue": venue[mine], "people": people}
-            venue_global[name] = None
+def mode_of(n_edges: int, n_venues: int, world_size: int) -> str:
+    """Exchange mode of ONE edge set from its global sizes (what choose_modes applies to every set)."""
+    if world_size == 1:
+        return "local"
+    return "halo" if n_edges / max(1, n_venues) <= HALO_MAX_MEAN_DEGREE else "partial"
+
+
+class RankPartitioner:
+    """Cuts a world into the parts of one or several ranks, ONE EDGE SET AT A TIME: a set's global COO is needed
+    only while ``add_set`` runs, so a rank never holds more than one set of the whole world (a 10^8-agent world
+    is ~14 GB of COO; ``bench.py --gpus N`` streams it set by set out of the generator) and a single process that
+    wants every rank's part (``PartitionedHotPath``) sorts each set once instead of scanning it once per rank."""
+
+    def __init__(self, n_agents: int, world_size: int, ranks: Optional[Sequence[int]] = None,
+                 modes: Optional[Dict[str, str]] = None):
+        self.n_agents, self.world_size = int(n_agents), int(world_size)
+        self.ranks = list(range(world_size)) if ranks is None else [int(r) for r in ranks]
+        self.bounds = partition_bounds(self.n_agents, self.world_size)
+        self.mode_override = dict(modes or {})
+        self.modes: Dict[str, str] = {}
+        self.local_sets = {r: {} for r in self.ranks}
+        self.halo_lists = {r: [] for r in self.ranks}
+        self.venue_global = {r: {} for r in self.ranks}
+        self.total_edges = 0
+        self.sizes: Dict[str, tuple] = {}          # global (edges, venues) per set
+
+    def add_set(self, name: str, agent, venue, people) -> str:
+        agent = np.asarray(agent, dtype=np.int64).ravel()
+        venue = np.asarray(venue, dtype=np.int64).ravel()
+        people = np.asarray(people)
+        mode = self.mode_override.get(name) or mode_of(len(agent), len(people), self.world_size)
+        self.modes[name] = mode
+        self.total_edges += len(agent)
+        self.sizes[name] = (len(agent), len(people))
+        b = self.bounds
+        if len(self.ranks) > 2:
+            # every rank's own edges with one stable sort by owner (COO order kept inside a rank)
+            owner = np.searchsorted(b, agent, side="right") - 1
+            order = np.argsort(owner, kind="stable")
+            cut = np.searchsorted(owner[order], np.arange(self.world_size + 1))
+            mine_idx = {r: order[cut[r]:cut[r + 1]] for r in self.ranks}
+            del owner, order
         else:
+            mine_idx = {r: np.flatnonzero((agent >= b[r]) & (agent < b[r + 1])) for r in self.ranks}
+        for r in self.ranks:
+            idx = mine_idx[r]
+            if mode in ("partial", "local"):
+                self.local_sets[r][name] = {"agent_global": agent[idx], "venue": venue[idx], "people": people}
+                self.venue_global[r][name] = None
+                continue
             touched = np.zeros(len(people), dtype=bool)
-            touched[venue[mine]] = True
-            keep = touched[venue]                      # every edge of a touched venue, local or remote
+            touched[venue[idx]] = True
+            keep = np.flatnonzero(touched[venue])          # every edge of a touched venue, local or remote, COO order
             vg = np.flatnonzero(touched)
             remap = np.full(len(people), -1, dtype=np.int64)
             remap[vg] = np.arange(len(vg))
-            local_sets[name] = {"agent_global": agent[keep], "venue": remap[venue[keep]], "people": people[vg]}
-            venue_global[name] = vg
-            remote = agent[keep & ~mine]
-            halo_lists.append(np.unique(remote))
-        if progress:
-            progress(f"rank {rank}: partitioned edge set {name} ({modes[name]})")
-    halo_global = np.unique(np.concatenate(halo_lists)) if halo_lists else np.zeros(0, dtype=np.int64)
-    owner = np.searchsorted(bounds, halo_global, side="right") - 1
-    halo_from = np.bincount(owner, minlength=world_size).astype(np.int64)   # sorted ids => grouped by owner
-    if slice_agents is None:
-        _, slice_agents = TL.choose_slices(n_local + len(halo_global))
-    n_local_pad = -(-n_local // slice_agents) * slice_agents if len(halo_global) else n_local
-    n_ext = n_local_pad + len(halo_global)
-    n_slices = max(1, -(-n_ext // slice_agents))
+            ag = agent[keep]
+            self.local_sets[r][name] = {"agent_global": ag, "venue": remap[venue[keep]], "people": people[vg]}
+            self.venue_global[r][name] = vg
+            self.halo_lists[r].append(np.unique(ag[(ag < b[r]) | (ag >= b[r + 1])]))
+        return mode
 
-    def to_ext(g):
-        out = g - a0
-        rem = (g < a0) | (g >= a1)
-        if rem.any():
-            out[rem] = n_local_pad + np.searchsorted(halo_global, g[rem])
+    def finish(self, age, sex, slice_agents: Optional[int] = None) -> Dict[int, "RankWorld"]:
+        age, sex = np.asarray(age), np.asarray(sex)
+        out = {}
+        for r in self.ranks:
+            a0, a1 = int(self.bounds[r]), int(self.bounds[r + 1])
+            n_local = a1 - a0
+            hl = self.halo_lists[r]
+            halo_global = np.unique(np.concatenate(hl)) if hl else np.zeros(0, dtype=np.int64)
+            owner = np.searchsorted(self.bounds, halo_global, side="right") - 1
+            halo_from = np.bincount(owner, minlength=self.world_size).astype(np.int64)   # sorted ids => grouped by owner
+            sa = slice_agents
+            if sa is None:
+                _, sa = TL.choose_slices(n_local + len(halo_global))
+            n_local_pad = -(-n_local // sa) * sa if len(halo_global) else n_local
+            n_ext = n_local_pad + len(halo_global)
+            n_slices = max(1, -(-n_ext // sa))
+            edge_sets = {}
+            for name, ls in self.local_sets[r].items():
+                g = ls.pop("agent_global")
+                ext = g - a0
+                rem = (g < a0) | (g >= a1)
+                if rem.any():
+                    ext[rem] = n_local_pad + np.searchsorted(halo_global, g[rem])
+                edge_sets[name] = {"agent": ext, "venue": ls["venue"], "people": ls["people"]}
+            ext_global = np.zeros(n_ext, dtype=np.int64)
+            ext_global[:n_local] = np.arange(a0, a1)
+            ext_global[n_local_pad:] = halo_global
+            out[r] = RankWorld(r, self.world_size, self.bounds, n_local, sa, n_local_pad, n_ext, n_slices, halo_global,
+                               halo_from, age[ext_global], sex[ext_global], edge_sets, dict(self.modes),
+                               dict(self.venue_global[r]))
+        self.local_sets = self.halo_lists = self.venue_global = None      # consumed
         return out
 
-    edge_sets = {}
-    for name, ls in local_sets.items():
-        edge_sets[name] = {"agent": to_ext(ls["agent_global"].copy()), "venue": ls["venue"], "people": ls["people"]}
-    ext_global = np.zeros(n_ext, dtype=np.int64)
-    ext_global[:n_local] = np.arange(a0, a1)
-    ext_global[n_local_pad:] = halo_global
-    age = np.asarray(world["age"])[ext_global]
-    sex = np.asarray(world["sex"])[ext_global]
-    return RankWorld(rank, world_size, bounds, n_local, slice_agents, n_local_pad, n_ext, n_slices, halo_global,
-                     halo_from, age, sex, edge_sets, modes, venue_global)
+
+def build_rank_worlds(world: dict, world_size: int, ranks: Optional[Sequence[int]] = None,
+                      modes: Optional[Dict[str, str]] = None, slice_agents: Optional[int] = None,
+                      progress=None) -> Dict[int, RankWorld]:
+    """The parts of ``ranks`` (default: all) of a world held in memory."""
+    part = RankPartitioner(world["n_agents"], world_size, ranks, modes)
+    for name, es in world["edge_sets"].items():
+        mode = part.add_set(name, es["agent"], es["venue"], es["people"])
+        if progress:
+            progress(f"partitioned edge set {name} ({mode})")
+    return part.finish(world["age"], world["sex"], slice_agents)
+
+
+def build_rank_world(world: dict, rank: int, world_size: int, modes: Optional[Dict[str, str]] = None,
+                     slice_agents: Optional[int] = None, progress=None) -> RankWorld:
+    return build_rank_worlds(world, world_size, [rank], modes, slice_agents, progress)[rank]
+
+
+def stream_rank_share(pieces, rank: int, world_size: int, reorder: Optional[str] = None,
+                      modes: Optional[Dict[str, str]] = None, progress=None):
+    """One rank's share of a world that arrives piece by piece (``synthetic.iter_world``): every edge set is
+    relabelled (``reorder``: the locality order of ``synthetic.reorder_agents``, defined by the FIRST set streamed),
+    cut down to this rank's part and dropped before the next one is generated.  Returns (RankWorld, share) where
+    share = {"networks", "state" (owned agents only), "n_agents", "total_edges", "sizes", "original_id" (owned)};
+    identical to ``build_rank_world(reorder_agents(make_world(...)), rank, world_size)`` - tested."""
+    from .synthetic import locality_permutation
+
+    part = header = state = None
+    order = new_of = None
+    for piece in pieces:
+        if piece[0] == "header":
+            header = piece[1]
+            part = RankPartitioner(header["n_agents"], world_size, [rank], modes)
+        elif piece[0] == "set":
+            _, name, es = piece
+            agent = es["agent"]
+            if reorder is not None:
+                if order is None:
+                    if name != reorder:
+                        raise ValueError(f"the locality order is defined by set {reorder!r}, which must be streamed first")
+                    order, new_of = locality_permutation(header["n_agents"], es["agent"], es["venue"])
+                agent = new_of[agent]
+            mode = part.add_set(name, agent, es["venue"], es["people"])
+            if progress:
+                progress(f"rank {rank}: kept its part of edge set {name} ({mode})")
+            del es, agent
+        else:
+            state = piece[1]
+    a0, a1 = int(part.bounds[rank]), int(part.bounds[rank + 1])
+    pick = (lambda v: v[a0:a1]) if order is None else (lambda v: v[order[a0:a1]])
+    age = header["age"] if order is None else header["age"][order]
+    sex = header["sex"] if order is None else header["sex"][order]
+    total_edges, sizes = part.total_edges, dict(part.sizes)
+    rw = part.finish(age, sex)[rank]
+    share = {"networks": header["networks"], "state": {k: np.ascontiguousarray(pick(v)) for k, v in state.items()},
+             "n_agents": header["n_agents"], "total_edges": total_edges, "sizes": sizes,
+             "original_id": (np.arange(a0, a1) if order is None else order[a0:a1])}
+    return rw, share
 
 
 class HaloExchange:
@@ -222,7 +320,11 @@ class DistributedHotPath:
     def __init__(self, world: dict, specs, betas: Dict[str, float], device, rank: int, world_size: int,
                  seed: int = 0, group=None, modes: Optional[Dict[str, str]] = None, collectives: bool = True,
                  progress=None, min_group_floats: int = 1 << 16, production_at_one_rank: bool = False,
-                 quarantine_threshold: Optional[float] = None):
+                 quarantine_threshold: Optional[float] = None, rank_world: Optional[RankWorld] = None,
+                 total_edges: Optional[int] = None, device_compile: bool = False):
+        """``world``: the whole world (this rank's part is cut out of it), or - with ``rank_world`` - only
+        {"networks": [...], "state": {name: this rank's OWNED agents' arrays}} next to the prebuilt part and the
+        world's ``total_edges`` (what ``RankPartitioner`` hands over when the world is streamed)."""
         from . import _native as N
         from .benchrun import EventLog
         from .engine import AgentBuffers, InfectionEngine
@@ -230,9 +332,11 @@ class DistributedHotPath:
 
         self.device = torch.device(device)
         self.rank, self.world_size, self.group = rank, world_size, group
-        rw = self.rw = build_rank_world(world, rank, world_size, modes, progress=progress)
+        rw = self.rw = rank_world if rank_world is not None else build_rank_world(world, rank, world_size, modes,
+                                                                                  progress=progress)
         host = compile_plan(rw.n_local, rw.edge_sets, age=rw.age, sex=rw.sex, n_ext_agents=rw.n_ext,
-                            layout="tiled", slices=(rw.n_slices, rw.slice_agents), progress=progress)
+                            layout="tiled", slices=(rw.n_slices, rw.slice_agents), progress=progress,
+                            device=self.device if device_compile else None)
         nets_on = {}
         for sp in specs:
             nets_on[sp.edge_set] = nets_on.get(sp.edge_set, 0) + 1
@@ -241,7 +345,8 @@ class DistributedHotPath:
         # A second all-reduce costs ~45 us of host time per step (tools/host_overhead.py): worth it only while
         # the rank's kernels take several times that, i.e. for shares of >= ~2e7 set-edges (global count / ranks,
         # so every rank takes the same decision)
-        total_edges = sum(len(es["agent"]) for es in world["edge_sets"].values())
+        if total_edges is None:
+            total_edges = sum(len(es["agent"]) for es in world["edge_sets"].values())
         pipelined = total_edges / max(1, world_size) >= PIPELINE_MIN_EDGES or min_group_floats <= 1
         self.reduce_groups = reduce_groups(floats, min_group_floats if pipelined else 1 << 62)
         partial = [n for g in self.reduce_groups for n in g]
@@ -257,7 +362,10 @@ class DistributedHotPath:
         self.networks = list(world["networks"])
         self.betas, self.seed = betas, seed
         a0, a1 = int(rw.bounds[rank]), int(rw.bounds[rank + 1])
-        st = {k: torch.from_numpy(np.ascontiguousarray(v[a0:a1])).to(self.device) for k, v in world["state"].items()}
+        own = (lambda v: v) if rank_world is not None else (lambda v: v[a0:a1])
+        st = {k: torch.from_numpy(np.ascontiguousarray(own(v))).to(self.device) for k, v in world["state"].items()}
+        if any(v.numel() != rw.n_local for v in st.values()):
+            raise ValueError("state arrays must cover exactly this rank's owned agents")
         st["transmission"] = torch.zeros(rw.n_ext, dtype=torch.float32, device=self.device)
         self.q_thr = quarantine_threshold
         # quarantine (quarantine_policies.py:13-33): q * transmission is a second per-agent array of pass 1; its halo
@@ -403,15 +511,21 @@ class PartitionedHotPath:
     Results are identical to the unpartitioned run (fixed-point sums, Philox keyed by global agent id)."""
 
     def __init__(self, world: dict, specs, betas: Dict[str, float], device, parts: int, seed: int = 0,
-                 progress=None):
+                 progress=None, device_compile: bool = False):
         from .benchrun import EventLog
 
         self.device = torch.device(device)
         self.parts = parts
         self.ranks: List[DistributedHotPath] = []
+        rws = build_rank_worlds(world, parts, progress=progress)          # every set sorted once, not scanned per part
+        total_edges = sum(len(es["agent"]) for es in world["edge_sets"].values())
         for r in range(parts):
-            self.ranks.append(DistributedHotPath(world, specs, betas, device, r, parts, seed=seed, collectives=False,
-                                                 progress=progress))
+            rw = rws.pop(r)
+            a0, a1 = int(rw.bounds[r]), int(rw.bounds[r + 1])
+            share = {"networks": world["networks"], "state": {k: v[a0:a1] for k, v in world["state"].items()}}
+            self.ranks.append(DistributedHotPath(share, specs, betas, device, r, parts, seed=seed, collectives=False,
+                                                 progress=None, rank_world=rw, total_edges=total_edges,
+                                                 device_compile=device_compile))
             if progress:
                 progress(f"compiled partition {r + 1}/{parts}")
         self.halo_index = [torch.from_numpy(rk.rw.halo_global).to(self.device) for rk in self.ranks]

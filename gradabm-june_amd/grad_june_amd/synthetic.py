@@ -103,28 +103,120 @@ def _edge_set(rng, n_agents: int, n_edges: int, dist) -> dict:
     return {"agent": agent, "venue": venue, "people": people}
 
 
-def make_world(preset: str = "c3", n_agents: Optional[int] = None, seed: int = 1234,
-               infected_fraction: float = 0.01, sets=None, edge_mult: float = 1.0, progress=None) -> Dict:
-    """Returns {"n_agents", "age", "sex", "edge_sets", "networks", "state"} as numpy arrays."""
+def iter_world(preset: str = "c3", n_agents: Optional[int] = None, seed: int = 1234,
+               infected_fraction: float = 0.01, sets=None, edge_mult: float = 1.0, progress=None):
+    """The world of ``make_world`` piece by piece, in the order the generator draws them:
+        ("header", {"preset", "n_agents", "age", "sex", "networks"})
+        ("set", name, {"agent", "venue", "people"})     once per edge set
+        ("state", {per-agent arrays})
+    A consumer that keeps only its share of every set (distributed.RankPartitioner) never holds the whole COO."""
     spec = PRESETS[preset]
     if n_agents is None:
         n_agents = {"c2": 1_000_000, "c3": 10_000_000, "c5": 100_000_000}[preset]
     rng = np.random.default_rng(seed)
     A = int(n_agents)
-    world = {
-        "preset": preset,
-        "n_agents": A,
-        "age": rng.integers(0, 100, A, dtype=np.int64),
-        "sex": rng.integers(0, 2, A, dtype=np.int64),
-        "edge_sets": {},
-        "networks": list(NETWORKS[preset]),
-    }
+    yield ("header", {"preset": preset, "n_agents": A, "age": rng.integers(0, 100, A, dtype=np.int64),
+                      "sex": rng.integers(0, 2, A, dtype=np.int64), "networks": list(NETWORKS[preset])})
     for name, (per_agent, dist) in spec.items():
         if sets is not None and name not in sets:
             continue
-        world["edge_sets"][name] = _edge_set(rng, A, int(round(per_agent * edge_mult * A)), dist)
+        es = _edge_set(rng, A, int(round(per_agent * edge_mult * A)), dist)
         if progress:
-            progress(f"generated edge set {name}: {len(world['edge_sets'][name]['agent'])} edges")
+            progress(f"generated edge set {name}: {len(es['agent'])} edges")
+        yield ("set", name, es)
+        del es
+    inf = (rng.random(A) < infected_fraction).astype(np.float32)
+    yield ("state", {
+        "max_infectiousness": rng.lognormal(0.0, 0.5, A).astype(np.float32),
+        "shape": rng.normal(1.56, 0.08, A).astype(np.float32),
+        "rate": rng.normal(0.53, 0.03, A).astype(np.float32),
+        "shift": rng.normal(-2.12, 0.1, A).astype(np.float32),
+        "is_infected": inf,
+        "susceptibility": (1.0 - inf).astype(np.float32),
+        "infection_time": (-10.0 * rng.random(A)).astype(np.float32) * inf,
+        "current_stage": np.where(inf > 0, rng.integers(2, 6, A), 1).astype(np.float32),
+    })
+
+
+def make_world(preset: str = "c3", n_agents: Optional[int] = None, seed: int = 1234,
+               infected_fraction: float = 0.01, sets=None, edge_mult: float = 1.0, progress=None) -> Dict:
+    """Returns {"n_agents", "age", "sex", "edge_sets", "networks", "state"} as numpy arrays."""
+    world: Dict = {"edge_sets": {}}
+    for piece in iter_world(preset, n_agents, seed, infected_fraction, sets, edge_mult, progress):
+        if piece[0] == "header":
+            world.update(piece[1])
+        elif piece[0] == "set":
+            world["edge_sets"][piece[1]] = piece[2]
+        else:
+            world["state"] = piece[1]
+    return world
+
+
+def locality_permutation(n_agents: int, agent: np.ndarray, venue: np.ndarray):
+    """(order, new_of) of ``reorder_agents`` from the edge set that defines the locality order."""
+    first = np.full(n_agents, np.iinfo(np.int64).max, dtype=np.int64)
+    np.minimum.at(first, agent, venue)
+    order = np.argsort(first, kind="stable")            # new position -> original id
+    new_of = np.empty(n_agents, dtype=np.int64)
+    new_of[order] = np.arange(n_agents)
+    return order, new_of
+
+
+def make_world_torch(preset: str, n_agents: int, seed: int, device, infected_fraction: float = 0.01) -> Dict:
+    """A world of the same shape as ``make_world``'s, drawn with torch's generator ON ``device`` in seconds (the
+    numpy generator needs minutes for 10^8 edges): the edge lists stay on the device as int64 tensors - what
+    ``compile_plan(device=...)`` takes - and the per-agent arrays come back as numpy.  A different random world than
+    ``make_world(seed)``, with the same distributions (venue sizes, memberships per agent, unsorted COO; the rare
+    duplicate (agent, venue) pairs are kept - the reference's format allows them).  For the large-size property
+    tests, which check the kernels against sums taken from the very same edge lists."""
+    import torch
+
+    dev = torch.device(device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    A = int(n_agents)
+    spec = PRESETS[preset]
+
+    def sizes_for(dist, n_edges):
+        kind = dist[0]
+        if kind == "poisson1":
+            mean = 1.0 + dist[1]
+            draw = lambda m: 1 + torch.poisson(torch.full((m,), float(dist[1]), device=dev), generator=g).to(torch.int64)
+        elif kind == "lognormal":
+            mu, sigma, mean = float(np.log(dist[1]) - 0.5 * dist[2] ** 2), float(dist[2]), dist[1]
+            draw = lambda m: torch.clamp(torch.exp(mu + sigma * torch.randn(m, device=dev, generator=g)), min=1.0).to(torch.int64)
+        else:     # zipf(alpha) truncated to [1, cap]: inverse CDF over the finite support
+            alpha, cap = dist[1], dist[2]
+            pmf = torch.arange(1, cap + 1, device=dev, dtype=torch.float64) ** (-alpha)
+            cdf = torch.cumsum(pmf / pmf.sum(), 0)
+            mean = float((torch.arange(1, cap + 1, device=dev, dtype=torch.float64) * pmf).sum() / pmf.sum())
+            draw = lambda m: 1 + torch.searchsorted(cdf, torch.rand(m, device=dev, dtype=torch.float64, generator=g)).clamp(max=cap - 1)
+        sizes = torch.zeros(0, dtype=torch.int64, device=dev)
+        while int(sizes.sum()) < n_edges:
+            sizes = torch.cat([sizes, draw(int((n_edges - int(sizes.sum())) / mean * 1.05) + 16)])
+        cs = torch.cumsum(sizes, 0)
+        last = int(torch.searchsorted(cs, torch.tensor([n_edges], device=dev), right=False))
+        sizes = sizes[: last + 1].clone()
+        sizes[last] -= cs[last] - n_edges
+        return sizes[sizes > 0]
+
+    world = {"preset": preset, "n_agents": A, "networks": list(NETWORKS[preset]), "edge_sets": {},
+             "age": torch.randint(0, 100, (A,), device=dev, generator=g).cpu().numpy(),
+             "sex": torch.randint(0, 2, (A,), device=dev, generator=g).cpu().numpy()}
+    for name, (per_agent, dist) in spec.items():
+        E = int(round(per_agent * A))
+        sizes = sizes_for(dist, E)
+        V = sizes.numel()
+        venue = torch.repeat_interleave(torch.arange(V, device=dev), sizes)
+        base, extra = divmod(E, A)
+        parts = [torch.arange(A, device=dev).repeat(base)] if base else []
+        if extra:
+            parts.append(torch.randperm(A, device=dev, generator=g)[:extra])
+        agent = torch.cat(parts)[torch.randperm(E, device=dev, generator=g)]       # memberships dealt to venue slots
+        perm = torch.randperm(E, device=dev, generator=g)                           # unsorted COO
+        agent, venue = agent[perm].contiguous(), venue[perm].contiguous()
+        world["edge_sets"][name] = {"agent": agent, "venue": venue, "people": sizes.cpu().numpy()}
+    rng = np.random.default_rng(seed)
     inf = (rng.random(A) < infected_fraction).astype(np.float32)
     world["state"] = {
         "max_infectiousness": rng.lognormal(0.0, 0.5, A).astype(np.float32),
@@ -147,11 +239,7 @@ def reorder_agents(world: Dict, by: str = "household") -> Dict:
     ``world["original_id"]`` maps new -> original agent id (results are reported through it)."""
     A = world["n_agents"]
     es = world["edge_sets"][by]
-    first = np.full(A, np.iinfo(np.int64).max, dtype=np.int64)
-    np.minimum.at(first, es["agent"], es["venue"])
-    order = np.argsort(first, kind="stable")            # new position -> original id
-    new_of = np.empty(A, dtype=np.int64)
-    new_of[order] = np.arange(A)
+    order, new_of = locality_permutation(A, es["agent"], es["venue"])
     out = dict(world)
     out["age"], out["sex"] = world["age"][order], world["sex"][order]
     out["state"] = {k: v[order] for k, v in world["state"].items()}

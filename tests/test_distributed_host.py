@@ -172,3 +172,41 @@ def test_reduce_groups_split_off_the_largest_partial_sum_set():
     assert reduce_groups({"school": 30_000, "company": 750_000, "care_home": 300_000}) == \
         [["company"], ["care_home", "school"]]
     assert reduce_groups({"x": 5, "y": 5}, min_floats=1) == [["x"], ["y"]]               # ties: by name
+
+
+@pytest.mark.parametrize("R,reorder", [(2, None), (3, "household"), (8, "household")])
+def test_streamed_partition_equals_the_in_memory_one(R, reorder):
+    """bench.py --gpus N: every rank generates the world set by set and keeps only its share
+    (distributed.stream_rank_share) - the same RankWorld, array for array, as cutting the part out of the whole
+    (re-ordered) world, and build_rank_worlds (one sort per set for all ranks) equals rank-by-rank scans."""
+    from grad_june_amd.distributed import build_rank_world, build_rank_worlds, stream_rank_share
+    from grad_june_amd.synthetic import iter_world, make_world, reorder_agents
+
+    kw = dict(preset="c3", n_agents=6000, seed=11, infected_fraction=0.1)
+    world = make_world(**kw)
+    if reorder:
+        world = reorder_agents(world, by=reorder)
+    all_at_once = build_rank_worlds(world, R)
+    for rank in range(R):
+        ref = build_rank_world(world, rank, R)
+        rw, share = stream_rank_share(iter_world(**kw), rank, R, reorder=reorder)
+        for got in (rw, all_at_once[rank]):
+            assert (got.n_local, got.n_local_pad, got.n_ext, got.n_slices, got.slice_agents) == \
+                   (ref.n_local, ref.n_local_pad, ref.n_ext, ref.n_slices, ref.slice_agents)
+            assert got.modes == ref.modes and list(got.edge_sets) == list(ref.edge_sets)
+            for k in ("halo_global", "halo_from", "age", "sex", "bounds"):
+                assert np.array_equal(getattr(got, k), getattr(ref, k)), k
+            for name, es in ref.edge_sets.items():
+                for k in ("agent", "venue", "people"):
+                    assert np.array_equal(got.edge_sets[name][k], es[k]), (name, k)
+                vg, vr = got.venue_global[name], ref.venue_global[name]
+                assert (vg is None and vr is None) or np.array_equal(vg, vr)
+        a0, a1 = int(ref.bounds[rank]), int(ref.bounds[rank + 1])
+        for k, v in world["state"].items():
+            assert np.array_equal(share["state"][k], v[a0:a1]), k
+        assert share["total_edges"] == sum(len(es["agent"]) for es in world["edge_sets"].values())
+        assert share["networks"] == world["networks"]
+        if reorder:
+            assert np.array_equal(share["original_id"], world["original_id"][a0:a1])
+    with pytest.raises(ValueError):
+        stream_rank_share(iter_world(**kw), 0, 2, reorder="school")

@@ -7,10 +7,10 @@
   * a random sample of venues / agents against fp64 sums taken straight from the COO edge list
   * run-to-run determinism: bitwise identical outputs
 
-C2 (1 M agents, 15 M edges) always runs; C3 (10 M agents, 120 M network-edges) when GJ_FULL_C3=1.
+C2 (1 M agents, 15 M edges) and C3 (10 M agents, 120 M network-edges: the world bench.py times, same seed) run at
+full size; C4's partitioning runs as 8 agent partitions of that C3 world on the one GPU; C5 (power-law venues up to
+50 000 attendees) at 1 M agents here and at 20 M agents in test_c5_20m_against_fp64_device_sums.
 """
-import os
-
 import numpy as np
 import pytest
 import torch
@@ -21,9 +21,47 @@ from grad_june_amd.synthetic import edge_set_of, make_world
 
 pytestmark = pytest.mark.gpu
 
-# c5 = power-law venue degrees (Zipf alpha 2, venues up to 50 000 attendees), scaled to one test box
-CASES = ([("c2", None)] + ([("c3", None)] if os.environ.get("GJ_FULL_C3") == "1" else [("c3", 2_000_000)])
-         + [("c5", 1_000_000)])
+# c5 = power-law venue degrees (Zipf alpha 2, venues up to 50 000 attendees)
+CASES = [("c2", None), ("c3", None), ("c5", 1_000_000)]
+
+_WORLDS = {}
+
+
+def cached_world(preset, agents, infected=0.03):
+    """The numpy-seeded worlds take ~30 s per 10 M agents to draw: one copy per (preset, size) for the whole module."""
+    key = (preset, agents, infected)
+    if key not in _WORLDS:
+        _WORLDS[key] = make_world(preset, n_agents=agents, seed=1234, infected_fraction=infected)
+    w = _WORLDS[key]
+    return dict(w, state={k: v.copy() for k, v in w["state"].items()})
+
+
+def fp64_device_reference(world, r, betas, device):
+    """Both passes restated with torch fp64 ops on the device, straight from the COO edge lists: per network the
+    venue sums cum_n[v] (base.py:78-79) and per agent ts = susceptibility * sum_n w_n[a] * sum_e cum_n[venue(e)]
+    (base.py:80-83, leisure_network.py:74-85) from the transmissions the kernels wrote."""
+    A = world["n_agents"]
+    x = r.state["transmission"][:A].double()
+    susc = r.state["susceptibility"].double()
+    cls = torch.from_numpy((world["sex"] * 100 + world["age"]).astype(np.int64)).to(device)
+    specs = {s.name: s for s in B.network_specs(world)}
+    tdev = lambda a: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))).to(device)
+    cum, acc = {}, torch.zeros(A, dtype=torch.float64, device=device)
+    for name in world["networks"]:
+        es = world["edge_sets"][edge_set_of(name)]
+        agent, venue = tdev(es["agent"]), tdev(es["venue"])
+        people = tdev(es["people"]).double()
+        pc = torch.clamp(1.0 / (people - 1.0), max=1.0).clamp(min=0.0).float().double()    # fp32 p_contact, as compiled
+        xs = x[agent]
+        w = None
+        if specs[name].table is not None:
+            w = torch.from_numpy(np.asarray(specs[name].table, dtype=np.float32).reshape(2, 200)[0]).to(device).double()[cls]
+            xs = w[agent] * xs
+        sums = torch.zeros(len(es["people"]), dtype=torch.float64, device=device).index_add_(0, venue, xs)
+        cum[name] = float(np.float32(betas[name])) * pc * sums
+        per_agent = torch.zeros(A, dtype=torch.float64, device=device).index_add_(0, agent, cum[name][venue])
+        acc += per_agent if w is None else w * per_agent
+    return cum, susc * acc
 
 
 def run_stages(r, sample=False):
@@ -35,11 +73,12 @@ def run_stages(r, sample=False):
 
 @pytest.mark.parametrize("preset,agents", CASES, ids=[f"{p}-{a or 'full'}" for p, a in CASES])
 def test_fullsize_properties(device, preset, agents):
-    world = make_world(preset, n_agents=agents, seed=1234, infected_fraction=0.03)
+    world = cached_world(preset, agents)
     A = world["n_agents"]
     specs, betas = B.network_specs(world), B.betas_of(world)
     noise = torch.empty(2, A).exponential_(generator=torch.Generator().manual_seed(1)).to(device)
-    tiled = SingleGpuHotPath(world, specs, betas, device, seed=3, layout="tiled", exp_noise=noise)
+    big = A >= 5_000_000           # the graph compiled on the device (bit-identical, test_device_compiled_plan_is_identical)
+    tiled = SingleGpuHotPath(world, specs, betas, device, seed=3, layout="tiled", exp_noise=noise, device_compile=big)
     csr = SingleGpuHotPath(world, specs, betas, device, seed=3, layout="csr", exp_noise=noise)
 
     # -- layouts agree (probabilities), first without touching the state ----------------------------
@@ -49,7 +88,21 @@ def test_fullsize_properties(device, preset, agents):
     assert np.abs(pt - pc).max() <= 2e-6
     assert (pt < 1.0).sum() > 0.5 * A            # the world is actually exposed
 
-    # -- sampled venues / agents against fp64 sums from the COO edge list ---------------------------
+    # -- EVERY venue and agent against fp64 sums taken on the device from the COO edge lists -----------
+    cum64, ts64 = fp64_device_reference(world, tiled, betas, device)
+    per_set = {}
+    for name in world["networks"]:
+        k = per_set.get(edge_set_of(name), 0)
+        per_set[edge_set_of(name)] = k + 1
+        for r in (tiled, csr):
+            got = r.engine.plan.cum_of(edge_set_of(name))[:, k].double()
+            err = (got - cum64[name]).abs() / (cum64[name].abs() + 1e-9)
+            assert float(err.max()) <= 3e-5, (name, r.layout, float(err.max()))
+    p64 = torch.exp(-torch.clamp(ts64, 1e-6, 100.0)).clamp(0.0, 1.0)
+    assert float((tiled.probs.double() - p64).abs().max()) <= 2e-6
+    del cum64, ts64, p64
+
+    # -- sampled venues / agents against fp64 sums from the COO edge list (host) -----------------------
     x = tiled.state["transmission"].cpu().numpy().astype(np.float64)
     rng = np.random.default_rng(0)
     for name in world["networks"]:
@@ -100,7 +153,7 @@ def test_fullsize_properties(device, preset, agents):
     # -- determinism and decisions: a full step twice from the same state ----------------------------
     outs = []
     for rep in range(2):
-        t2 = SingleGpuHotPath(world, specs, betas, device, seed=3, layout="tiled", exp_noise=noise)
+        t2 = SingleGpuHotPath(world, specs, betas, device, seed=3, layout="tiled", exp_noise=noise, device_compile=big)
         t2.step()
         torch.cuda.synchronize()
         outs.append((t2.probs.clone(), t2.new_infected.clone(), t2.state["is_infected"].clone()))
@@ -119,13 +172,90 @@ def test_fullsize_properties(device, preset, agents):
     assert abs(int(dt.sum()) - int(dc.sum())) <= bad.sum()
 
 
+def test_c3_full_size_eight_partitions_equal_unpartitioned(device):
+    """BASELINE.json configs[3]'s partitioning at full size on the one GPU there is: the 10 M-agent C3 world as 8 agent
+    partitions (each exactly a rank of the multi-GPU path: halo agents, partial venue sums; the two collectives become
+    device copies) against the unpartitioned run - bit for bit, over three steps of in-kernel Philox noise."""
+    from grad_june_amd.distributed import PartitionedHotPath
+
+    world = cached_world("c3", None)
+    specs, betas = B.network_specs(world), B.betas_of(world)
+    single = SingleGpuHotPath(world, specs, betas, device, seed=5, layout="tiled", device_compile=True)
+    parted = PartitionedHotPath(world, specs, betas, device, parts=8, seed=5, device_compile=True)
+    assert {m for rk in parted.ranks for m in rk.rw.modes.values()} == {"halo", "partial"}
+    assert sum(rk.rw.n_halo for rk in parted.ranks) > 1_000_000
+    for _ in range(3):
+        single.step()
+        parted.step()
+    torch.cuda.synchronize()
+    for k, v in parted.state.items():
+        assert torch.equal(v, single.state[k]), k
+    got_new = torch.cat([rk.new_infected for rk in parted.ranks])
+    assert torch.equal(got_new, single.new_infected)
+    assert single.state["is_infected"].sum().item() > 0.04 * world["n_agents"]
+
+
+def test_c5_20m_against_fp64_device_sums(device):
+    """BASELINE.json configs[4]'s shape at the largest size one GPU takes as a single partition:
+    20 M agents, power-law venue sizes up to 50 000 attendees (a venue then spans every slice and holds far more edges
+    than a slice has agents: the LDS-overflow / multi-block case).  The world is drawn on the device
+    (synthetic.make_world_torch: the numpy generator needs minutes at this size) and EVERY venue sum and EVERY agent's
+    probability is checked against fp64 sums taken from the same edge lists - in particular every venue with more
+    than 20 480 attendees; plus linearity of pass 1 and run-to-run determinism."""
+    from grad_june_amd.synthetic import make_world_torch
+
+    world = make_world_torch("c5", 20_000_000, seed=1234, device=device, infected_fraction=0.03)
+    A = world["n_agents"]
+    giant = {k: int((v["people"] > 20480).sum()) for k, v in world["edge_sets"].items()}
+    assert all(n >= 10 for n in giant.values()), giant
+    specs, betas = B.network_specs(world), B.betas_of(world)
+    r = SingleGpuHotPath(world, specs, betas, device, seed=3, layout="tiled", device_compile=True)
+    run_stages(r)
+    cum64, ts64 = fp64_device_reference(world, r, betas, device)
+    per_set = {}
+    for name in world["networks"]:
+        es_name = edge_set_of(name)
+        k = per_set.get(es_name, 0)
+        per_set[es_name] = k + 1
+        got = r.engine.plan.cum_of(es_name)[:, k].double()
+        err = (got - cum64[name]).abs() / (cum64[name].abs() + 1e-9)
+        assert float(err.max()) <= 3e-5, (name, float(err.max()))
+        big = torch.from_numpy(world["edge_sets"][es_name]["people"] > 20480).to(device)
+        assert float(err[big].max()) <= 3e-5 and float(cum64[name][big].abs().max()) > 0
+    p64 = torch.exp(-torch.clamp(ts64, 1e-6, 100.0)).clamp(0.0, 1.0)
+    assert float((r.probs.double() - p64).abs().max()) <= 2e-6
+    assert int((r.probs < 1.0).sum()) > 0.5 * A
+    del cum64, ts64, p64
+    # pass 1 is linear, bit for bit (fixed-point sums)
+    before = [r.engine.plan.cum_of(s.name).clone() for s in r.engine.plan.host.sets]
+    r.state["transmission"].mul_(2.0)
+    r.engine.venue_reduce(r.bufs, r.params())
+    torch.cuda.synchronize()
+    for s, b in zip(r.engine.plan.host.sets, before):
+        now = r.engine.plan.cum_of(s.name)
+        assert torch.equal(now, 2.0 * b) if s.name != "leisure" else torch.allclose(now, 2.0 * b, rtol=1e-5, atol=1e-10)
+    del before
+    # a full step twice from the same start: identical
+    start = {k: r.state[k].clone() for k in ("is_infected", "susceptibility", "infection_time")}
+    outs = []
+    for rep in range(2):
+        for k, v in start.items():
+            r.state[k].copy_(v)
+        r.t = 0
+        r.step()
+        torch.cuda.synchronize()
+        outs.append((r.probs.clone(), r.new_infected.clone(), r.state["is_infected"].clone()))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    assert outs[0][1].sum().item() > 1000
+
+
 def test_c2_full_size_against_the_oracle(device):
     """BASELINE.json configs[1] at full size (1 M agents, household/school/company, 15 M edges): one
     whole step on the GPU against the CPU oracle on identical injected noise - per-agent probabilities
     within 1e-5, infection decisions identical away from Gumbel ties, equal infection counts."""
     import gj_oracle as O
 
-    world = make_world("c2", seed=1234, infected_fraction=0.02)
+    world = cached_world("c2", None, infected=0.02)
     A = world["n_agents"]
     specs, betas = B.network_specs(world), B.betas_of(world)
     noise = O.draw_exp_noise(A, generator=torch.Generator().manual_seed(7))

@@ -1,0 +1,120 @@
+"""GPU: the sampler path bench.py times - in-kernel Philox noise and the ratio form of the Gumbel-max decision -
+validated three ways (every golden / oracle comparison injects the reference's noise and so takes the other branch):
+
+  * the decisions of the FUSED step (tiled epilogue with one Philox block per agent pair, CSR epilogue) equal those of
+    the stand-alone gj_sample_infect for the same (seed, step, global agent id) on the probabilities the step wrote,
+    bit for bit, for pair-aligned and odd agent offsets, and both equal an independent numpy restatement of the
+    stream (tests/gj_philox_ref.py, pinned by Random123's known answers) away from float ties;
+  * the number of new infections matches the probabilities: within 5 sigma of sum(1 - p) in every probability decile;
+  * (1-p)*e0 > p*e1 ("ratio" form, Philox mode) and the reference's op sequence (F.gumbel_softmax, infection.py:13-18;
+    injected-noise mode) take the same decision on 10^7 random (p, e0, e1), except within float rounding of a tie.
+"""
+import numpy as np
+import pytest
+import torch
+
+import bench as B
+import gj_philox_ref as P
+from grad_june_amd import _native as N
+from grad_june_amd.benchrun import SingleGpuHotPath
+from grad_june_amd.synthetic import make_world
+
+pytestmark = pytest.mark.gpu
+
+SEED, STEP = 0x1234_5678_9ABC, 41
+
+
+@pytest.fixture(scope="module")
+def c2_world():
+    return make_world("c2", seed=1234, infected_fraction=0.03)
+
+
+def sample_only(probs, device, seed, step, offset, exp_noise=None):
+    out = torch.empty_like(probs)
+    N.check(N.load().gj_sample_infect(probs.numel(), N.ptr(probs), N.ptr(exp_noise), seed, step, offset, 1.0, N.ptr(out),
+                                      None, None, None, N.current_stream()), "gj_sample_infect")
+    torch.cuda.synchronize()
+    return out
+
+
+def ratio_margin(p, e0, e1):
+    """|(1-p) e0 - p e1| relative to the larger side: how far a decision is from a tie."""
+    a, b = (1.0 - p.astype(np.float64)) * e0, p.astype(np.float64) * e1
+    return np.abs(a - b) / np.maximum(np.maximum(a, b), 1e-300)
+
+
+@pytest.mark.parametrize("layout,kw", [("tiled", {}), ("tiled", {"direct": False}), ("csr", {})],
+                         ids=["tiled-direct", "tiled-workspace", "csr"])
+@pytest.mark.parametrize("offset", [0, 1, (1 << 33) + 7], ids=["offset-0", "offset-odd", "offset-2^33+7"])
+def test_fused_philox_decisions_equal_sample_infect(device, c2_world, layout, kw, offset):
+    world = dict(c2_world, state={k: v.copy() for k, v in c2_world["state"].items()})
+    A = world["n_agents"]
+    specs, betas = B.network_specs(world), B.betas_of(world)
+    r = SingleGpuHotPath(world, specs, betas, device, seed=SEED, layout=layout, **kw)
+    p = r.engine.params(now=1.0, delta_time=1.0, day_type=0, active=r.networks, betas=betas, seed=SEED, step=STEP,
+                        agent_offset=offset)
+    before = r.state["is_infected"].clone()
+    r.engine.step(r.bufs, p, r.io)
+    torch.cuda.synchronize()
+    probs, new = r.probs.clone(), r.new_infected.clone()
+    assert set(np.unique(new.cpu().numpy())) <= {0.0, 1.0}
+    alone = sample_only(probs, device, SEED, STEP, offset)
+    assert torch.equal(new, alone), f"{int((new != alone).sum())} decisions differ from gj_sample_infect"
+    assert torch.equal(r.state["is_infected"], before + new)                   # a9 applied to exactly these agents
+    # the stream itself, against the numpy restatement (device logf vs numpy log: ties may fall either way)
+    pn = probs.cpu().numpy()
+    e0, e1 = P.exp_pair(SEED, STEP, offset + np.arange(A, dtype=np.uint64))
+    ref = ((np.float32(1.0) - pn) * e0 > pn * e1)
+    bad = ref != (new.cpu().numpy() > 0.5)
+    assert bad.sum() <= 5 and (ratio_margin(pn, e0, e1)[bad] < 1e-5).all()
+    assert ref.sum() > 1000
+
+    # -- the count follows the probabilities, decile by decile ------------------------------------------------------
+    q = 1.0 - pn.astype(np.float64)                      # P(infected)
+    live = q > 2e-6                                      # above the floor 1 - exp(-1e-6)
+    edges = np.quantile(q[live], np.linspace(0, 1, 11))
+    got = new.cpu().numpy().astype(np.float64)
+    for lo, hi in zip(edges[:-1], edges[1:]):
+        sel = live & (q >= lo) & (q <= hi)
+        mean, var = q[sel].sum(), (q[sel] * (1 - q[sel])).sum()
+        assert abs(got[sel].sum() - mean) <= 5.0 * np.sqrt(var) + 1.0, (lo, hi, got[sel].sum(), mean)
+    tot_var = (q * (1 - q)).sum()
+    assert abs(got.sum() - q.sum()) <= 5.0 * np.sqrt(tot_var) + 1.0
+
+
+def test_ratio_and_gumbel_forms_agree(device):
+    n = 10_000_000
+    g = torch.Generator().manual_seed(5)
+    p = torch.rand(n, generator=g)
+    p[: n // 10] = torch.rand(n // 10, generator=g) * 1e-6                    # nearly certain infection
+    p[n // 10: n // 5] = 1.0 - torch.rand(n // 10, generator=g) * 1e-6        # the floor region the reference sits in
+    p[n // 5: n // 5 + 1000] = 0.0
+    p[n // 5 + 1000: n // 5 + 2000] = 1.0
+    p_dev = p.to(device)
+    ratio = sample_only(p_dev, device, SEED, STEP, 0).cpu().numpy() > 0.5
+    e0, e1 = P.exp_pair(SEED, STEP, np.arange(n, dtype=np.uint64))
+    noise = torch.from_numpy(np.stack([e0, e1])).to(device).contiguous()
+    gumbel = sample_only(p_dev, device, SEED, STEP, 0, exp_noise=noise).cpu().numpy() > 0.5
+    pn = p.numpy()
+    assert not gumbel[pn == 1.0].any() and gumbel[pn == 0.0].all()               # p = 1 never, p = 0 always
+    assert not ratio[pn == 1.0].any() and ratio[pn == 0.0].all()
+    bad = ratio != gumbel
+    # the gumbel form rounds log(p), log(1-p), the two log(e) and a division by tau: a few 1e-7 of the margin
+    assert bad.sum() <= 200 and (ratio_margin(pn, e0, e1)[bad] < 1e-5).all(), (int(bad.sum()), ratio_margin(pn, e0, e1)[bad].max())
+    assert abs(ratio.mean() - (1.0 - pn.astype(np.float64)).mean()) < 1e-3
+
+
+def test_philox_draws_are_never_zero_or_infinite(device):
+    """u01 keeps 23 bits: (k + 0.5) * 2^-23 is exact, so no draw is 0 or 1 (24 bits round the top value up to 1,
+    an Exponential draw of exactly 0 about once per step of a 10 M-agent world, and a NaN in the backward pass).
+    p = 0.5 makes the decision e0 > e1: with a zero draw possible, counts at p -> 1 would show it; here the largest
+    word is checked through the numpy restatement and the device agrees with it on 10^7 draws."""
+    top = P.u01(np.array([0xFFFFFFFF], dtype=np.uint32))[0]
+    assert top < 1.0 and -np.log(top) > 0
+    n = 10_000_000
+    p = torch.full((n,), 0.5, device=device)
+    dec = sample_only(p, device, 99, 7, 0).cpu().numpy() > 0.5
+    e0, e1 = P.exp_pair(99, 7, np.arange(n, dtype=np.uint64))
+    assert (e0 > 0).all() and (e1 > 0).all() and np.isfinite(e0).all() and np.isfinite(e1).all()
+    assert (dec != (e0 > e1)).sum() <= 3
+    assert abs(dec.mean() - 0.5) < 1e-3
