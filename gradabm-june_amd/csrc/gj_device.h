@@ -114,6 +114,15 @@ __device__ __forceinline__ void infect(float nw, float now, float& susc, float& 
   t_inf = t_inf + nw * (now - t_inf);
 }
 
+// a7 (reference base.py:136-140): p = clamp(exp(-clamp(ts, 1e-6, 100) * dt), 0, 1).  torch.clamp passes a NaN
+// through; fminf / fmaxf would swallow it (and turn a poisoned agent into "never infected").
+__device__ __forceinline__ float clamp_keep_nan(float x, float lo, float hi) {
+  return (x != x) ? x : fminf(fmaxf(x, lo), hi);
+}
+__device__ __forceinline__ float not_infected_prob(float ts, float dt) {
+  return clamp_keep_nan(expf(-clamp_keep_nan(ts, 1e-6f, 100.0f) * dt), 0.0f, 1.0f);
+}
+
 __device__ __forceinline__ float sgnf(float x) { return (float)((0.0f < x) - (x < 0.0f)); }
 
 }  // namespace gj

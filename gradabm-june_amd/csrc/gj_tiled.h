@@ -34,19 +34,34 @@ constexpr int kVenueUnrollC = GJ_VENUE_UNROLL_C;  // same, phase C
 // against 4.9 for ds_add_u64 and 7.3 for ds_add_u32, so the per-venue and per-agent sums are kept
 // in 64-bit fixed point: integer adds are order-independent, which also makes both passes bitwise
 // reproducible, and exact (no rounding inside a sum).
-//   pass 1 (sums of transmissions per venue):  2^-40 resolution (9e-13), |sum| < 8.3e6
-//   pass 2 (sums of cum per agent):            2^-36 resolution (1.5e-11), |sum| < 1.3e8
+//   pass 1 (sums of transmissions per venue):  2^-40 resolution (9e-13), |value| <= 2.1e6, |sum| < 8.3e6
+//   pass 2 (sums of cum per agent):            2^-36 resolution (1.5e-11), |value| <= 3.4e7, |sum| < 1.3e8
 typedef unsigned long long fx_t;
 template <int BITS>
-__device__ __forceinline__ fx_t to_fx(float x) {
+__device__ __forceinline__ fx_t to_fx(float x) {      // |x| <= fx_max<BITS>() (fx_add checks)
   constexpr float scale = (float)(1ull << BITS);
-  constexpr float vmax = (float)(1ull << (62 - BITS));
-  x = fminf(fmaxf(x, -vmax), vmax);                   // also maps NaN to -vmax: finite, flagged by tests
   return (fx_t)__float2ll_rn(x * scale);
 }
 template <int BITS>
 __device__ __forceinline__ float from_fx(fx_t v) {
   return (float)((double)(long long)v * (1.0 / (double)(1ull << BITS)));
+}
+// One value may use a quarter of the 64-bit range.  Anything else - NaN, infinities, |x| beyond it - cannot be
+// summed as an integer: it sets the element's bit in `flags` instead and the element reads back as NaN (the
+// reference's scatter_add would give NaN / inf there; a silent clamp would turn a poisoned venue into a number).
+template <int BITS>
+__device__ __forceinline__ constexpr float fx_max() { return (float)(1ull << (61 - BITS)); }
+template <int BITS>
+__device__ __forceinline__ void fx_add(fx_t* sums, uint32_t* flags, int i, float x) {
+  if (fabsf(x) <= fx_max<BITS>()) {
+    atomicAdd(&sums[i], to_fx<BITS>(x));
+  } else {
+    atomicOr(&flags[i >> 5], 1u << (i & 31));
+  }
+}
+template <int BITS>
+__device__ __forceinline__ float fx_read(const fx_t* sums, const uint32_t* flags, int i) {
+  return ((flags[i >> 5] >> (i & 31)) & 1u) ? __builtin_nanf("") : from_fx<BITS>(sums[i]);
 }
 constexpr int kFxVenue = 40, kFxAgent = 36;
 
@@ -238,7 +253,7 @@ __device__ __forceinline__ void scatter_set(const TSetA& T, const float* lds_x, 
 // index / descriptor loads issued behind the current value loads - and 16 instead of 8 chunks per batch both
 // left the kernel at 0.25 ms on C3: it is bound by the ~0.5 KB granularity of the per-tile value reads.)
 template <bool WIDE>
-__device__ __forceinline__ void gather_set(const TSetA& T, fx_t* lds_acc, int s, int wave, int lane) {
+__device__ __forceinline__ void gather_set(const TSetA& T, fx_t* lds_acc, uint32_t* lds_flags, int s, int wave, int lane) {
   const int row = s * T.J;
   const int seg0 = T.tile_sptr[row], seg1 = T.tile_sptr[row + T.J];
   const int c_base = T.chunk_ptr[s];
@@ -261,7 +276,7 @@ __device__ __forceinline__ void gather_set(const TSetA& T, fx_t* lds_acc, int s,
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
       const int i = seg0 + (c0 + u) * kWave + lane;
-      if ((c0 + u < n_chunks) && (i < seg1)) atomicAdd(&lds_acc[la[u]], to_fx<kFxAgent>(v[u]));
+      if ((c0 + u < n_chunks) && (i < seg1)) fx_add<kFxAgent>(lds_acc, lds_flags, la[u], v[u]);
     }
   }
 }
@@ -342,6 +357,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
   fx_t* sums = reinterpret_cast<fx_t*>(lds_s);                    // [nk][nv] fixed-point sums (phase B)
   float* cumf = lds_s;                                            // cum of (k, lv) at float index 2*(k*nv+lv) (phase C)
   float* tabs = lds_s + 2 * (size_t)nk * nv;  // [nk][200] pass-1 tables, then [nk][200] pass-2 weights
+  uint32_t* vflags = reinterpret_cast<uint32_t*>(tabs + (T.leisure ? 2 * nk * 200 : 0));   // one bit per sum: not summable
   if (T.leisure) {
     for (int i = tid; i < nk * 200; i += kTileThreads) {
       const int k = i / 200, c = i % 200;
@@ -356,6 +372,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
   float4* val4 = reinterpret_cast<float4*>(T.val);
   if (B.mode != 2) {
     for (int i = tid; i < nk * nv; i += kTileThreads) sums[i] = 0;
+    for (int i = tid; i < (nk * nv + 31) / 32; i += kTileThreads) vflags[i] = 0u;
     __syncthreads();
     // B: each lane takes 8 consecutive slots (48 bytes), merges runs of one venue in registers and adds
     // each run to the block's LDS sums; kVenueUnroll such groups are loaded before the first is used
@@ -371,12 +388,12 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
           if (lv == cur) {
             acc += x[q];
           } else {
-            if (cur != 0xFFFF) atomicAdd(&sums[cur], to_fx<kFxVenue>(acc));
+            if (cur != 0xFFFF) fx_add<kFxVenue>(sums, vflags, cur, acc);
             cur = lv;
             acc = x[q];
           }
         }
-        if (cur != 0xFFFF) atomicAdd(&sums[cur], to_fx<kFxVenue>(acc));
+        if (cur != 0xFFFF) fx_add<kFxVenue>(sums, vflags, cur, acc);
       } else {
         const uint32_t cw[2] = {craw.x, craw.y};
         for (int k = 0; k < nk; ++k) {
@@ -390,12 +407,12 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
             if (lv == cur) {
               acc += xl;
             } else {
-              if (cur != 0xFFFF) atomicAdd(&sums[k * nv + cur], to_fx<kFxVenue>(acc));
+              if (cur != 0xFFFF) fx_add<kFxVenue>(sums, vflags, k * nv + cur, acc);
               cur = lv;
               acc = xl;
             }
           }
-          if (cur != 0xFFFF) atomicAdd(&sums[k * nv + cur], to_fx<kFxVenue>(acc));
+          if (cur != 0xFFFF) fx_add<kFxVenue>(sums, vflags, k * nv + cur, acc);
         }
       }
     };
@@ -419,7 +436,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
     for (int k = 0; k < nk; ++k) {
       const float beta = T.beta[k];
       for (int lv = tid; lv < nv; lv += kTileThreads) {
-        const float c = (beta * T.v_pc[v0 + lv]) * from_fx<kFxVenue>(sums[k * nv + lv]);
+        const float c = (beta * T.v_pc[v0 + lv]) * fx_read<kFxVenue>(sums, vflags, k * nv + lv);
         T.cum[(int64_t)(v0 + lv) * T.stride + k] = c;
         cumf[2 * (k * nv + lv)] = c;      // low half of the lane's own 8-byte slot
       }
@@ -475,7 +492,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
 // ---- phase D: per slice, accumulate the edges' values per agent in LDS; epilogue a7-a9 -----------
 constexpr int GJ_MAX_DIRECT = 6;
 constexpr int kClassWeightFloats = GJ_MAX_NETS_PER_SET * 200;
-constexpr int kMaxSliceAgents = 20480;
+constexpr int kMaxSliceAgents = 20160;   // 8-byte sums + one flag bit per agent within 160 KiB of LDS
 struct TDirect {          // a set whose pass 2 is taken straight from the venues' cum
   const uint16_t* ell;    // [planes][owned agents, padded to slices][K] venue ids, 0xFFFF = none
   const float* cum;       // [V * stride]
@@ -512,6 +529,7 @@ struct TileDArgs {
   int32_t day_type, transpose;
   const uint8_t* cls;
   const float* tables;
+  const gj_clock* clock;  // non-NULL: now / step are read from device memory (a captured step replayed)
   int32_t _pad2;
   int32_t io_vec4;        // susceptibility and the optional per-agent outputs are 16-byte aligned
 };
@@ -520,12 +538,12 @@ struct TileDArgs {
 __global__ __launch_bounds__(256) void k_tile_epilogue(const TileDArgs D) {
   const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= D.n_agents) return;
+  const float now = D.clock ? D.clock->now : D.now;
+  const uint64_t step = D.clock ? D.clock->step : D.step;
   float susc = D.susceptibility[a];
   float ts = susc * D.acc_scratch[a];
   if (D.trans_susc) D.trans_susc[a] = ts;
-  ts = fminf(fmaxf(ts, 1e-6f), 100.0f);
-  float p = expf(-ts * D.dt);
-  p = fminf(fmaxf(p, 0.0f), 1.0f);
+  const float p = not_infected_prob(ts, D.dt);
   if (D.not_infected_probs) D.not_infected_probs[a] = p;
   if (!D.sample) return;
   float e0, e1;
@@ -533,13 +551,13 @@ __global__ __launch_bounds__(256) void k_tile_epilogue(const TileDArgs D) {
     e0 = D.exp_noise[a];
     e1 = D.exp_noise[D.n_agents + a];
   } else {
-    exp_pair(D.seed, D.step, D.agent_offset + a, e0, e1);
+    exp_pair(D.seed, step, D.agent_offset + a, e0, e1);
   }
   const float nw = D.exp_noise ? gumbel_new_infected(p, e0, e1) : ratio_new_infected(p, e0, e1);
   if (D.new_infected) D.new_infected[a] = nw;
   if (nw != 0.0f) {
     float inf = D.is_infected[a], t_inf = D.infection_time[a];
-    infect(nw, D.now, susc, inf, t_inf);
+    infect(nw, now, susc, inf, t_inf);
     D.susceptibility[a] = susc;
     D.is_infected[a] = inf;
     D.infection_time[a] = t_inf;
@@ -778,7 +796,9 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
   const int s = blockIdx.x;
   const int64_t base = (int64_t)s * D.slice_agents;
   const int n_local = (int)min((int64_t)D.slice_agents, D.n_agents - base);
+  uint32_t* lds_flags = reinterpret_cast<uint32_t*>(lds_acc + D.slice_agents);   // one bit per agent: sum not summable
   for (int i = tid; i < n_local; i += kTileThreads) lds_acc[i] = 0;
+  for (int i = tid; i < D.slice_agents / 32; i += kTileThreads) lds_flags[i] = 0u;
   DirectBatch first;                       // rows of the first direct item: their round trip hides behind the tiled sets
   if (D.n_direct > 0) direct_load(D, D.direct[0], base, n_local, tid, 0, first);
   __syncthreads();
@@ -788,9 +808,9 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
       const TSetA& T = D.sets[t];
       if (!T.active || T.direct || T.raw != pass) continue;
       if (T.wide) {
-        gather_set<true>(T, lds_acc, s, wave, lane);
+        gather_set<true>(T, lds_acc, lds_flags, s, wave, lane);
       } else {
-        gather_set<false>(T, lds_acc, s, wave, lane);
+        gather_set<false>(T, lds_acc, lds_flags, s, wave, lane);
       }
     }
     __syncthreads();
@@ -810,7 +830,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
   for (int m = 0; m < kQ; ++m) {
     const int i0 = 4 * (tid + m * kTileThreads);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[m][j] = (i0 < n_local) ? from_fx<kFxAgent>(lds_acc[i0 + j]) : 0.0f;
+    for (int j = 0; j < 4; ++j) acc[m][j] = (i0 < n_local) ? fx_read<kFxAgent>(lds_acc, lds_flags, i0 + j) : 0.0f;
   }
   if (D.n_direct > 0) {
     uint32_t qmask = 0u;                                  // bit 4m + j: the agent is quarantined
@@ -871,6 +891,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
   GJ_STAMP(4);
   // Epilogue a7-a9, a quad at a time; in Philox mode one block serves an agent pair (two blocks per quad).
   const bool pair_aligned = ((D.agent_offset + base) & 1) == 0;   // local pairs are global pairs (else: per agent)
+  const float now = D.clock ? D.clock->now : D.now;
+  const uint64_t step = D.clock ? D.clock->step : D.step;
   for (int q = tid; 4 * q < n_local; q += kTileThreads) {
     const int i0 = 4 * q;
     const float4 aq = acc4[q], sv = susc4[q];
@@ -881,8 +903,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       ts[j] = susc[j] * accq[j];
-      const float tc = fminf(fmaxf(ts[j], 1e-6f), 100.0f);
-      p[j] = fminf(fmaxf(expf(-tc * D.dt), 0.0f), 1.0f);
+      p[j] = not_infected_prob(ts[j], D.dt);
     }
 #ifndef GJ_DIAG_STAMPS
     if (D.trans_susc) store_quad(D.trans_susc, a0, n_ok, vec, ts);
@@ -894,7 +915,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       uint32_t r[4] = {0u, 0u, 0u, 0u};
-      if (block) philox4x32_10((uint64_t)(D.agent_offset + a0 + 2 * h) >> 1, D.step, D.seed, r);
+      if (block) philox4x32_10((uint64_t)(D.agent_offset + a0 + 2 * h) >> 1, step, D.seed, r);
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
         const int j = 2 * h + g;
@@ -907,7 +928,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
         } else if (block) {
           exp_from_block(r, g, e0, e1);
         } else {
-          exp_pair(D.seed, D.step, D.agent_offset + a0 + j, e0, e1);
+          exp_pair(D.seed, step, D.agent_offset + a0 + j, e0, e1);
         }
         nw[j] = D.exp_noise ? gumbel_new_infected(p[j], e0, e1) : ratio_new_infected(p[j], e0, e1);
       }
@@ -918,7 +939,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
       if (j < n_ok && nw[j] != 0.0f) {
         const int64_t a = a0 + j;
         float sc = susc[j], inf = D.is_infected[a], t_inf = D.infection_time[a];
-        infect(nw[j], D.now, sc, inf, t_inf);
+        infect(nw[j], now, sc, inf, t_inf);
         D.susceptibility[a] = sc;
         D.is_infected[a] = inf;
         D.infection_time[a] = t_inf;

@@ -76,6 +76,7 @@ struct P2Args {
   int32_t day_type, has_q, sample;
   uint64_t seed, step;
   int64_t agent_offset;
+  const gj_clock* clock;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -95,8 +96,9 @@ __device__ __forceinline__ float transmission_value(float mx, float shp, float r
 __global__ __launch_bounds__(kThreads) void k_transmission(
     int64_t n, const float* __restrict__ mx, const float* __restrict__ shp, const float* __restrict__ rt,
     const float* __restrict__ sh, const float* __restrict__ t_inf, const float* __restrict__ inf,
-    const float* __restrict__ stage, float* __restrict__ trans, float* __restrict__ qtrans, float now,
-    int has_q, float q_thr) {
+    const float* __restrict__ stage, float* __restrict__ trans, float* __restrict__ qtrans, float now_arg,
+    int has_q, float q_thr, const gj_clock* __restrict__ clock) {
+  const float now = clock ? clock->now : now_arg;      // device clock: a captured step replayed for later timesteps
   const int64_t n4 = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -339,9 +341,7 @@ __global__ __launch_bounds__(kThreads) void k_agent_gather(const P2Args P) {
     }
   }
   if (P.trans_susc) P.trans_susc[a] = ts;
-  ts = fminf(fmaxf(ts, 1e-6f), 100.0f);
-  float p = expf(-ts * P.dt);
-  p = fminf(fmaxf(p, 0.0f), 1.0f);
+  const float p = not_infected_prob(ts, P.dt);
   if (P.not_infected_probs) P.not_infected_probs[a] = p;
   if (!P.sample) return;
 
@@ -350,13 +350,13 @@ __global__ __launch_bounds__(kThreads) void k_agent_gather(const P2Args P) {
     e0 = P.exp_noise[a];
     e1 = P.exp_noise[P.n_agents + a];
   } else {
-    exp_pair(P.seed, P.step, P.agent_offset + a, e0, e1);
+    exp_pair(P.seed, P.clock ? P.clock->step : P.step, P.agent_offset + a, e0, e1);
   }
   const float nw = P.exp_noise ? gumbel_new_infected(p, e0, e1) : ratio_new_infected(p, e0, e1);
   if (P.new_infected) P.new_infected[a] = nw;
   if (nw != 0.0f) {   // unchanged values are not rewritten
     float inf = P.is_infected[a], t_inf = P.infection_time[a];
-    infect(nw, P.now, susc, inf, t_inf);
+    infect(nw, P.clock ? P.clock->now : P.now, susc, inf, t_inf);
     P.susceptibility[a] = susc;
     P.is_infected[a] = inf;
     P.infection_time[a] = t_inf;
@@ -527,9 +527,7 @@ __global__ __launch_bounds__(kThreads) void k_adjoint_sample(
   const float ac = acc[a];
   const float ts = s0 * ac;
   const bool inside = (ts >= 1e-6f) && (ts <= 100.0f);
-  const float tsc = fminf(fmaxf(ts, 1e-6f), 100.0f);
-  float p = expf(-tsc * dt);
-  p = fminf(fmaxf(p, 0.0f), 1.0f);
+  const float p = not_infected_prob(ts, dt);
   float e0, e1;
   if (noise) {
     e0 = noise[a];
@@ -754,7 +752,7 @@ static int do_transmission(const gj_plan* plan, const gj_agent_state* st, const 
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(k_transmission, dim3((unsigned)blocks), dim3(kThreads), 0, stream, n, st->max_infectiousness,
                      st->shape, st->rate, st->shift, st->infection_time, st->is_infected, st->current_stage,
-                     st->transmission, st->q_transmission, p->now, p->has_quarantine, p->q_threshold);
+                     st->transmission, st->q_transmission, p->now, p->has_quarantine, p->q_threshold, p->clock);
   return launch_status();
 }
 
@@ -863,6 +861,7 @@ static int do_agent_gather(const gj_plan* plan, const gj_agent_state* st, const 
   P.seed = p->seed;
   P.step = p->step;
   P.agent_offset = p->agent_offset;
+  P.clock = p->clock;
   const int64_t blocks = (n + kThreads - 1) / kThreads;
   hipLaunchKernelGGL(k_agent_gather, dim3((unsigned)blocks), dim3(kThreads), 0, stream, P);
   return launch_status();
@@ -873,7 +872,7 @@ static int do_agent_gather(const gj_plan* plan, const gj_agent_state* st, const 
 // ------------------------------------------------------------------------------------------
 static int check_tiled(const gj_plan* plan) {
   const gj_tiled* T = plan->tiled;
-  if (T->n_slices < 1 || T->slice_agents < 64 || T->slice_agents % 64 || T->slice_agents > 20480) return GJ_E_PLAN;
+  if (T->n_slices < 1 || T->slice_agents < 64 || T->slice_agents % 64 || T->slice_agents > kMaxSliceAgents) return GJ_E_PLAN;
   // slices cover owned + halo agents; halo agents start on a slice boundary (phase D runs on the
   // slices of owned agents only)
   if ((int64_t)T->n_slices * T->slice_agents < plan->n_ext_agents) return GJ_E_PLAN;
@@ -927,6 +926,8 @@ static void fill_set_a(const gj_plan* plan, const gj_step_params* p, const Group
 
 // LDS of phases A and D: one slice (fp32 values in A, 64-bit fixed-point sums in D)
 static size_t slice_lds(const gj_tiled* T, size_t elem) { return (size_t)T->slice_agents * elem; }
+// phase D: 64-bit sums + one "not summable" bit per agent
+static size_t agents_lds(const gj_tiled* T) { return (size_t)T->slice_agents * sizeof(fx_t) + (size_t)T->slice_agents / 8; }
 
 static int tiled_scatter(const gj_plan* plan, const gj_agent_state* st, const gj_step_params* p, const Groups& G,
                          hipStream_t stream) {
@@ -983,7 +984,8 @@ static int tiled_venues(const gj_plan* plan, const gj_step_params* p, const Grou
       return GJ_E_PLAN;   // several networks on one set need per-network tables
     }
     const size_t need = (size_t)X.nk * S.max_block_venues * sizeof(fx_t) +
-                        (X.leisure ? 2 * 200 * (size_t)X.nk : 0) * sizeof(float);
+                        (X.leisure ? 2 * 200 * (size_t)X.nk : 0) * sizeof(float) +
+                        ((size_t)X.nk * S.max_block_venues + 31) / 32 * 4;          // one flag bit per sum
     if (X.nk && need > lds) lds = need;
   }
   B.work = T->work;
@@ -1022,8 +1024,9 @@ static int tiled_agents(const gj_plan* plan, const gj_agent_state* st, const gj_
   D.seed = p->seed;
   D.step = p->step;
   D.agent_offset = p->agent_offset;
+  D.clock = p->clock;
   D.acc_scratch = T->agent_scratch;
-  size_t lds = slice_lds(T, sizeof(fx_t));
+  size_t lds = agents_lds(T);
   // direct form of pass 2: the sets whose cum is read from an LDS table behind the slice's (compacted) sums
   D.n_direct = 0;
   D.day_type = p->day_type;
@@ -1105,11 +1108,23 @@ const char* gj_error_string(int code) {
     case GJ_E_NULL: return "required pointer is NULL";
     case GJ_E_RANGE: return "count or index out of range";
     case GJ_E_PLAN: return "inconsistent plan or network list";
-    case GJ_E_NODEVICE: return "no HIP device";
+    case GJ_E_NODEVICE: return "no HIP device, or not a gfx950 (MI355X) device";
     default: break;
   }
   if (code > 0) return hipGetErrorString((hipError_t)code);
   return "unknown error";
+}
+
+int gj_check_device(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return GJ_E_NODEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return GJ_E_NODEVICE;
+  // the code object holds gfx950 (CDNA4, MI355X) kernels only, sized for its 160 KiB of LDS per CU
+  const char* want = "gfx950";
+  for (int i = 0; want[i]; ++i)
+    if (prop.gcnArchName[i] != want[i]) return GJ_E_NODEVICE;
+  return GJ_OK;
 }
 
 int gj_transmission_update(const gj_plan* plan, const gj_agent_state* state, const gj_step_params* params,
@@ -1348,6 +1363,19 @@ int gj_step_phase(const gj_plan* plan, const gj_agent_state* state, const gj_ste
       return gj::tiled_venues(plan, params, G, phase == 7 ? 1 : 0, st);
     default: return GJ_E_RANGE;
   }
+}
+
+namespace gj {
+__global__ void k_clock_advance(gj_clock* clock, float delta_now) {
+  clock->now += delta_now;
+  clock->step += 1;
+}
+}  // namespace gj
+
+int gj_clock_advance(gj_clock* clock, float delta_now, void* stream) {
+  if (!clock) return GJ_E_NULL;
+  hipLaunchKernelGGL(gj::k_clock_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, clock, delta_now);
+  return gj::launch_status();
 }
 
 int gj_pack_f32(int64_t n, const int32_t* index, const float* src, float* out, void* stream) {

@@ -116,6 +116,7 @@ class StepParams(C.Structure):
         ("transpose", C.c_int32),
         ("_pad", C.c_int32),
         ("nets", Network * GJ_MAX_NETS),
+        ("clock", _vp),
     ]
 
 
@@ -169,6 +170,7 @@ class SymptomsParams(C.Structure):
 SYMBOLS = {
     "gj_version": (C.c_int, []),
     "gj_error_string": (C.c_char_p, [C.c_int]),
+    "gj_check_device": (C.c_int, []),
     "gj_transmission_update": (C.c_int, [C.POINTER(Plan), C.POINTER(AgentState), C.POINTER(StepParams), _vp]),
     "gj_quarantine_transmission": (C.c_int, [C.POINTER(Plan), C.POINTER(AgentState), C.POINTER(StepParams), _vp]),
     "gj_venue_reduce": (C.c_int, [C.POINTER(Plan), C.POINTER(AgentState), C.POINTER(StepParams), _vp]),
@@ -200,6 +202,7 @@ SYMBOLS = {
         C.c_int,
         [C.POINTER(Plan), C.POINTER(AgentState), C.POINTER(StepParams), C.POINTER(StepIO), C.c_int, _vp],
     ),
+    "gj_clock_advance": (C.c_int, [_vp, C.c_float, _vp]),
     "gj_pack_f32": (C.c_int, [C.c_int64, _vp, _vp, _vp, _vp]),
     "gj_unpack_f32": (C.c_int, [C.c_int64, _vp, _vp, _vp, _vp]),
     "gj_event_create": (C.c_int, [C.POINTER(_vp)]),

@@ -86,7 +86,29 @@ class SingleGpuHotPath:
                                   betas=self.betas, has_quarantine=has_q,
                                   q_threshold=self.q_thr if has_q else float("inf"), seed=self.seed, step=self.t)
 
+    # ---- one captured step replayed: a single host call per timestep ------------------------------------
+    def capture(self, delta_now: float = 1.0):
+        """Capture the step (clock advance + the launches of gj_step) in a hipGraph; ``step()`` then replays it.
+        The step's scalars that change - ``now`` and the Philox stream id - live in device memory (StepClock)."""
+        from .engine import StepClock
+
+        self.clock = StepClock(self.device)
+        p = self._graph_params = self.params()
+        p.clock = self.clock.ptr
+        self.clock.set(p.now - delta_now, self.t - 1)              # the first replay advances to (now, t)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=side):
+            self.clock.advance(delta_now)
+            self.engine.step(self.bufs, p, self.io)
+        return self.graph
+
     def step(self, timed: bool = False):
+        if getattr(self, "graph", None) is not None and not timed:
+            self.graph.replay()
+            self.t += 1
+            return
         p = self.params()
         e = self.engine
         if not timed:

@@ -43,6 +43,35 @@ class AgentBuffers:
         self.c = c
 
 
+class StepClock:
+    """``gj_clock`` in device memory: the two scalars that change from step to step (``now``, the Philox ``step``).
+    A step captured in a hipGraph with ``params.clock`` set is replayed for the following timesteps: the graph's first
+    node advances the clock (``advance``)."""
+
+    def __init__(self, device):
+        self.lib = N.load()
+        self.buf = torch.zeros(2, dtype=torch.int64, device=device)      # {float now; float pad; uint64 step}
+
+    @property
+    def ptr(self) -> int:
+        return self.buf.data_ptr()
+
+    def set(self, now: float, step: int) -> None:
+        import numpy as np
+
+        host = np.zeros(2, dtype=np.int64)
+        host.view(np.float32)[0] = now
+        host[1] = step
+        self.buf.copy_(torch.from_numpy(host))
+
+    def read(self):
+        host = self.buf.cpu().numpy()
+        return float(host.view("float32")[0]), int(host[1])
+
+    def advance(self, delta_now: float) -> None:
+        N.check(self.lib.gj_clock_advance(self.ptr, float(delta_now), N.current_stream()), "gj_clock_advance")
+
+
 class InfectionEngine:
     def __init__(self, plan: DevicePlan):
         self.lib = N.load()

@@ -75,21 +75,27 @@ class SymptomsSampler:
                     raise NotImplementedError(f"stage-time distribution {type(dist).__name__}: only LogNormal/Normal")
         return p
 
-    def sample_next_stage(self, ages, current_stage, next_stage, time_to_next_stage, time):
+    def sample_next_stage(self, ages, current_stage, next_stage, time_to_next_stage, time, sex=None):
+        """The reference's method (symptoms.py:82-128) on the HIP kernel: agents that are due move to their next stage
+        and draw what follows (``gj_symptoms_update`` with nobody newly infected).  Returns new tensors."""
+        from .world import require_hip
+
+        device = require_hip(current_stage.device)
         n = ages.shape[0]
-        moving = self._get_need_to_transition(current_stage, time_to_next_stage, time)
-        current_stage = current_stage - (current_stage - next_stage) * moving
-        stage_idx = current_stage.long()
-        progresses = torch.bernoulli(self._get_prob_next_symptoms_stage(ages, stage_idx)).to(torch.bool)
-        for i in range(2, len(self.stages) - 1):            # skip recovered, susceptible and dead
-            here = (stage_idx == i) & moving.to(torch.bool)
-            onward = (here & progresses).to(current_stage.dtype)
-            recover = (here & ~progresses).to(current_stage.dtype)
-            next_stage = next_stage + onward
-            time_to_next_stage = time_to_next_stage + self.stage_transition_times[i].rsample((n,)) * onward
-            next_stage = next_stage - next_stage * recover
-            time_to_next_stage = time_to_next_stage + self.recovery_times[i].rsample((n,)) * recover
-        return current_stage, next_stage, time_to_next_stage
+        cur, nxt, due = (t.detach().to(device=device, dtype=torch.float32).contiguous().clone()
+                         for t in (current_stage, next_stage, time_to_next_stage))
+        sexv = torch.zeros(n, dtype=torch.long, device=device) if sex is None else sex.to(device).long()
+        cls = (sexv * 100 + ages.to(device).long()).to(torch.uint8).contiguous()
+        table = self.stage_transition_probabilities.to(device=device, dtype=torch.float32).contiguous()
+        p = self.kernel_params()
+        p.progress = table.data_ptr()
+        p.time = float(time)
+        self._direct_calls = getattr(self, "_direct_calls", 0) + 1
+        p.seed, p.step, p.agent_offset = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, (1 << 62) + self._direct_calls, 0
+        zeros = torch.zeros(n, dtype=torch.float32, device=device)
+        N.check(N.load().gj_symptoms_update(n, N.ptr(cls), N.ptr(zeros), N.ptr(cur), N.ptr(nxt), N.ptr(due), C.byref(p),
+                                            None, None, N.current_stream()), "gj_symptoms_update")
+        return cur, nxt, due
 
 
 class SymptomsUpdater(torch.nn.Module):
@@ -169,24 +175,4 @@ class SymptomsUpdater(torch.nn.Module):
                                             C.byref(p), N.ptr(progresses), N.ptr(dwell), N.current_stream()),
                 "gj_symptoms_update")
         self.used_kernel = True
-        return symptoms
-
-    def forward_torch(self, data, timer, new_infected):
-        """The same state machine as plain device-side torch ops (kept for cross-checking)."""
-        try:
-            symptoms = data["agent"].symptoms
-        except (KeyError, AttributeError):
-            raise KeyError("data must contain the 'agent' key.")
-        for key in ("current_stage", "next_stage", "time_to_next_stage"):
-            if key not in symptoms:
-                raise KeyError("symptoms must contain the 'current_stage', 'next_stage', and "
-                               "'time_to_next_stage' keys.")
-        time = timer.now
-        # newly infected agents: next stage = exposed (2), due now
-        nxt = symptoms["next_stage"] + new_infected * (2.0 - symptoms["next_stage"])
-        due = symptoms["time_to_next_stage"] + new_infected * (time - symptoms["time_to_next_stage"])
-        cur, nxt, due = self.symptoms_sampler.sample_next_stage(
-            ages=data["agent"].age, current_stage=symptoms["current_stage"], next_stage=nxt,
-            time_to_next_stage=due, time=time)
-        symptoms["current_stage"], symptoms["next_stage"], symptoms["time_to_next_stage"] = cur, nxt, due
         return symptoms

@@ -27,7 +27,7 @@ from typing import Optional
 
 import numpy as np
 
-SA_MAX = 20480        # agents per slice: 160 KiB of LDS as 64-bit fixed-point sums (phase D)
+SA_MAX = 20160        # agents per slice: 64-bit fixed-point sums + one flag bit per agent in 160 KiB of LDS (phase D)
 SV_MAX = 8192         # venues per block: 64 KiB of 64-bit sums in phase B, so two blocks share a CU's LDS
                       # (measured: phases B+C 0.27 -> 0.21 ms on C3 against 16384; local venue index is 16-bit)
 EB_TARGET = 131072    # edges per block aimed for (work per workgroup of phases B/C)

@@ -40,7 +40,23 @@ def require_hip(device) -> torch.device:
             f"grad_june_amd computes the infection path on a HIP device only; got device={device}. "
             "There is no CPU or eager-PyTorch fallback (set system.device: cuda:0)."
         )
+    _check_device_once(device)
     return device
+
+
+_DEVICE_OK = set()
+
+
+def _check_device_once(device: torch.device) -> None:
+    """gj_check_device on first use of a device: the library's kernels exist for gfx950 (MI355X) only."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx in _DEVICE_OK:
+        return
+    from . import _native as N
+
+    with torch.cuda.device(idx):
+        N.check(N.load().gj_check_device(), f"gj_check_device (cuda:{idx})")
+    _DEVICE_OK.add(idx)
 
 
 def edge_sets_of(data, set_names: Sequence[str]) -> Dict[str, dict]:

@@ -146,7 +146,7 @@ typedef struct gj_tiled_set {
 
 typedef struct gj_tiled {
   int32_t n_slices;          /* S                                                            */
-  int32_t slice_agents;      /* SA (multiple of 64, <= 20480: one slice of 8-byte sums fits LDS) */
+  int32_t slice_agents;      /* SA (multiple of 64, <= 20160: one slice of 8-byte sums + flag bits fits LDS) */
   int32_t direct_table_floats; /* 0: the direct form of pass 2 stages as many venue values through LDS at once
                                 as fit; > 0: at most this many (tests: forces several groups)   */
   int32_t n_work;            /* entries of `work`                                            */
@@ -191,6 +191,16 @@ typedef struct gj_network {
   int32_t table;       /* index into gj_plan.tables, or -1                                    */
 } gj_network;
 
+/* The two scalars that change from one timestep to the next, in DEVICE memory: with gj_step_params.clock set, the
+ * kernels read `now` and `step` from there instead of from the launch arguments, so a step captured once in a
+ * hipGraph (kernels + the multi-GPU collectives) can be replayed for every following timestep of the same kind
+ * (same networks, betas, duration) - gj_clock_advance is the graph's first node.                              */
+typedef struct gj_clock {
+  float now;      /* timer.now, days                                   */
+  float _pad;
+  uint64_t step;  /* Philox stream id: timestep counter                */
+} gj_clock;
+
 /* Scalars of one timestep.  `nets` MUST be in the reference's accumulation order
  * (activity hierarchy, grad_june/timer.py:14-26,139-157) with the networks of one edge set
  * adjacent; the kernels add the per-network terms in exactly this order.                   */
@@ -209,6 +219,8 @@ typedef struct gj_step_params {
                            aggregation w.r.t. the transmissions (row f3)                      */
   int32_t _pad;
   gj_network nets[GJ_MAX_NETS];
+  const gj_clock* clock; /* device pointer or NULL.  Non-NULL: `now` and `step` above are ignored, the kernels read
+                            them from *clock (see gj_clock)                                                 */
 } gj_step_params;
 
 /* Per-agent state, all device fp32 [n_agents] unless noted.
@@ -229,6 +241,11 @@ typedef struct gj_agent_state {
 
 int gj_version(void);
 const char* gj_error_string(int code);
+
+/* GJ_OK when the CURRENT HIP device can run this library (a gfx950 / MI355X: the kernels are built for that
+ * architecture only and size their workgroups for its 160 KiB of LDS per CU), GJ_E_NODEVICE otherwise.
+ * The host mirror calls it once per process before the first launch (there is no other path to fall back to). */
+int gj_check_device(void);
 
 /* Which optional outputs / inputs the fused step uses. NULL = not wanted / not supplied.  */
 typedef struct gj_step_io {
@@ -366,6 +383,9 @@ int gj_step(const gj_plan* plan, const gj_agent_state* state, const gj_step_para
  * cum between the two; 7 = phases 1 then 5, 8 = phases 1 then 2, in one call.                  */
 int gj_step_phase(const gj_plan* plan, const gj_agent_state* state, const gj_step_params* params,
                   const gj_step_io* io, int phase, void* stream);
+
+/* clock->now += delta_now; clock->step += 1 - one tiny launch on `stream` (the first node of a captured step).   */
+int gj_clock_advance(gj_clock* clock, float delta_now, void* stream);
 
 /* Multi-GPU halo exchange helpers (one process per GPU; the all-to-all itself is issued by
  * the host through torch.distributed/RCCL between the two calls).

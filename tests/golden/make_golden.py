@@ -18,6 +18,8 @@ Files written (data only - no reference source text):
     june769_hot.npz   the same with every log_beta raised by 0.9 (a real epidemic wave)
     synth10k.npz      10k-agent synthetic with degree-0/1 venues, a 5k-agent venue, duplicates
     world769.npz      test/data/data.pkl as neutral arrays (graph + agent attributes)
+    june769_series.npz  the reference Runner's own result series (cases, daily cases, cases by age bin, deaths) over a
+                      90-day run of the shipped world + the per-agent state after every step (row f2)
     grads.npz         d(cases)/d(log_beta) of every network through 4 / 6 timesteps (autograd of the
                       reference), with the noise of every step, on the 100- and 769-agent worlds
     default_params.json   yaml.safe_load(configs/default.yaml) (dates stringified)
@@ -478,7 +480,12 @@ def make_june769(tag="june769", beta_shift=0.0, write_world=True):
         runner.restore_initial_data()
         runner.set_initial_cases()
     out["seed/is_infected"] = data["agent"].is_infected.numpy().copy()
+    out["seed/current_stage"] = data["agent"].symptoms["current_stage"].numpy().astype(np.float32)
     cases = [float(data["agent"].is_infected.sum())]
+    # row f2: the Runner's own per-step reductions (runner.py:158-171, 198-224), taken by the reference's methods on
+    # the state after every recorded step - cases by age bin (OPEN intervals lo < age < hi) and the deaths series
+    by_age = [runner.get_cases_by_age(data).numpy().copy()]
+    runner.store_differentiable_deaths(data)
     recs = []
     while timer.date < timer.final_date:
         next(timer)
@@ -486,8 +493,15 @@ def make_june769(tag="june769", beta_shift=0.0, write_world=True):
         check_oracle(rec, pre, world, tabs)
         recs.append(rec)
         cases.append(float(data["agent"].is_infected.sum()))
+        by_age.append(runner.get_cases_by_age(data).numpy().copy())
+        runner.store_differentiable_deaths(data)
     add_steps(out, recs)
     out["cases_per_timestep"] = np.array(cases, dtype=np.float32)
+    out["series/age_bins"] = runner.age_bins.numpy().astype(np.int64)
+    out["series/cases_by_age"] = np.stack(by_age).astype(np.float32)                     # [T+1, bins]
+    out["series/deaths_per_timestep"] = data["results"]["deaths_per_timestep"].detach().numpy().astype(np.float32)
+    out["series/daily_cases_per_timestep"] = torch.diff(torch.tensor(cases), prepend=torch.tensor([0.0])).numpy()
+    out["series/dead_stage"] = np.int64(model.symptoms_updater.stages_ids[-1])
     print(tag, "cases:", cases)
     save(tag + ".npz", out)
     if not write_world:
@@ -502,6 +516,65 @@ def make_june769(tag="june769", beta_shift=0.0, write_world=True):
     for s in EDGE_SETS:
         w[f"venue_id/{s}"] = np.asarray(data[s]["id"])
     save("world769.npz", w)
+
+
+# ------------------------------------------------------------------------------------------
+# case: june769_series  (row f2: the reference Runner's OWN result series over a long run)
+# ------------------------------------------------------------------------------------------
+class _StateRecorder(torch.nn.Module):
+    """Wraps the reference model inside the reference Runner: same forward, keeps the state after every step."""
+
+    def __init__(self, inner):
+        super().__init__()
+        self.inner = inner
+        self.is_infected, self.current_stage = [], []
+
+    def __getattr__(self, name):
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            return getattr(super().__getattr__("inner"), name)
+
+    def forward(self, data, timer):
+        data = self.inner(data, timer)
+        self.is_infected.append(data["agent"].is_infected.detach().numpy().astype(np.float32).copy())
+        self.current_stage.append(data["agent"].symptoms["current_stage"].detach().numpy().astype(np.float32).copy())
+        return data
+
+
+def make_june769_series():
+    """Runner.forward() of the reference, unmodified (runner.py:151-183), on the shipped world for 90 days with every
+    log_beta raised by 0.9: its results dict (cases_per_timestep, daily_cases_per_timestep, deaths_per_timestep,
+    cases_by_age_18/65/100) next to the per-agent state after every step that those series were reduced from."""
+    params = default_params()
+    params["timer"]["total_days"] = 90
+    for n in params["networks"]:
+        params["networks"][n]["log_beta"] = params["networks"][n]["log_beta"] + 0.9
+    # the default severity table kills ~1 in 10^4 of the infected: make the later stages likely, so that the deaths
+    # series of 769 agents is not identically zero
+    for stage in ("symptomatic", "severe", "critical"):
+        params["symptoms"]["stage_transition_probabilities"][stage] = {"0-100": 0.6}
+    seed_all(7690)
+    runner = Runner.from_parameters(params)
+    rec = _StateRecorder(runner.model)
+    runner.model = rec
+    with torch.no_grad():
+        results, is_inf = runner()
+    # the state the first row was reduced from is gone (the loop has run); rows 1.. have their state recorded
+    out = {"age": runner.data["agent"].age.numpy().astype(np.int64),
+           "sex": runner.data["agent"].sex.numpy().astype(np.int64),
+           "age_bins": runner.age_bins.numpy().astype(np.int64),
+           "dead_stage": np.int64(runner.model.symptoms_updater.stages_ids[-1]),
+           "post/is_infected": np.stack(rec.is_infected), "post/current_stage": np.stack(rec.current_stage),
+           "final/is_infected": is_inf.numpy().astype(np.float32)}
+    for k, v in results.items():
+        if k != "dates":
+            out["results/" + k] = v.detach().numpy().astype(np.float32)
+    out["results/n_dates"] = np.int64(len(results["dates"]))
+    assert out["results/deaths_per_timestep"][-1] > 0, "no deaths in the run: lengthen it"
+    assert len(rec.is_infected) == len(results["dates"]) - 1
+    print("june769_series deaths:", out["results/deaths_per_timestep"][-1], "cases:", out["results/cases_per_timestep"][-1])
+    save("june769_series.npz", out)
 
 
 # ------------------------------------------------------------------------------------------
@@ -823,6 +896,14 @@ def make_grads_symptoms():
 
 if __name__ == "__main__":
     torch.set_num_threads(1)
+    if sys.argv[1:] == ["june769"]:          # only the trajectories of the shipped world
+        make_june769()
+        make_june769("june769_hot", beta_shift=0.9, write_world=False)
+        make_june769_series()
+        sys.exit(0)
+    if sys.argv[1:] == ["series"]:
+        make_june769_series()
+        sys.exit(0)
     make_kat6()
     make_c100()
     make_june769()
@@ -830,4 +911,5 @@ if __name__ == "__main__":
     make_synth10k()
     make_grads()
     make_grads_symptoms()
+    make_june769_series()
     print("all golden cases generated; oracle == reference on every recorded stage")

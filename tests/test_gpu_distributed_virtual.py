@@ -107,7 +107,7 @@ def _two_rank_worker(rank, R, port, out, min_group_floats):
     dist.init_process_group("gloo", rank=rank, world_size=R)
     try:
         device = torch.device("cuda:0")
-        world = make_world("c3", n_agents=30_000, seed=4, infected_fraction=0.05)
+        world = make_world("c3", n_agents=30_001, seed=4, infected_fraction=0.05)       # partitions of unequal size
         specs, betas = B.network_specs(world), B.betas_of(world)
         rk = DistributedHotPath(world, specs, betas, device, rank, R, seed=9, min_group_floats=min_group_floats)
         assert rk.halo.host_staged and rk.halo.active
@@ -116,8 +116,9 @@ def _two_rank_worker(rank, R, port, out, min_group_floats):
             rk.step()
         torch.cuda.synchronize()
         mine = rk.state["is_infected"].cpu()
-        parts = [torch.empty(int(rk.rw.bounds[r + 1] - rk.rw.bounds[r])) for r in range(R)]
-        dist.all_gather(parts, mine) if len({p.numel() for p in parts}) == 1 else None
+        assert mine.numel() == int(rk.rw.bounds[rank + 1] - rk.rw.bounds[rank])
+        parts = [None] * R
+        dist.all_gather_object(parts, mine)          # every rank enters the collective; partitions may differ in size
         if rank == 0:
             single = SingleGpuHotPath(world, specs, betas, device, seed=9, layout="tiled")
             for _ in range(3):
@@ -210,8 +211,6 @@ def _api_worker(rank, R, port, out):
             results, local_inf = runner()
         a0, a1 = runner.model.agent_range
         assert local_inf.shape[0] == a1 - a0
-        parts = [torch.empty(int(runner.model._hp.rw.bounds[r + 1] - runner.model._hp.rw.bounds[r])) for r in range(R)]
-        sizes = {p_.numel() for p_ in parts}
         gathered = [None] * R
         dist.all_gather_object(gathered, local_inf.cpu())
         if rank == 0:

@@ -252,6 +252,65 @@ def test_no_active_network(device, layout):
     assert torch.equal(st["is_infected"], before + new)
 
 
+@pytest.mark.parametrize("poison", ["nan", "inf", "huge"])
+@pytest.mark.parametrize("layout", LAYOUTS, ids=LAYOUT_IDS)
+def test_non_finite_transmissions_propagate(device, layout, poison):
+    """A NaN / infinite / out-of-range infectiousness is not turned into a number: the reference's scatter_add and
+    torch.clamp (base.py:78-83, 136-140) carry it to every co-attendee of the poisoned agent's venues, and so do the
+    kernels - the tiled layout sums in fixed point and flags what it cannot represent (gj_tiled.h fx_add), both
+    epilogues clamp NaN-preservingly.  Everyone else gets exactly the clean run's probability."""
+    import gj_oracle as O
+    from grad_june_amd.engine import AgentBuffers
+
+    npz = L.load_npz("c100.npz")
+    world = L.world_from(npz)
+    rec = L.step_record(npz, "plain_t3/")
+    sc = L.step_scalars(rec)
+    pre = L.pre_state(rec)
+    who = int(torch.nonzero(pre["is_infected"] > 0)[0])
+    bad = {"nan": float("nan"), "inf": float("inf"), "huge": 3e30}[poison]
+    dirty = {k: v.clone() for k, v in pre.items()}
+    dirty["max_infectiousness"][who] = bad
+    noise = torch.from_numpy(rec["exp_noise"])
+    ref_clean = O.hot_path_step(world, pre, exp_noise=noise, **sc)
+    ref = O.hot_path_step(world, dirty, exp_noise=noise, **sc)
+    hit = ~torch.isfinite(ref["not_infected_probs"]) | (ref["not_infected_probs"] != ref_clean["not_infected_probs"])
+    assert 2 <= int(hit.sum()) < 100                      # the agent's co-attendees, not the whole world
+    eng = engine_for(world, None, device, layout)
+    st = L.device_state(dirty, device)
+    p = eng.params(now=sc["now"], delta_time=sc["delta_time"], day_type=sc["day_type"], active=sc["active"],
+                   betas=sc["betas"])
+    bufs = AgentBuffers(eng.plan, max_infectiousness=st["max_infectiousness"], shape=st["shape"], rate=st["rate"],
+                        shift=st["shift"], infection_time=st["infection_time"], is_infected=st["is_infected"],
+                        susceptibility=st["susceptibility"], transmission=st["transmission"])
+    probs = torch.empty(100, device=device)
+    eng.step(bufs, p, eng.io(not_infected_probs=probs, new_infected=torch.empty(100, device=device),
+                             exp_noise=noise.to(device).contiguous()))
+    torch.cuda.synchronize()
+    got = probs.cpu()
+    # everyone who shares a venue with the poisoned agent
+    touched = torch.zeros(100, dtype=torch.bool)
+    for es in world["edge_sets"].values():
+        mine = es["venue"][es["agent"] == who]
+        touched[es["agent"][torch.isin(es["venue"], mine)]] = True
+    assert bool(hit[~touched].sum() == 0) and 2 <= int(touched.sum()) < 100
+    clean = ~touched
+    assert np.abs(got[clean].numpy() - ref_clean["not_infected_probs"][clean].numpy()).max() <= 1e-5
+    want_nan = torch.isnan(ref["not_infected_probs"])
+    if poison == "nan":
+        assert bool(want_nan[hit].all()) and bool(torch.isnan(got[hit]).all())
+    else:
+        # inf / 3e30: the reference saturates (ts -> 100, p = exp(-100)) where the sum stays +inf or finite, and gives NaN
+        # where inf meets a zero factor; the fixed-point path reports every unsummable element as NaN.  Either way the
+        # poisoned agents are set apart from the clean ones - never a plausible probability.
+        g = got[hit]
+        assert bool((torch.isnan(g) | (g <= 1e-30)).all())
+    # co-attendees the reference leaves untouched (susceptibility 0: 0 * 3e30 == 0) may read NaN here (0 * "unsummable")
+    rest = touched & ~hit
+    r = got[rest]
+    assert bool((torch.isnan(r) | ((r - ref_clean["not_infected_probs"][rest]).abs() <= 1e-5)).all())
+
+
 def O_sample(p, noise):
     import gj_oracle as O
 

@@ -293,6 +293,39 @@ def test_hip_backward_matches_reference(device, case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("factor", [1e6, 1e-9, 3e12], ids=["x1e6", "x1e-9", "x3e12"])
+def test_hip_backward_is_linear_in_the_loss_scale(device, factor):
+    """The backward's sparse passes sum in fixed point with scales chosen for the forward's transmissions; the
+    cotangents they carry have whatever size the user's loss has (MSE on case counts: 1e5; a normalised loss: 1e-10).
+    They are renormalised by a power of two on the way in and out, so d(c * loss) == c * d(loss) to fp32 rounding,
+    far outside the fixed-point window - nothing clipped to the window's edge, nothing flushed to zero."""
+    import grad_june_amd as G
+
+    sub, world, tables, names = load_case("g2")
+    model, timer = _model_and_timer(G, "g2", device)
+    data = _hetero(G, sub, world, device)
+    for n in names:
+        net = model.infection_networks.networks[n]
+        net.log_beta = torch.nn.Parameter(net.log_beta.detach().clone())
+    series = []
+    for i in range(int(sub["n_steps"])):
+        s = step_info(sub, i)
+        next(timer)
+        data["agent"].symptoms["current_stage"] = s["stage"].to(device)
+        model.hot_path(data, timer, exp_noise=s["noise"])
+        series.append(data["agent"].is_infected.sum())
+    params = [model.infection_networks.networks[n].log_beta for n in names]
+    loss = torch.stack(series).sum()
+    base = torch.autograd.grad(loss, params, retain_graph=True, allow_unused=True)
+    scaled = torch.autograd.grad(loss * factor, params, retain_graph=True, allow_unused=True)
+    assert any(g is not None and float(g) != 0.0 for g in base)
+    for n, g0, g1 in zip(names, base, scaled):
+        a, b = (0.0 if g0 is None else float(g0)), (0.0 if g1 is None else float(g1))
+        assert np.isfinite(b)
+        assert b == pytest.approx(a * factor, rel=1e-4, abs=1e-6 * factor), (n, a, b)
+
+
+@pytest.mark.gpu
 def test_gradient_is_zero_for_network_not_attended(device):
     """test_model.py:76-143: an agent infected at school carries no gradient to the company network."""
     import grad_june_amd as G

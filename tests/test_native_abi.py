@@ -47,7 +47,7 @@ def test_version_and_error_strings(lib):
 def test_struct_sizes_match_the_header_layout():
     assert ctypes.sizeof(N.EdgeSet) == 72
     assert ctypes.sizeof(N.Network) == 16
-    assert ctypes.sizeof(N.StepParams) == 56 + 16 * N.GJ_MAX_NETS
+    assert ctypes.sizeof(N.StepParams) == 56 + 16 * N.GJ_MAX_NETS + 8
     assert ctypes.sizeof(N.AgentState) == 80
     assert ctypes.sizeof(N.StepIO) == 32
     assert ctypes.sizeof(N.Plan) == 16 + 16 + 72 * N.GJ_MAX_SETS + 5 * 8 + 8 + 8

@@ -114,25 +114,35 @@ def test_kernel_symptoms_statistics(device):
 
 
 @pytest.mark.gpu
-def test_kernel_agrees_with_torch_form(device):
-    """The fused kernel and the plain torch form of the state machine agree in distribution."""
+def test_kernel_agrees_in_distribution_with_the_restatement(device):
+    """The fused kernel with its own (Philox) randomness against the CPU restatement of symptoms.py:82-128 fed
+    torch.bernoulli / rsample draws (oracle/gj_oracle.py:symptoms_update): same share of agents progressing, same mean
+    dwell time.  The reference's SymptomsSampler.sample_next_stage entry point runs on the same kernel."""
     import grad_june_amd as G
+    import gj_oracle as O
 
     torch.manual_seed(3)
     n = 100_000
-    outs = []
-    for mode in ("kernel", "torch"):
-        upd = _updater(device)
-        d = G.HeteroData()
-        d["agent"].age = (torch.arange(n, device=device) % 100)
-        d["agent"].sex = torch.zeros(n, dtype=torch.long, device=device)
-        d["agent"].symptoms = {"current_stage": torch.full((n,), 3.0, device=device),
-                               "next_stage": torch.full((n,), 4.0, device=device),
-                               "time_to_next_stage": torch.zeros(n, device=device)}
-        (upd if mode == "kernel" else upd.forward_torch)(d, _T(2.0), torch.zeros(n, device=device))
-        s = d["agent"].symptoms
-        outs.append(((s["next_stage"] == 5).float().mean().item(), s["time_to_next_stage"].mean().item()))
-    assert abs(outs[0][0] - outs[1][0]) < 0.01 and abs(outs[0][1] - outs[1][1]) / outs[1][1] < 0.03
+    upd = _updater(device)
+    sp = upd.symptoms_sampler
+    age = torch.arange(n) % 100
+    cur0, nxt0, ttn0 = torch.full((n,), 3.0), torch.full((n,), 4.0), torch.zeros(n)
+    # restatement on the CPU: the agents move to stage 4 and draw from its table / distributions
+    table = sp.stage_transition_probabilities.cpu()
+    progresses = torch.bernoulli(table[4, age])
+    dwell = torch.where(progresses > 0, sp.stage_transition_times[4].rsample((n,)).cpu(), sp.recovery_times[4].rsample((n,)).cpu())
+    _, ref_next, ref_ttn = O.symptoms_update(age, cur0, nxt0, ttn0, torch.zeros(n), 2.0, len(sp.stages), progresses, dwell)
+    d = G.HeteroData()
+    d["agent"].age = age.to(device)
+    d["agent"].sex = torch.zeros(n, dtype=torch.long, device=device)
+    d["agent"].symptoms = {"current_stage": cur0.to(device), "next_stage": nxt0.to(device), "time_to_next_stage": ttn0.to(device)}
+    upd(d, _T(2.0), torch.zeros(n, device=device))
+    s = d["agent"].symptoms
+    direct = sp.sample_next_stage(age.to(device), cur0.to(device), nxt0.to(device), ttn0.to(device), 2.0)
+    for got_next, got_ttn in ((s["next_stage"], s["time_to_next_stage"]), (direct[1], direct[2])):
+        assert abs((got_next == 5).float().mean().item() - (ref_next == 5).float().mean().item()) < 0.01
+        assert abs(got_ttn.mean().item() - ref_ttn.mean().item()) / ref_ttn.mean().item() < 0.03
+    assert (direct[0] == 4).all() and (s["current_stage"] == 4).all()
 
 
 @pytest.mark.gpu

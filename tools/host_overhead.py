@@ -38,6 +38,12 @@ def main():
                    world, specs, betas, dev, 0, 1, seed=1, modes=modes, production_at_one_rank=True),
                "distributed(1 rank), production form, two all-reduces": DistributedHotPath(
                    world, specs, betas, dev, 0, 1, seed=1, modes=modes, production_at_one_rank=True, min_group_floats=1)}
+    captured = DistributedHotPath(world, specs, betas, dev, 0, 1, seed=1, modes=modes, production_at_one_rank=True)
+    captured.capture()
+    runners["distributed(1 rank), production form CAPTURED in a hipGraph (kernels + collectives), one replay per step"] = captured
+    single_graph = SingleGpuHotPath(world, specs, betas, dev, seed=1, layout="tiled")
+    single_graph.capture()
+    runners["single, captured"] = single_graph
     for name, r in runners.items():
         for _ in range(20):
             r.step()
