@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--direct", default="auto", choices=["auto", "off"],
                     help="pass 2 of sets with few venues straight from an LDS table of venue values (auto) or, like the "
                          "other sets, through the per-edge workspace (off)")
+    ap.add_argument("--no-events", action="store_true",
+                    help="diagnostic: time the K steps as plain gj_step calls, without HIP events between the launches")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: diagnostic runs with several ranks sharing one GPU (collectives staged through the host)")
     ap.add_argument("--force-distributed", action="store_true",
@@ -69,6 +71,10 @@ def parse():
     ap.add_argument("--world-cache", default=None,
                     help="directory in which generated worlds are kept (.npz) and reloaded from: kernel experiments "
                          "that run bench.py many times on one box skip the ~30 s of generation")
+    ap.add_argument("--high-prevalence", type=float, default=0.3,
+                    help="second, short timed region on the same world re-seeded at this infected fraction (0 = skip): "
+                         "k_transmission skips uninfected agents' parameter lines and phase D rewrites state only where it "
+                         "changes, so the headline state (1 %% infected, SURVEY 8d) is the cheap end")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
     return ap.parse_args()
@@ -175,6 +181,18 @@ def _es(n):
     from grad_june_amd.synthetic import edge_set_of
 
     return edge_set_of(n)
+
+
+def csrc_hash() -> str:
+    """sha256 over the kernel sources and the ABI header (what a PMC profile is valid for)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    paths = sorted(os.path.join(ROOT, "gradabm-june_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "gradabm-june_amd", "csrc")))
+    for path in paths + [os.path.join(ROOT, "include", "gradjune_hip.h")]:
+        with open(path, "rb") as f:
+            h.update(os.path.basename(path).encode() + b"\0" + f.read())
+    return h.hexdigest()
 
 
 def cached_world(args, progress, make_world):
@@ -348,17 +366,27 @@ def main():
     sync()
     runner.reset_timers()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        # one GPU: the step's launches are bracketed by HIP events (on the launch stream) inside the timed
-        # region.  N > 1: the production step overlaps collectives with compute and cannot be bracketed.
-        runner.step(timed=not distributed)
+    # One GPU: launches are bracketed by HIP events (on the launch stream) INSIDE the timed region - on every
+    # `events_every`-th step: an event between two launches costs the GPU ~4 us (measured: 19 us per step of five
+    # events, 3 % of the default workload's step and 10 % of C2's), which the production call (gj_step, no events)
+    # does not pay.  N > 1: the production step overlaps collectives with compute and cannot be bracketed.
+    events_every = 1 if (args.steps < 12 or distributed) else 4
+    if args.no_events:
+        events_every = 1 << 30
+    for i in range(args.steps):
+        runner.step(timed=not distributed and i % events_every == 0)
     sync()
     elapsed = time.perf_counter() - t0
+    if args.no_events and not distributed:
+        for _ in range(args.steps):
+            runner.step(timed=True)
+        sync()
     if distributed:
         # per-launch durations for N > 1: the same K steps again in the sequential, event-bracketed form
         for _ in range(args.steps):
             runner.step(timed=True)
         sync()
+    kt = runner.kernel_ms()          # mean ms per launch over the timed region, HIP events on the launch stream
     import resource
 
     peak_rss_mb = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0     # this process: set-up included
@@ -374,6 +402,32 @@ def main():
     if rank != 0:
         dist.destroy_process_group()
         return
+
+    high = None
+    if not distributed and hasattr(runner, "load_state") and args.high_prevalence > 0:
+        from grad_june_amd.synthetic import epidemic_state
+
+        kept = {k: v.clone() for k, v in runner.state.items()}
+        kept_t = runner.t
+        runner.load_state(epidemic_state(world["n_agents"], args.high_prevalence, args.seed + 1))
+        n_hi = max(10, args.steps // 2)
+        for _ in range(3):
+            runner.step()
+        torch.cuda.synchronize()
+        runner.reset_timers()
+        t0 = time.perf_counter()
+        for _ in range(n_hi):
+            runner.step(timed=True)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        high = {"infected_fraction_at_start": args.high_prevalence, "steps": n_hi, "ms_per_step": 1e3 * el / n_hi,
+                "steps_per_s": n_hi / el, "kernel_ms": runner.kernel_ms(),
+                "infected_fraction_at_end": float(runner.state["is_infected"].clamp(max=1).mean())}
+        for k, v in kept.items():                      # back to the headline run's state for what follows
+            runner.state[k].copy_(v)
+        runner.t = kept_t
+        runner.reset_timers()
+        del kept
 
     full = None
     if not distributed and hasattr(runner, "enable_full_step"):
@@ -402,7 +456,6 @@ def main():
     n_edges = network_edges(world, networks)
     b_step = algorithmic_bytes(world, networks)
     kb = kernel_bytes(world, networks)
-    kt = runner.kernel_ms()          # mean ms per launch, HIP events on the launch stream
     dom = max((k for k in kt if k in kb), key=kt.get)
     share = 1.0 / world_size         # each rank streams its own partition
     achieved = kb[dom] * share / (kt[dom] * 1e-3) / 1e9
@@ -433,6 +486,7 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": kb[dom] * share, "ms_per_launch": kt[dom]},
         "kernel_ms": kt,
+        "kernel_ms_method": f"HIP events around every launch of every {events_every}th step of the timed region",
         "state_checksum": checksum,
         "host_peak_rss_mb": peak_rss_mb,     # max over ranks: a rank streams the world and keeps only its share
         "setup_s": {"generate": t_gen, "total": t_setup},
@@ -440,14 +494,22 @@ def main():
     out.update(extra)
     if full:
         out["full_step"] = full
-    # HBM traffic of the dominant kernel from the committed PMC profile of this exact workload
+    if high:
+        out["high_prevalence"] = high
+    # HBM traffic of the dominant kernel from the committed PMC profile of this exact workload AND these exact kernel
+    # sources (tools/pmc_traffic.py stamps the profile with a hash of csrc/ + the ABI header): a profile of other
+    # kernels is not reported
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pmc = json.load(f)
         w = pmc["workload"]
-        if (w["preset"], w["n_agents"], w["layout"]) == (args.preset, world["n_agents"], args.layout) and world_size == 1:
+        same_workload = (w["preset"], w["n_agents"], w["layout"]) == (args.preset, world["n_agents"], args.layout)
+        if same_workload and world_size == 1 and pmc.get("csrc_sha256") == csrc_hash():
             out["roofline"]["traffic"] = pmc["per_launch_bytes"][dom]["total"]
-            out["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE)"
+            out["roofline"]["traffic_source"] = ("profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, "
+                                                 "kernel sources " + pmc["csrc_sha256"][:12] + ")")
+        elif same_workload and world_size == 1:
+            out["roofline"]["traffic_source"] = "none: profiles/pmc_traffic.json was taken with other kernel sources"
     except (OSError, KeyError):
         pass
     if not args.no_cpu_baseline and world_size == 1:

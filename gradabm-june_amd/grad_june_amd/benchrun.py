@@ -80,6 +80,13 @@ class SingleGpuHotPath:
         self.t = 0
         self.log = EventLog()
 
+    def load_state(self, state: Dict[str, np.ndarray]) -> None:
+        """Overwrite the per-agent arrays in place (same world, another epidemic state) and restart the clock."""
+        for k, v in state.items():
+            self.state[k].copy_(torch.from_numpy(np.ascontiguousarray(v)))
+        self.state["transmission"].zero_()
+        self.t = 0
+
     def params(self):
         has_q = self.q_thr is not None
         return self.engine.params(now=1.0 + self.t, delta_time=1.0, day_type=0, active=self.networks,

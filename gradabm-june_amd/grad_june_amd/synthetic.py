@@ -138,6 +138,24 @@ def iter_world(preset: str = "c3", n_agents: Optional[int] = None, seed: int = 1
     })
 
 
+def epidemic_state(n_agents: int, infected_fraction: float, seed: int) -> Dict:
+    """Per-agent infection parameters and state at a given prevalence (a stream of its own: bench.py's second timed
+    region re-seeds the SAME world at 30 % infected, where the transmission profile and the state updates cost most)."""
+    rng = np.random.default_rng(seed)
+    A = int(n_agents)
+    inf = (rng.random(A) < infected_fraction).astype(np.float32)
+    return {
+        "max_infectiousness": rng.lognormal(0.0, 0.5, A).astype(np.float32),
+        "shape": rng.normal(1.56, 0.08, A).astype(np.float32),
+        "rate": rng.normal(0.53, 0.03, A).astype(np.float32),
+        "shift": rng.normal(-2.12, 0.1, A).astype(np.float32),
+        "is_infected": inf,
+        "susceptibility": (1.0 - inf).astype(np.float32),
+        "infection_time": (-10.0 * rng.random(A)).astype(np.float32) * inf,
+        "current_stage": np.where(inf > 0, rng.integers(2, 6, A), 1).astype(np.float32),
+    }
+
+
 def make_world(preset: str = "c3", n_agents: Optional[int] = None, seed: int = 1234,
                infected_fraction: float = 0.01, sets=None, edge_mult: float = 1.0, progress=None) -> Dict:
     """Returns {"n_agents", "age", "sex", "edge_sets", "networks", "state"} as numpy arrays."""

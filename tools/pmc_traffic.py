@@ -54,7 +54,11 @@ def main():
             vals = [v for kk, _, v, _ in rows if kk == k][-8:]           # the timed steps (after warm-up)
             if vals:
                 per.setdefault(name, {})[counter] = sum(vals) / len(vals) * 1024.0
+    sys.path.insert(0, ROOT)
+    import bench
+
     out = {"workload": {"preset": "c3", "n_agents": n_agents, "layout": "tiled"},
+           "csrc_sha256": bench.csrc_hash(),       # bench.py reports this traffic only for the same kernel sources
            "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), mean over the last "
                      "8 dispatches; bytes = KiB*1024; FETCH_SIZE doubled (gfx950 reports 1/2 of streamed reads, "
                      "MI355X_MICROARCH.md HBM section; checked against k_transmission's known 24 B/agent of reads)",
