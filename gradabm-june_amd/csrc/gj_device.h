@@ -69,9 +69,14 @@ __device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 9) + 0.5
 // One Philox block serves the agent pair (2k, 2k+1) of GLOBAL agent ids: counter = agent >> 1, the even agent
 // takes words 0-1, the odd one words 2-3 (the integer multiplies of the ten rounds are the expensive part of
 // the sampler; the fused tiled epilogue computes one block per pair, every other caller one per agent).
+#ifndef GJ_PRECISE_DRAW_LOG
+#define GJ_DRAW_LOG __logf        // v_log_f32 * ln 2: the draws feed a comparison and a softmax, not a parity check
+#else
+#define GJ_DRAW_LOG logf
+#endif
 __device__ __forceinline__ void exp_from_block(const uint32_t (&r)[4], int half, float& e0, float& e1) {
-  e0 = -logf(u01(half ? r[2] : r[0]));
-  e1 = -logf(u01(half ? r[3] : r[1]));
+  e0 = -GJ_DRAW_LOG(u01(half ? r[2] : r[0]));
+  e1 = -GJ_DRAW_LOG(u01(half ? r[3] : r[1]));
 }
 __device__ __forceinline__ void exp_pair(uint64_t seed, uint64_t step, int64_t agent, float& e0, float& e1) {
   uint32_t r[4];
@@ -99,12 +104,15 @@ __device__ __forceinline__ float gumbel_new_infected(float p, float e0, float e1
 }
 
 // The same decision when the noise is the library's own Philox stream (no reference draw to reproduce):
-// argmax of the two Gumbel-perturbed logits, log(1-p) - log(e1) > log(p) - log(e0), is (1-p)*e0 > p*e1 -
-// a monotone transform, so the same (e0, e1) give the same outcome (up to rounding at exact ties) at a third
-// of the transcendental work.  p = 1 never infects, p = 0 always does, as in the reference.  The backward
-// pass (k_adjoint_sample) replays this rule from the same draws.
+// argmax of the two Gumbel-perturbed logits, log(1-p) - log(e1) > log(p) - log(e0), is (1-p)*e0 > p*e1, i.e.
+// p < e0 / (e0 + e1) - a monotone transform, so the same (e0, e1) give the same outcome (up to rounding at exact
+// ties) at a third of the transcendental work.  The threshold depends on the draws only (it is Uniform(0,1)), so the
+// fused epilogue computes it while the agents' data are still on their way.  p = 1 never infects, p = 0 always
+// does, as in the reference (e0, e1 > 0 are finite: u01).  The backward pass (k_adjoint_sample) replays this rule
+// from the same draws.
+__device__ __forceinline__ float infection_threshold(float e0, float e1) { return e0 / (e0 + e1); }
 __device__ __forceinline__ float ratio_new_infected(float p, float e0, float e1) {
-  return ((1.0f - p) * e0 > p * e1) ? 1.0f : 0.0f;
+  return (p < infection_threshold(e0, e1)) ? 1.0f : 0.0f;
 }
 
 // a9: GradJune.infect_people (reference grad_june/model.py:103-110)

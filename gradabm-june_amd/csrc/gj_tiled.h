@@ -252,13 +252,16 @@ __device__ __forceinline__ void scatter_set(const TSetA& T, const float* lds_x, 
 // Phase D's inner loop for one set.  (Measured, not adopted: software-pipelining this loop - the next batch's
 // index / descriptor loads issued behind the current value loads - and 16 instead of 8 chunks per batch both
 // left the kernel at 0.25 ms on C3: it is bound by the ~0.5 KB granularity of the per-tile value reads.)
+#ifndef GJ_UNROLL_D_NARROW
+#define GJ_UNROLL_D_NARROW 8       // chunks in flight per wave on sets with 16-byte descriptors (16: 8 % slower, registers)
+#endif
 template <bool WIDE>
 __device__ __forceinline__ void gather_set(const TSetA& T, fx_t* lds_acc, uint32_t* lds_flags, int s, int wave, int lane) {
   const int row = s * T.J;
   const int seg0 = T.tile_sptr[row], seg1 = T.tile_sptr[row + T.J];
   const int c_base = T.chunk_ptr[s];
   const int n_chunks = T.chunk_ptr[s + 1] - c_base;
-  constexpr int kU = kUnroll;
+  constexpr int kU = WIDE ? kUnroll : GJ_UNROLL_D_NARROW;
   for (int c0 = wave * kU; c0 < n_chunks; c0 += kTileWaves * kU) {
     int la[kU], slot[kU];
     float v[kU];
@@ -571,7 +574,8 @@ __global__ __launch_bounds__(256) void k_tile_epilogue(const TileDArgs D) {
 // one dword and its sums one 16-byte LDS access.  A lane's quads are loaded in batches that fit its registers (K <= 2:
 // all of the slice's at once, BEFORE the table is staged, so that the two latencies overlap and a set with several
 // venue groups reads its rows once).
-constexpr int kQuadsPerLane = kMaxSliceAgents / (4 * kTileThreads);   // 5
+constexpr int kQuadsPerLane = (kMaxSliceAgents + 4 * kTileThreads - 1) / (4 * kTileThreads);   // 5
+static_assert(kQuadsPerLane * 4 * kTileThreads >= kMaxSliceAgents, "a lane's quads must cover the largest slice");
 
 struct DirectBatch {            // a lane's five quads of one set and plane
   uint32_t w[kQuadsPerLane][4]; // quad's ELL rows: agent j, column c = half-word 2 * j + c
@@ -829,8 +833,17 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
 #pragma unroll
   for (int m = 0; m < kQ; ++m) {
     const int i0 = 4 * (tid + m * kTileThreads);
+    // (the quad's four "not summable" bits sit in one word: i0 is a multiple of 4)
+    const int iq = min(i0, D.slice_agents - 4);           // unconditional, clamped LDS reads (the whole quad is in LDS)
+    const uint32_t bad = (lds_flags[iq >> 5] >> (iq & 31)) & 0xFu;
+    fx_t raw[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[m][j] = (i0 < n_local) ? fx_read<kFxAgent>(lds_acc, lds_flags, i0 + j) : 0.0f;
+    for (int j = 0; j < 4; ++j) raw[j] = lds_acc[iq + j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float v = from_fx<kFxAgent>(raw[j]);
+      acc[m][j] = (i0 < n_local) ? (((bad >> j) & 1u) ? __builtin_nanf("") : v) : 0.0f;
+    }
   }
   if (D.n_direct > 0) {
     uint32_t qmask = 0u;                                  // bit 4m + j: the agent is quarantined
@@ -866,83 +879,143 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
     }
     return;
   }
-  // The sums go back to LDS as fp32, next to the slice's susceptibilities (a lane reads back only what it wrote: no
-  // barrier after the stores): ALL of a lane's susceptibility loads are issued together - one memory round trip, not
-  // one per quad - and the epilogue is a rolled loop with four agents' worth of registers.
-  float4* acc4 = reinterpret_cast<float4*>(lds_acc);
-  float4* susc4 = acc4 + D.slice_agents / 4;
+  // Epilogue a7-a9.  ALL of a lane's susceptibility loads are issued together (one memory round trip, not one per
+  // quad) and, while they are in flight, the lane draws its agents' infection thresholds (Philox: the epilogue's
+  // arithmetic, and independent of the data).  ts = susceptibility * sum and the thresholds then go to LDS (a lane
+  // reads back only what it wrote), so that the final loop is rolled and short.  (Measured, not adopted: loading the
+  // susceptibilities at kernel start - the 20 registers held through the tiled phase cost it more than the epilogue wins.)
+  const float now = D.clock ? D.clock->now : D.now;
+  const uint64_t step = D.clock ? D.clock->step : D.step;
+  const bool own_noise = D.sample && !D.exp_noise;
+  float4* ts4 = reinterpret_cast<float4*>(lds_acc);
+  float4* th4 = ts4 + D.slice_agents / 4;
   {
-    float sq[kQ][4];
+    float sq[kQ][4], th[kQ][4];
 #pragma unroll
     for (int m = 0; m < kQ; ++m) {
       const int i0 = 4 * (tid + m * kTileThreads);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sq[m][j] = th[m][j] = 0.0f;
       if (i0 < n_local) load_quad(D.susceptibility, base + i0, n_local - i0, vec, sq[m]);
+    }
+    if (own_noise) {
+      // one Philox block serves the GLOBAL agent pair (2k, 2k+1): a quad that starts on an even global id takes two
+      // blocks, one that starts on an odd id three (wave-uniform: base is even)
+      const bool odd = ((D.agent_offset + base) & 1) != 0;
+#pragma unroll
+      for (int m = 0; m < kQ; ++m) {
+        const int i0 = 4 * (tid + m * kTileThreads);
+        if (i0 >= n_local) continue;
+        const uint64_t g0 = (uint64_t)(D.agent_offset + base + i0);
+        uint32_t r0[4], r1[4], r2[4] = {0u, 0u, 0u, 0u};
+        philox4x32_10(g0 >> 1, step, D.seed, r0);
+        philox4x32_10((g0 >> 1) + 1, step, D.seed, r1);
+        if (odd) philox4x32_10((g0 >> 1) + 2, step, D.seed, r2);
+        float e0, e1;
+        if (!odd) {
+          exp_from_block(r0, 0, e0, e1);
+          th[m][0] = infection_threshold(e0, e1);
+          exp_from_block(r0, 1, e0, e1);
+          th[m][1] = infection_threshold(e0, e1);
+          exp_from_block(r1, 0, e0, e1);
+          th[m][2] = infection_threshold(e0, e1);
+          exp_from_block(r1, 1, e0, e1);
+          th[m][3] = infection_threshold(e0, e1);
+        } else {
+          exp_from_block(r0, 1, e0, e1);
+          th[m][0] = infection_threshold(e0, e1);
+          exp_from_block(r1, 0, e0, e1);
+          th[m][1] = infection_threshold(e0, e1);
+          exp_from_block(r1, 1, e0, e1);
+          th[m][2] = infection_threshold(e0, e1);
+          exp_from_block(r2, 0, e0, e1);
+          th[m][3] = infection_threshold(e0, e1);
+        }
+      }
     }
     __syncthreads();          // every lane has its sums in registers, the last venue table has been read by every wave
 #pragma unroll
     for (int m = 0; m < kQ; ++m) {
       const int q = tid + m * kTileThreads;
       if (4 * q < n_local) {
-        acc4[q] = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
-        susc4[q] = make_float4(sq[m][0], sq[m][1], sq[m][2], sq[m][3]);
+        ts4[q] = make_float4(sq[m][0] * acc[m][0], sq[m][1] * acc[m][1], sq[m][2] * acc[m][2], sq[m][3] * acc[m][3]);
+        th4[q] = make_float4(th[m][0], th[m][1], th[m][2], th[m][3]);
       }
     }
   }
   GJ_STAMP(4);
-  // Epilogue a7-a9, a quad at a time; in Philox mode one block serves an agent pair (two blocks per quad).
-  const bool pair_aligned = ((D.agent_offset + base) & 1) == 0;   // local pairs are global pairs (else: per agent)
-  const float now = D.clock ? D.clock->now : D.now;
-  const uint64_t step = D.clock ? D.clock->step : D.step;
-  for (int q = tid; 4 * q < n_local; q += kTileThreads) {
+  uint32_t infected = 0u;                       // bit 4m + j: agent 4 * (tid + m * 1024) + j was infected in this step
+  int m_run = 0;
+  for (int q = tid; 4 * q < n_local; q += kTileThreads, ++m_run) {
     const int i0 = 4 * q;
-    const float4 aq = acc4[q], sv = susc4[q];
-    const float accq[4] = {aq.x, aq.y, aq.z, aq.w};
+    const float4 tq = ts4[q], hq = th4[q];
+    const float ts[4] = {tq.x, tq.y, tq.z, tq.w}, th[4] = {hq.x, hq.y, hq.z, hq.w};
     const int64_t a0 = base + i0;
     const int n_ok = n_local - i0;
-    float susc[4] = {sv.x, sv.y, sv.z, sv.w}, ts[4], p[4];
+    float p[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      ts[j] = susc[j] * accq[j];
-      p[j] = not_infected_prob(ts[j], D.dt);
-    }
+    for (int j = 0; j < 4; ++j) p[j] = not_infected_prob(ts[j], D.dt);
 #ifndef GJ_DIAG_STAMPS
     if (D.trans_susc) store_quad(D.trans_susc, a0, n_ok, vec, ts);
 #endif
     if (D.not_infected_probs) store_quad(D.not_infected_probs, a0, n_ok, vec, p);
     if (!D.sample) continue;
     float nw[4];
-    const bool block = !D.exp_noise && pair_aligned;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      uint32_t r[4] = {0u, 0u, 0u, 0u};
-      if (block) philox4x32_10((uint64_t)(D.agent_offset + a0 + 2 * h) >> 1, step, D.seed, r);
-#pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        const int j = 2 * h + g;
-        float e0 = 1.0f, e1 = 1.0f;
-        if (D.exp_noise) {
-          if (j < n_ok) {
-            e0 = D.exp_noise[a0 + j];
-            e1 = D.exp_noise[D.n_agents + a0 + j];
-          }
-        } else if (block) {
-          exp_from_block(r, g, e0, e1);
-        } else {
-          exp_pair(D.seed, step, D.agent_offset + a0 + j, e0, e1);
-        }
-        nw[j] = D.exp_noise ? gumbel_new_infected(p[j], e0, e1) : ratio_new_infected(p[j], e0, e1);
-      }
-    }
-    if (D.new_infected) store_quad(D.new_infected, a0, n_ok, vec, nw);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (j < n_ok && nw[j] != 0.0f) {
+      if (own_noise) {
+        nw[j] = (p[j] < th[j]) ? 1.0f : 0.0f;        // ratio_new_infected with the threshold drawn above
+      } else {
+        float e0 = 1.0f, e1 = 1.0f;
+        if (j < n_ok) {
+          e0 = D.exp_noise[a0 + j];
+          e1 = D.exp_noise[D.n_agents + a0 + j];
+        }
+        nw[j] = gumbel_new_infected(p[j], e0, e1);
+      }
+      if (j < n_ok && nw[j] != 0.0f) infected |= 1u << (4 * m_run + j);
+    }
+    if (D.new_infected) store_quad(D.new_infected, a0, n_ok, vec, nw);
+    // a9 where nw is neither 0 nor 1 (a NaN probability under injected noise): on the spot, with the value itself
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < n_ok && nw[j] != 0.0f && nw[j] != 1.0f) {
+        infected &= ~(1u << (4 * m_run + j));
         const int64_t a = a0 + j;
-        float sc = susc[j], inf = D.is_infected[a], t_inf = D.infection_time[a];
+        float sc = D.susceptibility[a], inf = D.is_infected[a], t_inf = D.infection_time[a];
         infect(nw[j], now, sc, inf, t_inf);
         D.susceptibility[a] = sc;
         D.is_infected[a] = inf;
         D.infection_time[a] = t_inf;
+      }
+    }
+  }
+  // a9 for the agents infected in this step (new_infected == 1), all of a lane's at once: one memory round trip for
+  // the whole slice instead of one per quad that holds a new case (a wave covers 256 agents per iteration: at one
+  // new case per thousand agents a quarter of the iterations would wait on these loads)
+  if (__builtin_amdgcn_ballot_w64(infected != 0u) != 0ull) {
+    float sc[kQ][4], inf[kQ][4], tinf[kQ][4];
+#pragma unroll
+    for (int m = 0; m < kQ; ++m) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool hit = (infected >> (4 * m + j)) & 1u;
+        const int64_t a = base + 4 * (tid + m * kTileThreads) + j;
+        sc[m][j] = hit ? D.susceptibility[a] : 0.0f;
+        inf[m][j] = hit ? D.is_infected[a] : 0.0f;
+        tinf[m][j] = hit ? D.infection_time[a] : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < kQ; ++m) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (!((infected >> (4 * m + j)) & 1u)) continue;
+        const int64_t a = base + 4 * (tid + m * kTileThreads) + j;
+        infect(1.0f, now, sc[m][j], inf[m][j], tinf[m][j]);
+        D.susceptibility[a] = sc[m][j];
+        D.is_infected[a] = inf[m][j];
+        D.infection_time[a] = tinf[m][j];
       }
     }
   }

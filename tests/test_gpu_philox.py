@@ -6,7 +6,7 @@ validated three ways (every golden / oracle comparison injects the reference's n
     bit for bit, for pair-aligned and odd agent offsets, and both equal an independent numpy restatement of the
     stream (tests/gj_philox_ref.py, pinned by Random123's known answers) away from float ties;
   * the number of new infections matches the probabilities: within 5 sigma of sum(1 - p) in every probability decile;
-  * (1-p)*e0 > p*e1 ("ratio" form, Philox mode) and the reference's op sequence (F.gumbel_softmax, infection.py:13-18;
+  * p < e0/(e0+e1), i.e. (1-p)*e0 > p*e1 ("ratio" form, Philox mode) and the reference's op sequence (F.gumbel_softmax, infection.py:13-18;
     injected-noise mode) take the same decision on 10^7 random (p, e0, e1), except within float rounding of a tie.
 """
 import numpy as np
@@ -43,6 +43,11 @@ def ratio_margin(p, e0, e1):
     return np.abs(a - b) / np.maximum(np.maximum(a, b), 1e-300)
 
 
+def threshold_decision(p, e0, e1):
+    """ratio_new_infected of gj_device.h in fp32: infected iff p < e0 / (e0 + e1)."""
+    return p < (e0 / (e0 + e1)).astype(np.float32)
+
+
 @pytest.mark.parametrize("layout,kw", [("tiled", {}), ("tiled", {"direct": False}), ("csr", {})],
                          ids=["tiled-direct", "tiled-workspace", "csr"])
 @pytest.mark.parametrize("offset", [0, 1, (1 << 33) + 7], ids=["offset-0", "offset-odd", "offset-2^33+7"])
@@ -64,7 +69,7 @@ def test_fused_philox_decisions_equal_sample_infect(device, c2_world, layout, kw
     # the stream itself, against the numpy restatement (device logf vs numpy log: ties may fall either way)
     pn = probs.cpu().numpy()
     e0, e1 = P.exp_pair(SEED, STEP, offset + np.arange(A, dtype=np.uint64))
-    ref = ((np.float32(1.0) - pn) * e0 > pn * e1)
+    ref = threshold_decision(pn, e0, e1)
     bad = ref != (new.cpu().numpy() > 0.5)
     assert bad.sum() <= 5 and (ratio_margin(pn, e0, e1)[bad] < 1e-5).all()
     assert ref.sum() > 1000
@@ -116,5 +121,5 @@ def test_philox_draws_are_never_zero_or_infinite(device):
     dec = sample_only(p, device, 99, 7, 0).cpu().numpy() > 0.5
     e0, e1 = P.exp_pair(99, 7, np.arange(n, dtype=np.uint64))
     assert (e0 > 0).all() and (e1 > 0).all() and np.isfinite(e0).all() and np.isfinite(e1).all()
-    assert (dec != (e0 > e1)).sum() <= 3
+    assert (dec != threshold_decision(np.full(n, 0.5, np.float32), e0, e1)).sum() <= 3
     assert abs(dec.mean() - 0.5) < 1e-3
