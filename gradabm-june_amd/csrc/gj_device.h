@@ -66,22 +66,34 @@ __device__ __forceinline__ void philox4x32_10(uint64_t ctr_lo, uint64_t ctr_hi, 
 // about once per step of a 10 M-agent world.)
 __device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 9) + 0.5f) * 1.1920928955078125e-7f; }
 
-// One Philox block serves the agent pair (2k, 2k+1) of GLOBAL agent ids: counter = agent >> 1, the even agent
-// takes words 0-1, the odd one words 2-3 (the integer multiplies of the ten rounds are the expensive part of
-// the sampler; the fused tiled epilogue computes one block per pair, every other caller one per agent).
-#ifndef GJ_PRECISE_DRAW_LOG
-#define GJ_DRAW_LOG __logf        // v_log_f32 * ln 2: the draws feed a comparison and a softmax, not a parity check
-#else
-#define GJ_DRAW_LOG logf
-#endif
-__device__ __forceinline__ void exp_from_block(const uint32_t (&r)[4], int half, float& e0, float& e1) {
-  e0 = -GJ_DRAW_LOG(u01(half ? r[2] : r[0]));
-  e1 = -GJ_DRAW_LOG(u01(half ? r[3] : r[1]));
+// ---- the library's own noise for a8 (no reference draw to reproduce) ---------------------------------------------
+// The reference draws two Exponential(1) variates (e0, e1) per agent and infects iff log(1-p) - log(e1) > log(p) -
+// log(e0), i.e. iff p < e0 / (e0 + e1).  For two iid exponentials theta = e0 / (e0 + e1) is Uniform(0,1) and
+// INDEPENDENT of s = e0 + e1 ~ Gamma(2,1).  So:
+//   forward : theta = one 23-bit uniform; infected iff p < theta.  One Philox4x32-10 block (four words) serves the FOUR
+//             agents 4k .. 4k+3 of GLOBAL ids (counter = agent >> 2) - a quarter of the integer multiplies that are the
+//             sampler's cost, no logarithm, no division.
+//   backward: the straight-through softmax needs both draws: e0 = theta * s, e1 = (1 - theta) * s with s = -log(u1 u2)
+//             from a second block (counter = agent >> 1, stream bit 62 set) - the same joint law as two iid draws,
+//             and by construction the same decision as the forward's.
+__device__ __forceinline__ float infection_uniform_from_block(const uint32_t (&r)[4], int which) {
+  return u01(which == 0 ? r[0] : (which == 1 ? r[1] : (which == 2 ? r[2] : r[3])));
 }
-__device__ __forceinline__ void exp_pair(uint64_t seed, uint64_t step, int64_t agent, float& e0, float& e1) {
+__device__ __forceinline__ float infection_uniform(uint64_t seed, uint64_t step, int64_t agent) {
   uint32_t r[4];
-  philox4x32_10((uint64_t)agent >> 1, step, seed, r);
-  exp_from_block(r, (int)(agent & 1), e0, e1);
+  philox4x32_10((uint64_t)agent >> 2, step, seed, r);
+  return infection_uniform_from_block(r, (int)(agent & 3));
+}
+__device__ __forceinline__ float own_new_infected(float p, float theta) { return (p < theta) ? 1.0f : 0.0f; }
+// (e0, e1) with e0 / (e0 + e1) == theta up to rounding: what k_adjoint_sample feeds the softmax derivative
+__device__ __forceinline__ void exp_pair(uint64_t seed, uint64_t step, int64_t agent, float& e0, float& e1) {
+  const float theta = infection_uniform(seed, step, agent);
+  uint32_t r[4];
+  philox4x32_10((uint64_t)agent >> 1, step | (1ull << 62), seed, r);
+  const float u1 = u01((agent & 1) ? r[2] : r[0]), u2 = u01((agent & 1) ? r[3] : r[1]);
+  const float s = -logf(u1) - logf(u2);
+  e0 = theta * s;
+  e1 = (1.0f - theta) * s;
 }
 
 // a8: IsInfectedSampler.forward = F.gumbel_softmax(vstack(p, 1-p).log(), tau=0.1, hard=True, dim=0)
@@ -101,18 +113,6 @@ __device__ __forceinline__ float gumbel_new_infected(float p, float e0, float e1
   const float h0 = (y1 > y0) ? 0.0f : 1.0f;  // argmax, ties -> row 0 (not infected)
   const float ret0 = (h0 - y0) + y0;
   return 1.0f - ret0;
-}
-
-// The same decision when the noise is the library's own Philox stream (no reference draw to reproduce):
-// argmax of the two Gumbel-perturbed logits, log(1-p) - log(e1) > log(p) - log(e0), is (1-p)*e0 > p*e1, i.e.
-// p < e0 / (e0 + e1) - a monotone transform, so the same (e0, e1) give the same outcome (up to rounding at exact
-// ties) at a third of the transcendental work.  The threshold depends on the draws only (it is Uniform(0,1)), so the
-// fused epilogue computes it while the agents' data are still on their way.  p = 1 never infects, p = 0 always
-// does, as in the reference (e0, e1 > 0 are finite: u01).  The backward pass (k_adjoint_sample) replays this rule
-// from the same draws.
-__device__ __forceinline__ float infection_threshold(float e0, float e1) { return e0 / (e0 + e1); }
-__device__ __forceinline__ float ratio_new_infected(float p, float e0, float e1) {
-  return (p < infection_threshold(e0, e1)) ? 1.0f : 0.0f;
 }
 
 // a9: GradJune.infect_people (reference grad_june/model.py:103-110)

@@ -34,36 +34,43 @@ constexpr int kVenueUnrollC = GJ_VENUE_UNROLL_C;  // same, phase C
 // against 4.9 for ds_add_u64 and 7.3 for ds_add_u32, so the per-venue and per-agent sums are kept
 // in 64-bit fixed point: integer adds are order-independent, which also makes both passes bitwise
 // reproducible, and exact (no rounding inside a sum).
-//   pass 1 (sums of transmissions per venue):  2^-40 resolution (9e-13), |value| <= 2.1e6, |sum| < 8.3e6
-//   pass 2 (sums of cum per agent):            2^-36 resolution (1.5e-11), |value| <= 3.4e7, |sum| < 1.3e8
+//   pass 1 (sums of transmissions per venue):  2^-36 resolution (1.5e-11), |value| <= 16384, |sum| < 1.3e8
+//   pass 2 (sums of cum per agent):            2^-32 resolution (2.3e-10), |value| <= 2.6e5, |sum| < 2.1e9
+// float -> fixed point is the classic magic-number conversion in fp64 (two instructions + a 64-bit subtract instead
+// of the dozen a float -> int64 conversion compiles to; phase D issues instructions, it does not wait for memory):
+// x * 2^BITS + 1.5 * 2^52 is exact up to the final round-to-nearest-even at integer granularity, and the double's bit
+// pattern minus the magic's is the integer in two's complement, for |x * 2^BITS| < 2^50.
 typedef unsigned long long fx_t;
 template <int BITS>
+__device__ __forceinline__ constexpr float fx_max() { return (float)(1ull << (50 - BITS)); }
+template <int BITS>
 __device__ __forceinline__ fx_t to_fx(float x) {      // |x| <= fx_max<BITS>() (fx_add checks)
-  constexpr float scale = (float)(1ull << BITS);
-  return (fx_t)__float2ll_rn(x * scale);
+  constexpr double scale = (double)(1ull << BITS);
+  constexpr double magic = 6755399441055744.0;       // 1.5 * 2^52
+  const double d = __builtin_fma((double)x, scale, magic);
+  return (fx_t)(__double_as_longlong(d) - 0x4338000000000000LL);
 }
 template <int BITS>
 __device__ __forceinline__ float from_fx(fx_t v) {
   return (float)((double)(long long)v * (1.0 / (double)(1ull << BITS)));
 }
-// One value may use a quarter of the 64-bit range.  Anything else - NaN, infinities, |x| beyond it - cannot be
-// summed as an integer: it sets the element's bit in `flags` instead and the element reads back as NaN (the
-// reference's scatter_add would give NaN / inf there; a silent clamp would turn a poisoned venue into a number).
-template <int BITS>
-__device__ __forceinline__ constexpr float fx_max() { return (float)(1ull << (61 - BITS)); }
+// What cannot be summed as an integer - NaN, infinities, |x| beyond fx_max - sets the element's bit in `flags`
+// instead and the element reads back as NaN (the reference's scatter_add would give NaN / inf there; a silent clamp
+// would turn a poisoned venue into a number).
+// Branch-free on the common path (such a value adds 0 and raises its flag bit): control flow around every add lets
+// hipcc sink each global load that feeds one into the add's own block, behind an s_waitcnt of its own - a batch of
+// eight loads then costs eight memory round trips instead of one.
 template <int BITS>
 __device__ __forceinline__ void fx_add(fx_t* sums, uint32_t* flags, int i, float x) {
-  if (fabsf(x) <= fx_max<BITS>()) {
-    atomicAdd(&sums[i], to_fx<BITS>(x));
-  } else {
-    atomicOr(&flags[i >> 5], 1u << (i & 31));
-  }
+  const bool ok = fabsf(x) <= fx_max<BITS>();
+  atomicAdd(&sums[i], to_fx<BITS>(ok ? x : 0.0f));
+  if (__builtin_expect(!ok, 0)) atomicOr(&flags[i >> 5], 1u << (i & 31));
 }
 template <int BITS>
 __device__ __forceinline__ float fx_read(const fx_t* sums, const uint32_t* flags, int i) {
   return ((flags[i >> 5] >> (i & 31)) & 1u) ? __builtin_nanf("") : from_fx<BITS>(sums[i]);
 }
-constexpr int kFxVenue = 40, kFxAgent = 36;
+constexpr int kFxVenue = 36, kFxAgent = 32;
 
 struct TSetA {            // what phases A and D need of one set
   const uint16_t* a_la;
@@ -255,6 +262,9 @@ __device__ __forceinline__ void scatter_set(const TSetA& T, const float* lds_x, 
 #ifndef GJ_UNROLL_D_NARROW
 #define GJ_UNROLL_D_NARROW 8       // chunks in flight per wave on sets with 16-byte descriptors (16: 8 % slower, registers)
 #endif
+#ifndef GJ_GATHER_PIPELINE
+#define GJ_GATHER_PIPELINE 1
+#endif
 template <bool WIDE>
 __device__ __forceinline__ void gather_set(const TSetA& T, fx_t* lds_acc, uint32_t* lds_flags, int s, int wave, int lane) {
   const int row = s * T.J;
@@ -262,26 +272,72 @@ __device__ __forceinline__ void gather_set(const TSetA& T, fx_t* lds_acc, uint32
   const int c_base = T.chunk_ptr[s];
   const int n_chunks = T.chunk_ptr[s + 1] - c_base;
   constexpr int kU = WIDE ? kUnroll : GJ_UNROLL_D_NARROW;
-  for (int c0 = wave * kU; c0 < n_chunks; c0 += kTileWaves * kU) {
-    int la[kU], slot[kU];
-    float v[kU];
-    const int word = batch_desc_load<WIDE, kU>(T, c_base, n_chunks, c0, lane);   // first: the val loads wait on it
+  constexpr int kStride = kTileWaves * kU;
+  // A batch costs two dependent memory round trips (descriptors + local agent indices, then the values at the slots
+  // the descriptors give), ~2 us each while every CU streams.  The next batch's first trip is issued before the
+  // current batch's values are waited for (vmcnt counts in order), so a batch costs one.
+  auto stage1 = [&](int c, int& word, int (&la)[kU]) {        // descriptors + local agent indices of batch c
+    const int cc = min(c, n_chunks - 1);                      // past the end: a harmless re-load of the last chunk
+    word = batch_desc_load<WIDE, kU>(T, c_base, n_chunks, cc, lane);
 #pragma unroll
-    for (int u = 0; u < kU; ++u)    // unconditional (clamped) loads: straight-line, all in flight
-      la[u] = T.a_la[min(seg0 + (c0 + u) * kWave + lane, seg1 - 1)];
-    batch_slots<WIDE, kU>(T, word, row, seg0, seg1, c0, lane, slot);
-#pragma unroll
-    for (int u = 0; u < kU; ++u) {  // the slot depends on the position only: these loads overlap the ones above
-      const int i = seg0 + (c0 + u) * kWave + lane;
-      const bool ok = (c0 + u < n_chunks) && (i < seg1);
-      v[u] = T.val[ok ? slot[u] : 0];
-    }
+    for (int u = 0; u < kU; ++u) la[u] = T.a_la[min(seg0 + (cc + u) * kWave + lane, seg1 - 1)];
+  };
+  auto values = [&](int c, int word, float (&v)[kU]) {        // the batch's value loads (issued, not waited for)
+    int slot[kU];
+    batch_slots<WIDE, kU>(T, word, row, seg0, seg1, c, lane, slot);
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
-      const int i = seg0 + (c0 + u) * kWave + lane;
-      if ((c0 + u < n_chunks) && (i < seg1)) fx_add<kFxAgent>(lds_acc, lds_flags, la[u], v[u]);
+      const int i = seg0 + (c + u) * kWave + lane;
+      const bool ok = (c + u < n_chunks) && (i < seg1);
+      v[u] = T.val[ok ? slot[u] : 0];
     }
+  };
+  auto add = [&](int c, const int (&la)[kU], const float (&v)[kU]) {
+    // straight-line: every lane adds (0 where there is no edge; la is a valid local index either way), what cannot
+    // be summed is flagged after the batch
+    uint32_t bad = 0u;
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int i = seg0 + (c + u) * kWave + lane;
+      const bool edge = (c + u < n_chunks) && (i < seg1);
+      const float x = edge ? v[u] : 0.0f;
+      const bool ok = fabsf(x) <= fx_max<kFxAgent>();
+      atomicAdd(&lds_acc[la[u]], to_fx<kFxAgent>(ok ? x : 0.0f));
+      bad |= ok ? 0u : (1u << u);
+    }
+    if (__builtin_expect(bad != 0u, 0)) {
+#pragma unroll
+      for (int u = 0; u < kU; ++u)
+        if ((bad >> u) & 1u) atomicOr(&lds_flags[la[u] >> 5], 1u << (la[u] & 31));
+    }
+  };
+  int c0 = wave * kU;
+  if (c0 >= n_chunks) return;
+  int laA[kU], wordA;
+  float v[kU];
+#if GJ_GATHER_PIPELINE
+  int laB[kU], wordB;
+  stage1(c0, wordA, laA);
+  while (true) {
+    const int c1 = c0 + kStride;
+    values(c0, wordA, v);
+    stage1(c1, wordB, laB);           // behind the value loads: in flight while they are waited for and added
+    add(c0, laA, v);
+    if (c1 >= n_chunks) break;
+    const int c2 = c1 + kStride;
+    values(c1, wordB, v);
+    stage1(c2, wordA, laA);
+    add(c1, laB, v);
+    if (c2 >= n_chunks) break;
+    c0 = c2;
   }
+#else
+  for (; c0 < n_chunks; c0 += kStride) {
+    stage1(c0, wordA, laA);
+    values(c0, wordA, v);
+    add(c0, laA, v);
+  }
+#endif
 }
 
 // ---- phase A: scatter the slice's transmissions to every edge, in block-major tile order -------
@@ -554,9 +610,10 @@ __global__ __launch_bounds__(256) void k_tile_epilogue(const TileDArgs D) {
     e0 = D.exp_noise[a];
     e1 = D.exp_noise[D.n_agents + a];
   } else {
-    exp_pair(D.seed, step, D.agent_offset + a, e0, e1);
+    e0 = e1 = 1.0f;
   }
-  const float nw = D.exp_noise ? gumbel_new_infected(p, e0, e1) : ratio_new_infected(p, e0, e1);
+  const float nw = D.exp_noise ? gumbel_new_infected(p, e0, e1)
+                               : own_new_infected(p, infection_uniform(D.seed, step, D.agent_offset + a));
   if (D.new_infected) D.new_infected[a] = nw;
   if (nw != 0.0f) {
     float inf = D.is_infected[a], t_inf = D.infection_time[a];
@@ -880,67 +937,30 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
     return;
   }
   // Epilogue a7-a9.  ALL of a lane's susceptibility loads are issued together (one memory round trip, not one per
-  // quad) and, while they are in flight, the lane draws its agents' infection thresholds (Philox: the epilogue's
-  // arithmetic, and independent of the data).  ts = susceptibility * sum and the thresholds then go to LDS (a lane
-  // reads back only what it wrote), so that the final loop is rolled and short.  (Measured, not adopted: loading the
-  // susceptibilities at kernel start - the 20 registers held through the tiled phase cost it more than the epilogue wins.)
+  // quad); ts = susceptibility * sum goes to LDS (a lane reads back only what it wrote), so that the final loop is
+  // rolled.  In it a quad's infection thresholds are drawn (Philox: the epilogue's arithmetic, independent of the
+  // data) between its stores - measured: as a phase of its own in front of the loop the same arithmetic costs 40 %
+  // more, there is nothing in flight for it to hide behind.
   const float now = D.clock ? D.clock->now : D.now;
   const uint64_t step = D.clock ? D.clock->step : D.step;
   const bool own_noise = D.sample && !D.exp_noise;
+  const int mis = (int)((D.agent_offset + base) & 3);       // (wave-uniform: base is a multiple of 64)
   float4* ts4 = reinterpret_cast<float4*>(lds_acc);
-  float4* th4 = ts4 + D.slice_agents / 4;
   {
-    float sq[kQ][4], th[kQ][4];
+    float sq[kQ][4];
 #pragma unroll
     for (int m = 0; m < kQ; ++m) {
       const int i0 = 4 * (tid + m * kTileThreads);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) sq[m][j] = th[m][j] = 0.0f;
+      for (int j = 0; j < 4; ++j) sq[m][j] = 0.0f;
       if (i0 < n_local) load_quad(D.susceptibility, base + i0, n_local - i0, vec, sq[m]);
-    }
-    if (own_noise) {
-      // one Philox block serves the GLOBAL agent pair (2k, 2k+1): a quad that starts on an even global id takes two
-      // blocks, one that starts on an odd id three (wave-uniform: base is even)
-      const bool odd = ((D.agent_offset + base) & 1) != 0;
-#pragma unroll
-      for (int m = 0; m < kQ; ++m) {
-        const int i0 = 4 * (tid + m * kTileThreads);
-        if (i0 >= n_local) continue;
-        const uint64_t g0 = (uint64_t)(D.agent_offset + base + i0);
-        uint32_t r0[4], r1[4], r2[4] = {0u, 0u, 0u, 0u};
-        philox4x32_10(g0 >> 1, step, D.seed, r0);
-        philox4x32_10((g0 >> 1) + 1, step, D.seed, r1);
-        if (odd) philox4x32_10((g0 >> 1) + 2, step, D.seed, r2);
-        float e0, e1;
-        if (!odd) {
-          exp_from_block(r0, 0, e0, e1);
-          th[m][0] = infection_threshold(e0, e1);
-          exp_from_block(r0, 1, e0, e1);
-          th[m][1] = infection_threshold(e0, e1);
-          exp_from_block(r1, 0, e0, e1);
-          th[m][2] = infection_threshold(e0, e1);
-          exp_from_block(r1, 1, e0, e1);
-          th[m][3] = infection_threshold(e0, e1);
-        } else {
-          exp_from_block(r0, 1, e0, e1);
-          th[m][0] = infection_threshold(e0, e1);
-          exp_from_block(r1, 0, e0, e1);
-          th[m][1] = infection_threshold(e0, e1);
-          exp_from_block(r1, 1, e0, e1);
-          th[m][2] = infection_threshold(e0, e1);
-          exp_from_block(r2, 0, e0, e1);
-          th[m][3] = infection_threshold(e0, e1);
-        }
-      }
     }
     __syncthreads();          // every lane has its sums in registers, the last venue table has been read by every wave
 #pragma unroll
     for (int m = 0; m < kQ; ++m) {
       const int q = tid + m * kTileThreads;
-      if (4 * q < n_local) {
+      if (4 * q < n_local)
         ts4[q] = make_float4(sq[m][0] * acc[m][0], sq[m][1] * acc[m][1], sq[m][2] * acc[m][2], sq[m][3] * acc[m][3]);
-        th4[q] = make_float4(th[m][0], th[m][1], th[m][2], th[m][3]);
-      }
     }
   }
   GJ_STAMP(4);
@@ -948,8 +968,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
   int m_run = 0;
   for (int q = tid; 4 * q < n_local; q += kTileThreads, ++m_run) {
     const int i0 = 4 * q;
-    const float4 tq = ts4[q], hq = th4[q];
-    const float ts[4] = {tq.x, tq.y, tq.z, tq.w}, th[4] = {hq.x, hq.y, hq.z, hq.w};
+    const float4 tq = ts4[q];
+    const float ts[4] = {tq.x, tq.y, tq.z, tq.w};
     const int64_t a0 = base + i0;
     const int n_ok = n_local - i0;
     float p[4];
@@ -960,11 +980,24 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
 #endif
     if (D.not_infected_probs) store_quad(D.not_infected_probs, a0, n_ok, vec, p);
     if (!D.sample) continue;
-    float nw[4];
+    float nw[4], th[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (own_noise) {
+      // one Philox block serves the GLOBAL agents 4k .. 4k+3: a quad that starts on a multiple of four takes one
+      // block, any other quad two (wave-uniform: base is a multiple of 64)
+      const uint64_t g0 = (uint64_t)(D.agent_offset + a0);
+      uint32_t r0[4], r1[4] = {0u, 0u, 0u, 0u};
+      philox4x32_10(g0 >> 2, step, D.seed, r0);
+      if (mis) philox4x32_10((g0 >> 2) + 1, step, D.seed, r1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int w = mis + j;                       // word of the pair of blocks
+        th[j] = u01(w == 0 ? r0[0] : w == 1 ? r0[1] : w == 2 ? r0[2] : w == 3 ? r0[3] : w == 4 ? r1[0] : w == 5 ? r1[1] : r1[2]);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (own_noise) {
-        nw[j] = (p[j] < th[j]) ? 1.0f : 0.0f;        // ratio_new_infected with the threshold drawn above
+        nw[j] = own_new_infected(p[j], th[j]);
       } else {
         float e0 = 1.0f, e1 = 1.0f;
         if (j < n_ok) {
@@ -993,29 +1026,33 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
   // a9 for the agents infected in this step (new_infected == 1), all of a lane's at once: one memory round trip for
   // the whole slice instead of one per quad that holds a new case (a wave covers 256 agents per iteration: at one
   // new case per thousand agents a quarter of the iterations would wait on these loads)
+  GJ_STAMP(6);
   if (__builtin_amdgcn_ballot_w64(infected != 0u) != 0ull) {
+    // straight-line loads: a lane without a case at (m, j) reads the slice's first agent instead (one line for the
+    // whole wave) - a load under its own branch would be waited for on its own
     float sc[kQ][4], inf[kQ][4], tinf[kQ][4];
 #pragma unroll
     for (int m = 0; m < kQ; ++m) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const bool hit = (infected >> (4 * m + j)) & 1u;
-        const int64_t a = base + 4 * (tid + m * kTileThreads) + j;
-        sc[m][j] = hit ? D.susceptibility[a] : 0.0f;
-        inf[m][j] = hit ? D.is_infected[a] : 0.0f;
-        tinf[m][j] = hit ? D.infection_time[a] : 0.0f;
+        const int64_t a = hit ? base + 4 * (tid + m * kTileThreads) + j : base;
+        sc[m][j] = D.susceptibility[a];
+        inf[m][j] = D.is_infected[a];
+        tinf[m][j] = D.infection_time[a];
       }
     }
 #pragma unroll
     for (int m = 0; m < kQ; ++m) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (!((infected >> (4 * m + j)) & 1u)) continue;
         const int64_t a = base + 4 * (tid + m * kTileThreads) + j;
         infect(1.0f, now, sc[m][j], inf[m][j], tinf[m][j]);
-        D.susceptibility[a] = sc[m][j];
-        D.is_infected[a] = inf[m][j];
-        D.infection_time[a] = tinf[m][j];
+        if ((infected >> (4 * m + j)) & 1u) {
+          D.susceptibility[a] = sc[m][j];
+          D.is_infected[a] = inf[m][j];
+          D.infection_time[a] = tinf[m][j];
+        }
       }
     }
   }

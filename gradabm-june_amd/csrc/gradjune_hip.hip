@@ -350,9 +350,11 @@ __global__ __launch_bounds__(kThreads) void k_agent_gather(const P2Args P) {
     e0 = P.exp_noise[a];
     e1 = P.exp_noise[P.n_agents + a];
   } else {
-    exp_pair(P.seed, P.clock ? P.clock->step : P.step, P.agent_offset + a, e0, e1);
+    e0 = e1 = 1.0f;
   }
-  const float nw = P.exp_noise ? gumbel_new_infected(p, e0, e1) : ratio_new_infected(p, e0, e1);
+  const float nw = P.exp_noise ? gumbel_new_infected(p, e0, e1)
+                               : own_new_infected(p, infection_uniform(P.seed, P.clock ? P.clock->step : P.step,
+                                                                       P.agent_offset + a));
   if (P.new_infected) P.new_infected[a] = nw;
   if (nw != 0.0f) {   // unchanged values are not rewritten
     float inf = P.is_infected[a], t_inf = P.infection_time[a];
@@ -376,9 +378,10 @@ __global__ __launch_bounds__(kThreads) void k_sample_infect(int64_t n, const flo
     e0 = noise[a];
     e1 = noise[n + a];
   } else {
-    exp_pair(seed, step, agent_offset + a, e0, e1);
+    e0 = e1 = 1.0f;
   }
-  const float nw = noise ? gumbel_new_infected(p_not[a], e0, e1) : ratio_new_infected(p_not[a], e0, e1);
+  const float nw = noise ? gumbel_new_infected(p_not[a], e0, e1)
+                         : own_new_infected(p_not[a], infection_uniform(seed, step, agent_offset + a));
   if (new_inf) new_inf[a] = nw;
   if (susc != nullptr && nw != 0.0f) {   // state pointers NULL: sample only
     float s = susc[a], i = inf[a], t = t_inf[a];
@@ -541,7 +544,8 @@ __global__ __launch_bounds__(kThreads) void k_adjoint_sample(
   const float m = fmaxf(z0, z1);
   const float x0 = expf(z0 - m), x1 = expf(z1 - m);
   const float y0 = x0 / (x0 + x1), y1 = x1 / (x0 + x1);
-  const float nu = noise ? ((y1 > y0) ? 1.0f : 0.0f) : ratio_new_infected(p, e0, e1);   // the forward's rule
+  const float nu = noise ? ((y1 > y0) ? 1.0f : 0.0f)                                   // the forward's rule
+                         : own_new_infected(p, infection_uniform(seed, step, agent_offset + a));
   const float gs = g_susc ? g_susc[a] : 0.0f, gi = g_inf ? g_inf[a] : 0.0f, gt = g_time ? g_time[a] : 0.0f;
   const float gn = g_new ? g_new[a] : 0.0f;
   const float x = s0 - nu;                                   // torch.maximum(0, x): tie splits the gradient

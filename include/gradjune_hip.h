@@ -107,7 +107,8 @@ typedef struct gj_long_row {
  *   C  same workgroup (fused)  :  val[i] = cum[e_lv[i]]          (in place)
  *   D  one workgroup per slice :  acc[a_la] += val[block-major pos]; epilogue a7-a9
  * A tile is contiguous in both the slice-major (s, j) and the block-major (j, s) edge order.
- * Sums are accumulated with 64-bit fixed-point LDS atomics (resolution 2^-36, |value| < 1e8):
+ * Sums are accumulated with 64-bit fixed-point LDS atomics (resolution 2^-36 per venue, 2^-32 per agent; a value
+ * beyond 16384 / 262144, an infinity or a NaN cannot be summed and makes its venue / agent read back NaN):
  * integer adds are order-independent, so results are bitwise reproducible from run to run, and
  * agree with the CSR path to fp32 rounding.                                                  */
 typedef struct gj_tiled_set {

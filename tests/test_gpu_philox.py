@@ -6,8 +6,9 @@ validated three ways (every golden / oracle comparison injects the reference's n
     bit for bit, for pair-aligned and odd agent offsets, and both equal an independent numpy restatement of the
     stream (tests/gj_philox_ref.py, pinned by Random123's known answers) away from float ties;
   * the number of new infections matches the probabilities: within 5 sigma of sum(1 - p) in every probability decile;
-  * p < e0/(e0+e1), i.e. (1-p)*e0 > p*e1 ("ratio" form, Philox mode) and the reference's op sequence (F.gumbel_softmax, infection.py:13-18;
-    injected-noise mode) take the same decision on 10^7 random (p, e0, e1), except within float rounding of a tie.
+  * the forward's one-uniform decision p < theta and the reference's op sequence (F.gumbel_softmax, infection.py:13-18;
+    injected-noise mode) fed the pair of Exponential draws the backward pass derives for the same agents
+    (theta * s, (1 - theta) * s) take the same decision on 10^7 random p, except within float rounding of a tie.
 """
 import numpy as np
 import pytest
@@ -43,9 +44,9 @@ def ratio_margin(p, e0, e1):
     return np.abs(a - b) / np.maximum(np.maximum(a, b), 1e-300)
 
 
-def threshold_decision(p, e0, e1):
-    """ratio_new_infected of gj_device.h in fp32: infected iff p < e0 / (e0 + e1)."""
-    return p < (e0 / (e0 + e1)).astype(np.float32)
+def theta_margin(p, theta):
+    """|p - theta| relative: how far a decision is from a tie."""
+    return np.abs(p.astype(np.float64) - theta) / np.maximum(theta.astype(np.float64), 1e-300)
 
 
 @pytest.mark.parametrize("layout,kw", [("tiled", {}), ("tiled", {"direct": False}), ("csr", {})],
@@ -68,10 +69,9 @@ def test_fused_philox_decisions_equal_sample_infect(device, c2_world, layout, kw
     assert torch.equal(r.state["is_infected"], before + new)                   # a9 applied to exactly these agents
     # the stream itself, against the numpy restatement (device logf vs numpy log: ties may fall either way)
     pn = probs.cpu().numpy()
-    e0, e1 = P.exp_pair(SEED, STEP, offset + np.arange(A, dtype=np.uint64))
-    ref = threshold_decision(pn, e0, e1)
-    bad = ref != (new.cpu().numpy() > 0.5)
-    assert bad.sum() <= 5 and (ratio_margin(pn, e0, e1)[bad] < 1e-5).all()
+    theta = P.infection_uniform(SEED, STEP, offset + np.arange(A, dtype=np.uint64))
+    ref = pn < theta                                      # exact arithmetic on both sides: no tie tolerance needed
+    assert np.array_equal(ref, new.cpu().numpy() > 0.5)
     assert ref.sum() > 1000
 
     # -- the count follows the probabilities, decile by decile ------------------------------------------------------
@@ -97,7 +97,8 @@ def test_ratio_and_gumbel_forms_agree(device):
     p[n // 5 + 1000: n // 5 + 2000] = 1.0
     p_dev = p.to(device)
     ratio = sample_only(p_dev, device, SEED, STEP, 0).cpu().numpy() > 0.5
-    e0, e1 = P.exp_pair(SEED, STEP, np.arange(n, dtype=np.uint64))
+    assert np.array_equal(ratio, p.numpy() < P.infection_uniform(SEED, STEP, np.arange(n, dtype=np.uint64)))
+    e0, e1 = P.exp_pair(SEED, STEP, np.arange(n, dtype=np.uint64))     # the backward's pair of draws for the same agents
     noise = torch.from_numpy(np.stack([e0, e1])).to(device).contiguous()
     gumbel = sample_only(p_dev, device, SEED, STEP, 0, exp_noise=noise).cpu().numpy() > 0.5
     pn = p.numpy()
@@ -121,5 +122,5 @@ def test_philox_draws_are_never_zero_or_infinite(device):
     dec = sample_only(p, device, 99, 7, 0).cpu().numpy() > 0.5
     e0, e1 = P.exp_pair(99, 7, np.arange(n, dtype=np.uint64))
     assert (e0 > 0).all() and (e1 > 0).all() and np.isfinite(e0).all() and np.isfinite(e1).all()
-    assert (dec != threshold_decision(np.full(n, 0.5, np.float32), e0, e1)).sum() <= 3
+    assert np.array_equal(dec, np.float32(0.5) < P.infection_uniform(99, 7, np.arange(n, dtype=np.uint64)))
     assert abs(dec.mean() - 0.5) < 1e-3

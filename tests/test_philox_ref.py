@@ -27,7 +27,11 @@ def test_uniforms_and_exponentials():
     assert np.array_equal(P.u01(k << np.uint32(9)).astype(np.float64), (k.astype(np.float64) + 0.5) * 2.0 ** -23)
     e0, e1 = P.exp_pair(7, 3, np.arange(200_000))
     assert e0.dtype == np.float32 and abs(e0.mean() - 1.0) < 0.01 and abs(e1.mean() - 1.0) < 0.01
-    assert abs(np.corrcoef(e0, e1)[0, 1]) < 0.01
-    a, b = P.exp_pair(7, 3, np.array([10, 11]))          # one block serves the pair: different words
-    assert a[0] != a[1] and b[0] != b[1]
-    assert not np.array_equal(P.exp_pair(7, 4, np.arange(100))[0], e0[:100])      # the step is part of the counter
+    assert abs(np.corrcoef(e0, e1)[0, 1]) < 0.01                  # two iid Exponential(1) draws, in law
+    assert abs(e0.var() - 1.0) < 0.03 and abs(e1.var() - 1.0) < 0.03
+    theta = P.infection_uniform(7, 3, np.arange(200_000))
+    assert (theta > 0).all() and (theta < 1).all() and abs(theta.mean() - 0.5) < 0.005
+    assert np.allclose(e0 / (e0 + e1), theta, rtol=3e-7)          # the backward's draws give the forward's decision
+    a, b = P.exp_pair(7, 3, np.array([8, 9, 10, 11]))            # one block serves four agents: different words
+    assert len(set(P.infection_uniform(7, 3, np.array([8, 9, 10, 11])).tolist())) == 4 and len(set(a.tolist())) == 4
+    assert not np.array_equal(P.infection_uniform(7, 4, np.arange(100)), theta[:100])      # the step is part of the counter
