@@ -415,7 +415,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
   const int g0 = T.blk_e0[j] >> 3, g1 = T.blk_e0[j + 1] >> 3;   // groups of 8 slots
   fx_t* sums = reinterpret_cast<fx_t*>(lds_s);                    // [nk][nv] fixed-point sums (phase B)
   float* cumf = lds_s;                                            // cum of (k, lv) at float index 2*(k*nv+lv) (phase C)
-  float* tabs = lds_s + 2 * (size_t)nk * nv;  // [nk][200] pass-1 tables, then [nk][200] pass-2 weights
+  float* tabs = lds_s + 2 * ((size_t)nk * nv + 64);  // (64 scratch sums, one per lane of a wave, follow the sums)
+                                                     // [nk][200] pass-1 tables, then [nk][200] pass-2 weights
   uint32_t* vflags = reinterpret_cast<uint32_t*>(tabs + (T.leisure ? 2 * nk * 200 : 0));   // one bit per sum: not summable
   if (T.leisure) {
     for (int i = tid; i < nk * 200; i += kTileThreads) {
@@ -430,48 +431,42 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
   const uint2* cls8 = reinterpret_cast<const uint2*>(T.e_cls);
   float4* val4 = reinterpret_cast<float4*>(T.val);
   if (B.mode != 2) {
-    for (int i = tid; i < nk * nv; i += kTileThreads) sums[i] = 0;
-    for (int i = tid; i < (nk * nv + 31) / 32; i += kTileThreads) vflags[i] = 0u;
+    for (int i = tid; i < nk * nv + 64; i += kTileThreads) sums[i] = 0;
+    for (int i = tid; i < (nk * nv + 64 + 31) / 32; i += kTileThreads) vflags[i] = 0u;
     __syncthreads();
     // B: each lane takes 8 consecutive slots (48 bytes), merges runs of one venue in registers and adds
     // each run to the block's LDS sums; kVenueUnroll such groups are loaded before the first is used
+    // Straight-line: a run of one venue is summed left to right in a register and added where the run ends; every
+    // slot position issues an add, the ones that are not the end of a run (or are padding) add 0 to a scratch slot of
+    // the lane's own.  (Branches per slot made this launch issue three times the instructions: it is bound by
+    // instruction issue, SQ_ACTIVE_INST_ANY x waves per SIMD ~ 0.8.)
+    const int dummy = nk * nv + (tid & 63);
+    auto run_sums = [&](const int (&lv)[8], const float (&x)[8], int base_k) {
+      float s8 = x[0];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const bool last = (q == 7) || (lv[q + (q < 7)] != lv[q]);
+        const bool take = last && lv[q] != 0xFFFF;
+        fx_add<kFxVenue>(sums, vflags, take ? base_k + lv[q] : dummy, take ? s8 : 0.0f);
+        if (q < 7) s8 = last ? x[q + 1] : s8 + x[q + 1];
+      }
+    };
     auto add_group = [&](const uint4 raw, const float4 xa, const float4 xb, const uint2 craw) {
       const Slots8 L{{raw.x, raw.y, raw.z, raw.w}};
       const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-      if (!T.leisure) {
-        int cur = L.lv(0);
-        float acc = x[0];
+      int lv[8];
 #pragma unroll
-        for (int q = 1; q < 8; ++q) {
-          const int lv = L.lv(q);
-          if (lv == cur) {
-            acc += x[q];
-          } else {
-            if (cur != 0xFFFF) fx_add<kFxVenue>(sums, vflags, cur, acc);
-            cur = lv;
-            acc = x[q];
-          }
-        }
-        if (cur != 0xFFFF) fx_add<kFxVenue>(sums, vflags, cur, acc);
+      for (int q = 0; q < 8; ++q) lv[q] = L.lv(q);
+      if (!T.leisure) {
+        run_sums(lv, x, 0);
       } else {
         const uint32_t cw[2] = {craw.x, craw.y};
         for (int k = 0; k < nk; ++k) {
           const float* tk = tabs + k * 200;
-          int cur = L.lv(0);
-          float acc = tk[cw[0] & 0xFF] * x[0];
+          float xl[8];
 #pragma unroll
-          for (int q = 1; q < 8; ++q) {
-            const int lv = L.lv(q);
-            const float xl = tk[(cw[q >> 2] >> ((q & 3) * 8)) & 0xFF] * x[q];
-            if (lv == cur) {
-              acc += xl;
-            } else {
-              if (cur != 0xFFFF) fx_add<kFxVenue>(sums, vflags, k * nv + cur, acc);
-              cur = lv;
-              acc = xl;
-            }
-          }
-          if (cur != 0xFFFF) fx_add<kFxVenue>(sums, vflags, k * nv + cur, acc);
+          for (int q = 0; q < 8; ++q) xl[q] = tk[(cw[q >> 2] >> ((q & 3) * 8)) & 0xFF] * x[q];
+          run_sums(lv, xl, k * nv);
         }
       }
     };
@@ -526,9 +521,10 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
       float r[8];
       if (!T.leisure) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < 8; ++q) {      // straight-line: a pad slot reads venue 0 and keeps 0
           const int lv = L.lv(q);
-          r[q] = (lv != 0xFFFF) ? cumf[2 * lv] : 0.0f;
+          const float c = cumf[2 * (lv != 0xFFFF ? lv : 0)];
+          r[q] = (lv != 0xFFFF) ? c : 0.0f;
         }
       } else {
         const uint32_t cw[2] = {craw[u].x, craw[u].y};
@@ -536,10 +532,10 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
         for (int q = 0; q < 8; ++q) {
           const int lv = L.lv(q);
           const int c = (cw[q >> 2] >> ((q & 3) * 8)) & 0xFF;
+          const int li = lv != 0xFFFF ? lv : 0;
           float a = 0.0f;
-          if (lv != 0xFFFF)
-            for (int k = 0; k < nk; ++k) a += tabs[nk * 200 + k * 200 + c] * cumf[2 * (k * nv + lv)];
-          r[q] = a;
+          for (int k = 0; k < nk; ++k) a += tabs[nk * 200 + k * 200 + c] * cumf[2 * (k * nv + li)];
+          r[q] = (lv != 0xFFFF) ? a : 0.0f;
         }
       }
       val4[2 * gu] = make_float4(r[0], r[1], r[2], r[3]);

@@ -987,9 +987,9 @@ static int tiled_venues(const gj_plan* plan, const gj_step_params* p, const Grou
     } else if (G.nk[g] != 1) {
       return GJ_E_PLAN;   // several networks on one set need per-network tables
     }
-    const size_t need = (size_t)X.nk * S.max_block_venues * sizeof(fx_t) +
-                        (X.leisure ? 2 * 200 * (size_t)X.nk : 0) * sizeof(float) +
-                        ((size_t)X.nk * S.max_block_venues + 31) / 32 * 4;          // one flag bit per sum
+    const size_t n_sums = (size_t)X.nk * S.max_block_venues + 64;               // + a scratch sum per lane of a wave
+    const size_t need = n_sums * sizeof(fx_t) + (X.leisure ? 2 * 200 * (size_t)X.nk : 0) * sizeof(float) +
+                        (n_sums + 31) / 32 * 4;                                       // one flag bit per sum
     if (X.nk && need > lds) lds = need;
   }
   B.work = T->work;
