@@ -186,7 +186,9 @@ class SingleGpuHotPath:
 
 
 #: tile geometries tried by tune_geometry: {} = the size-based defaults of tiling.py
-GEOMETRY_CANDIDATES = ({}, {"eb_target": 131072, "sv_max": 16384}, {"eb_target": 65536, "sv_max": 16384})
+GEOMETRY_CANDIDATES = ({}, {"eb_target": 131072, "sv_max": 16384}, {"eb_target": 65536, "sv_max": 16384},
+                       {"eb_target": 131072, "sv_max": 16384, "slice_agents": 2048},
+                       {"eb_target": 32768, "sv_max": 16384, "slice_agents": 2048})
 
 
 def tune_geometry(world: dict, specs, betas, device, candidates=GEOMETRY_CANDIDATES, progress=None, **kw):
@@ -197,9 +199,14 @@ def tune_geometry(world: dict, specs, betas, device, candidates=GEOMETRY_CANDIDA
     compiling a world of a few 10^7 edges takes seconds."""
     best, best_ms, seen = None, float("inf"), {}
     for cand in candidates:
+        cand = dict(cand)
+        sa = cand.pop("slice_agents", None)
+        if sa is not None:        # twice the default number of slices: phase A likes it, phase D does not - measure
+            cand["slices"] = (-(-world["n_agents"] // sa), sa)
         r = SingleGpuHotPath(world, specs, betas, device, progress=None, **{**kw, **cand})
         ms = r.time_stateless()
         label = ",".join(f"{k}={v}" for k, v in cand.items()) or "default"
+        label = label.replace(" ", "")
         seen[label] = ms
         if progress:
             progress(f"geometry {label}: {ms:.3f} ms")
