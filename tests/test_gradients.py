@@ -289,7 +289,7 @@ def test_hip_backward_matches_reference(device, case):
         for n, g in zip(names, grads):
             got = 0.0 if g is None else float(g)
             ref = float(sub[f"grad_{tag}/{n}"])
-            assert got == pytest.approx(ref, rel=2e-3, abs=1e-4), (tag, n, got, ref)
+            assert got == pytest.approx(ref, rel=2e-5, abs=1e-7), (tag, n, got, ref)
 
 
 @pytest.mark.gpu
@@ -443,4 +443,4 @@ def test_hip_backward_through_symptoms_matches_reference(device):
         for n, g in zip(names, grads):
             got = 0.0 if g is None else float(g)
             ref = float(sub[f"grad_{tag}/{n}"])
-            assert got == pytest.approx(ref, rel=3e-3, abs=1e-4), (tag, n, got, ref)
+            assert got == pytest.approx(ref, rel=1e-4, abs=1e-6), (tag, n, got, ref)
