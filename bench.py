@@ -63,6 +63,10 @@ def parse():
     ap.add_argument("--direct", default="auto", choices=["auto", "off"],
                     help="pass 2 of sets with few venues straight from an LDS table of venue values (auto) or, like the "
                          "other sets, through the per-edge workspace (off)")
+    ap.add_argument("--graph", action="store_true",
+                    help="N > 1: capture the production step (kernels + RCCL collectives) in a hipGraph after the warm-up "
+                         "and replay it per timed step (13.5 us of host time per step instead of ~100; verified under RCCL "
+                         "with one rank only, hence opt-in)")
     ap.add_argument("--no-events", action="store_true",
                     help="diagnostic: time the K steps as plain gj_step calls, without HIP events between the launches")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -345,10 +349,12 @@ def main():
             tune = args.tune == "on" or (args.tune == "auto" and args.layout == "tiled" and not (set(kw) - {"device_compile", "direct"})
                                          and set_edges <= 40_000_000)
             if tune:      # small worlds compile in seconds: measure the candidate tile geometries, keep the best
-                from grad_june_amd.benchrun import tune_geometry
+                from grad_june_amd.benchrun import GEOMETRY_CANDIDATES, tune_geometry
 
                 runner, seen = tune_geometry(world, specs, betas, dev, seed=args.seed, layout=args.layout,
-                                             quarantine_threshold=args.quarantine, progress=progress, **kw)
+                                             quarantine_threshold=args.quarantine, progress=progress,
+                                             **kw, **({"candidates": [c for c in GEOMETRY_CANDIDATES if "direct" not in c]}
+                                                      if "direct" in kw else {}))
                 extra = {"geometry_tuning_ms": seen}
             else:
                 runner = SingleGpuHotPath(world, specs, betas, dev, seed=args.seed, layout=args.layout,
@@ -365,6 +371,9 @@ def main():
     for _ in range(args.warmup):
         runner.step()
     sync()
+    if args.graph and distributed and hasattr(runner, "capture"):
+        runner.capture()
+        sync()
     runner.reset_timers()
     t0 = time.perf_counter()
     # One GPU: launches are bracketed by HIP events (on the launch stream) INSIDE the timed region - on every

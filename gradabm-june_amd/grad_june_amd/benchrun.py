@@ -188,7 +188,8 @@ class SingleGpuHotPath:
 #: tile geometries tried by tune_geometry: {} = the size-based defaults of tiling.py
 GEOMETRY_CANDIDATES = ({}, {"eb_target": 131072, "sv_max": 16384}, {"eb_target": 65536, "sv_max": 16384},
                        {"eb_target": 131072, "sv_max": 16384, "slice_agents": 2048},
-                       {"eb_target": 32768, "sv_max": 16384, "slice_agents": 2048})
+                       {"eb_target": 32768, "sv_max": 16384, "slice_agents": 2048},
+                       {"eb_target": 131072, "sv_max": 16384, "direct": False})
 
 
 def tune_geometry(world: dict, specs, betas, device, candidates=GEOMETRY_CANDIDATES, progress=None, **kw):
