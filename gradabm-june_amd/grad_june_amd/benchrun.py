@@ -116,6 +116,8 @@ class SingleGpuHotPath:
             self.graph.replay()
             self.t += 1
             return
+        if getattr(self, "graph", None) is not None:      # an eager step of a captured runner: keep the device clock in step
+            self.clock.advance(1.0)
         p = self.params()
         e = self.engine
         if not timed:

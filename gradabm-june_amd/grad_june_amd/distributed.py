@@ -445,6 +445,8 @@ class DistributedHotPath:
             self.graph.replay()              # clock advance + every launch and collective of the production step
             self.t += 1
             return
+        if self.graph is not None:           # an eager (event-bracketed) step of a captured runner: keep the device clock in step
+            self.clock.advance(1.0)
         self.run_step(self.bufs, self.io, self.params, timed=timed)
         self.t += 1
 

@@ -102,4 +102,13 @@ def test_single_gpu_step_replayed_with_the_device_clock(device):
             assert torch.equal(graph.state[k], eager.state[k]), (i, k)
         assert torch.equal(graph.new_infected, eager.new_infected) and torch.equal(graph.probs, eager.probs)
     assert graph.clock.read() == (5.0, 4)
+    # an eager, event-bracketed step in between (bench.py's per-launch timing) keeps the device clock in step
+    eager.step()
+    graph.step(timed=True)
+    eager.step()
+    graph.step()
+    torch.cuda.synchronize()
+    assert graph.clock.read() == (7.0, 6)
+    for k in ("is_infected", "susceptibility", "infection_time"):
+        assert torch.equal(graph.state[k], eager.state[k]), k
     assert eager.state["is_infected"].sum().item() > 1.2 * world["state"]["is_infected"].sum()
