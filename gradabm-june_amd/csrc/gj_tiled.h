@@ -553,7 +553,10 @@ struct TDirect {          // a set whose pass 2 is taken straight from the venue
   const float* cum;       // [V * stride]
   int64_t plane_stride;   // elements of one plane
   int32_t K, planes;      // K entries per agent and plane (1, or 2: a pair of columns per plane)
-  int32_t V, stride, nk, _pad;
+  int32_t V, stride, nk;
+  int32_t region;         // which of the two LDS table regions its venue values are staged in
+  int32_t group_venues;   // venues per staging group (== V unless the table is larger than region 0)
+  int32_t _pad;
   int32_t raw, leisure;
   int32_t table[GJ_MAX_NETS_PER_SET];
   int32_t age75[GJ_MAX_NETS_PER_SET];
@@ -580,7 +583,9 @@ struct TileDArgs {
   // "direct" form of pass 2 (sets with few venues, tiling.py build_ell): no per-edge workspace
   TDirect direct[GJ_MAX_DIRECT];
   int32_t n_direct;
-  int32_t table_floats;   // LDS floats available for one group of venue values
+  int32_t table_floats;   // LDS floats of table region 0 (+ 64 of slack); region 1 follows
+  int32_t table1_floats;  // LDS floats of table region 1 (0: none - every table is staged in region 0, one after the other)
+  int32_t _pad3;
   int32_t day_type, transpose;
   const uint8_t* cls;
   const float* tables;
@@ -658,7 +663,7 @@ __device__ __forceinline__ void direct_add(const TileDArgs& D, const TDirect& T,
                                            uint32_t qmask, const float* wtab, const float* tab, int v0, int nv,
                                            int n_local, int tid, const DirectBatch& b) {
   constexpr int K = 2;
-  const int nk = T.nk;
+  const int nk = T.nk, stride = T.stride;       // tab is the venues' cum in memory order: [venue][stride]
 #pragma unroll
   for (int u = 0; u < kQuadsPerLane; ++u) {
     const int q = tid + u * kTileThreads;
@@ -684,7 +689,7 @@ __device__ __forceinline__ void direct_add(const TileDArgs& D, const TDirect& T,
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int c = 0; c < K; ++c) x[j][c] = tab[idx[j][c]];
+        for (int c = 0; c < K; ++c) x[j][c] = tab[idx[j][c] * stride];
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -694,11 +699,10 @@ __device__ __forceinline__ void direct_add(const TileDArgs& D, const TDirect& T,
         float w[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) w[j] = wtab[k * 200 + ((b.cls[u] >> (8 * j)) & 0xFF)];
-        const float* tk = tab + k * nv;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int c = 0; c < K; ++c) x[j][c] += w[j] * tk[idx[j][c]];
+          for (int c = 0; c < K; ++c) x[j][c] += w[j] * tab[idx[j][c] * stride + k];
       }
     }
 #pragma unroll
@@ -711,45 +715,34 @@ __device__ __forceinline__ void direct_add(const TileDArgs& D, const TDirect& T,
   }
 }
 
-// The venues [v0, v0 + nv) of a direct set into LDS as tab[k][venue] (and, with the first group of a leisure set,
-// the receiving side's class weights).  Callers bracket this with barriers.
-__device__ __forceinline__ void direct_table(const TileDArgs& D, const TDirect& T, float* wtab, float* tab, int v0,
+// Staging of one group of a direct set's venue values: LDS-DMA (global_load_lds: no registers, asynchronous until the
+// next vmcnt(0), which hipcc places in front of __syncthreads()), in memory order [venue][stride].  64-float pieces,
+// one per wave-instruction; the last piece re-reads the last element into the region's slack.  With the first group
+// of a leisure set the receiving side's class weights are computed into that set's weight buffer.
+__device__ __forceinline__ void direct_stage(const TileDArgs& D, const TDirect& T, float* wtab, float* tab, int v0,
                                              int nv, int tid) {
-  const int nk = T.nk;
   if (T.leisure && v0 == 0) {
-    for (int i = tid; i < nk * 200; i += kTileThreads) {
+    for (int i = tid; i < T.nk * 200; i += kTileThreads) {
       const int k = i / 200, c = i % 200;
       const float l = D.tables[(int64_t)T.table[k] * GJ_TABLE_SIZE + D.day_type * 200 + c];
       const float lw = T.age75[k] ? l * (((c % 100) > 75) ? 1.0f : 0.0f) : l;
       wtab[i] = D.transpose ? l : lw;       // weights of the receiving side (pass 2)
     }
   }
-  // batches of independent (clamped, unconditional) loads: a plain copy loop waits out one L2 round trip per element
+#ifndef GJ_DIAG_NO_DIRECT_TABLE
   const float* src = T.cum + (int64_t)v0 * T.stride;
-  const int n = nv * T.stride, stride = T.stride;
-  constexpr int kLoads = 16;
-  for (int i0 = tid; i0 < n; i0 += kLoads * kTileThreads) {
-    float x[kLoads];
-#pragma unroll
-    for (int u = 0; u < kLoads; ++u) x[u] = src[min(i0 + u * kTileThreads, n - 1)];
-#pragma unroll
-    for (int u = 0; u < kLoads; ++u) {
-      const int i = i0 + u * kTileThreads;
-      if (i >= n) continue;
-      if (stride == 1) {
-        tab[i] = x[u];
-      } else {                                     // tab is [k][venue]
-        const int v = i / stride, k = i - v * stride;
-        if (k < nk) tab[k * nv + v] = x[u];
-      }
-    }
-  }
+  const int n = nv * T.stride;
+  const int lane = tid % kWave, wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+  for (int p = wave; p * kWave < n; p += kTileWaves)
+    __builtin_amdgcn_global_load_lds(src + min(p * kWave + lane, n - 1), tab + p * kWave, 4, 0, 0);
+#endif
 }
 
-// All direct sets of the slice.  Work items are (set, venue group, plane) in order; the rows of item i + 1 are
-// loaded while item i is summed (a memory round trip costs ~4 us when every CU streams: nothing here waits for one
-// that was not issued a whole item earlier), `first` holds the rows of the first item, issued before the caller's
-// own LDS phase.  LDS: the class weights of a leisure set, then the venue table of the current group.
+// All direct sets of the slice.  Work items are (set, venue group, plane) in order.  While item i is summed, the rows
+// of item i + 1 are on their way to registers and - when it opens a new venue group that was given the other LDS
+// region - its venue values on their way to LDS (DMA): a memory round trip costs 4-10 us while every CU streams, and
+// with one workgroup per CU nothing else would hide it.  `cur` holds the rows of the first item, issued before the
+// caller's own LDS phase.  LDS: two class-weight buffers (sets alternate), table region 0, table region 1.
 __device__ __forceinline__ bool direct_next(const TileDArgs& D, int& t, int& v0, int& plane) {
   const TDirect& T = D.direct[t];
   if (plane + 1 < T.planes) {
@@ -757,9 +750,8 @@ __device__ __forceinline__ bool direct_next(const TileDArgs& D, int& t, int& v0,
     return true;
   }
   plane = 0;
-  const int vpg = max(1, D.table_floats / T.nk);
-  if (v0 + vpg < T.V) {
-    v0 += vpg;
+  if (v0 + T.group_venues < T.V) {
+    v0 += T.group_venues;
     return true;
   }
   v0 = 0;
@@ -770,30 +762,33 @@ __device__ __forceinline__ bool direct_next(const TileDArgs& D, int& t, int& v0,
 __device__ __forceinline__ void direct_sets(const TileDArgs& D, float (&acc)[kQuadsPerLane][4], uint32_t qmask,
                                             float* lds, int64_t base, int n_local, int tid, DirectBatch& cur,
                                             uint64_t diag_t0 = 0) {
-  float* wtab = lds;
-  float* tab = lds + kClassWeightFloats;
+  auto wtab_of = [&](int t) { return lds + (t & 1) * kClassWeightFloats; };
+  auto tab_of = [&](const TDirect& T) {
+    return lds + 2 * kClassWeightFloats + (T.region ? D.table_floats + kWave : 0);
+  };
   int t = 0, v0 = 0, plane = 0;
+  __syncthreads();                              // the LDS is free: every lane has its sums in registers
+  direct_stage(D, D.direct[0], wtab_of(0), tab_of(D.direct[0]), 0, min(D.direct[0].group_venues, D.direct[0].V), tid);
   bool more = true;
   while (more) {
     const TDirect& T = D.direct[t];
-    const int nv = min(max(1, D.table_floats / T.nk), T.V - v0);
-    if (plane == 0) {                           // a new venue group: stage its values
-      __syncthreads();                          // the LDS is free: the sums are in registers, the previous table is used up
-#ifndef GJ_DIAG_NO_DIRECT_TABLE
-      direct_table(D, T, wtab, tab, v0, nv, tid);
-#endif
-      __syncthreads();
-    }
+    const int nv = min(T.group_venues, T.V - v0);
+    if (plane == 0) __syncthreads();            // this group's values have landed (vmcnt(0) + barrier) - and its rows
 #ifdef GJ_DIAG_STAMPS
     if (threadIdx.x == 0 && D.trans_susc && t < 4)
       D.trans_susc[(int64_t)blockIdx.x * D.slice_agents + 8 + 2 * t] = (float)(__builtin_amdgcn_s_memtime() - diag_t0);
 #endif
     int tn = t, vn = v0, pn = plane;
     more = direct_next(D, tn, vn, pn);
+    const bool new_group = more && pn == 0;
+    // the next group's values can be staged while this one is read if they go to the other region
+    const bool overlap = new_group && D.direct[tn].region != T.region;
+    if (overlap)
+      direct_stage(D, D.direct[tn], wtab_of(tn), tab_of(D.direct[tn]), vn, min(D.direct[tn].group_venues, D.direct[tn].V - vn), tid);
     DirectBatch nxt;
     if (more) direct_load(D, D.direct[tn], base, n_local, tid, pn, nxt);     // in flight while this item is summed
 #ifndef GJ_DIAG_NO_DIRECT_ADD
-    direct_add(D, T, acc, qmask, wtab, tab, v0, nv, n_local, tid, cur);
+    direct_add(D, T, acc, qmask, wtab_of(t), tab_of(T), v0, nv, n_local, tid, cur);
 #else
     if (cur.w[0][0] == 0x12345678u && cur.cls[0] == 77u) acc[0][0] = 1.0f;     // keep the loads alive
 #endif
@@ -801,6 +796,10 @@ __device__ __forceinline__ void direct_sets(const TileDArgs& D, float (&acc)[kQu
     if (threadIdx.x == 0 && D.trans_susc && t < 4)
       D.trans_susc[(int64_t)blockIdx.x * D.slice_agents + 9 + 2 * t] = (float)(__builtin_amdgcn_s_memtime() - diag_t0);
 #endif
+    if (new_group && !overlap) {                // same region: only once every wave is done reading this group
+      __syncthreads();
+      direct_stage(D, D.direct[tn], wtab_of(tn), tab_of(D.direct[tn]), vn, min(D.direct[tn].group_venues, D.direct[tn].V - vn), tid);
+    }
     if (more) cur = nxt;
     t = tn;
     v0 = vn;

@@ -1037,7 +1037,6 @@ static int tiled_agents(const gj_plan* plan, const gj_agent_state* st, const gj_
   D.transpose = p->transpose;
   D.cls = plan->agent_class;
   D.tables = plan->tables;
-  int64_t need = 0;
   const int64_t owned_slices = (plan->n_agents + T->slice_agents - 1) / T->slice_agents;
   for (int g = 0; g < G.n; ++g) {
     const int s = G.set[g];
@@ -1071,15 +1070,39 @@ static int tiled_agents(const gj_plan* plan, const gj_agent_state* st, const gj_
     } else if (G.nk[g] != 1) {
       return GJ_E_PLAN;
     }
-    need = need > (int64_t)X.nk * X.V ? need : (int64_t)X.nk * X.V;
   }
-  D.table_floats = 0;
+  D.table_floats = D.table1_floats = 0;
+  D._pad3 = 0;
   if (D.n_direct) {
-    const int64_t avail = 160 * 1024 / 4 - kClassWeightFloats;     // the slice's sums are in registers by then
-    D.table_floats = (int32_t)(need < avail ? need : avail);
-    if (T->direct_table_floats > 0 && T->direct_table_floats < D.table_floats) D.table_floats = T->direct_table_floats;
-    if (D.table_floats < GJ_MAX_NETS_PER_SET) D.table_floats = GJ_MAX_NETS_PER_SET;
-    const size_t direct_lds = 4 * ((size_t)kClassWeightFloats + (size_t)D.table_floats);
+    // LDS of the direct form (the slice's sums are in registers by then): two class-weight buffers, then two table
+    // regions, each followed by 64 floats of slack for the last DMA piece.  Region 0 takes the largest table (in
+    // groups of venues if it is larger than everything), region 1 what is left: a set whose whole table fits there is
+    // staged while the previous set - in region 0 - is still being read.
+    const int64_t budget = 160 * 1024 / 4 - 2 * kClassWeightFloats - 2 * kWave;
+    int64_t largest = 0;
+    for (int t = 0; t < D.n_direct; ++t) {
+      const int64_t sz = (int64_t)D.direct[t].V * D.direct[t].stride;
+      largest = largest > sz ? largest : sz;
+    }
+    int64_t cap0 = largest < budget ? largest : budget;
+    if (T->direct_table_floats > 0 && T->direct_table_floats < cap0) cap0 = T->direct_table_floats;
+    if (cap0 < GJ_MAX_NETS_PER_SET) cap0 = GJ_MAX_NETS_PER_SET;
+    int64_t cap1 = budget - cap0;
+    if (T->direct_table_floats > 0 && T->direct_table_floats < cap1) cap1 = T->direct_table_floats;
+    int prev_region = -1;
+    for (int t = 0; t < D.n_direct; ++t) {
+      TDirect& X = D.direct[t];
+      const int64_t sz = (int64_t)X.V * X.stride;
+      X.region = (prev_region == 0 && sz <= cap1) ? 1 : 0;
+      const int64_t cap = X.region ? cap1 : cap0;
+      X.group_venues = sz <= cap ? X.V : (int32_t)(cap / X.stride);
+      if (X.group_venues < 1) return GJ_E_PLAN;
+      X._pad = 0;
+      prev_region = X.region;
+    }
+    D.table_floats = (int32_t)cap0;
+    D.table1_floats = (int32_t)cap1;
+    const size_t direct_lds = 4 * ((size_t)2 * kClassWeightFloats + (size_t)cap0 + kWave + (size_t)cap1 + kWave);
     if (direct_lds > lds) lds = direct_lds;
   }
   {

@@ -260,8 +260,8 @@ DIRECT_WEIGHT_FLOATS = 8 * 200   # per-class weights of up to GJ_MAX_NETS_PER_SE
 
 def direct_table_floats(slice_agents: int = 0) -> int:
     """Floats of LDS for a group of venue values in phase D's direct form: by then the slice's sums are in
-    registers, so all of the LDS but the leisure class weights."""
-    return LDS_BYTES // 4 - DIRECT_WEIGHT_FLOATS
+    registers, so all of the LDS but two leisure class-weight buffers and the slack of the two staging regions."""
+    return LDS_BYTES // 4 - 2 * DIRECT_WEIGHT_FLOATS - 2 * 64
 
 
 def direct_columns(degree_max: int) -> int:
