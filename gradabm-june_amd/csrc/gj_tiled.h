@@ -72,6 +72,18 @@ __device__ __forceinline__ float fx_read(const fx_t* sums, const uint32_t* flags
 }
 constexpr int kFxVenue = 36, kFxAgent = 32;
 
+// Element `idx` of a wave-uniform array through a 32-bit BYTE offset (scalar base + vector offset addressing: no
+// 64-bit address arithmetic per lane - phases A and D issue instructions, they do not wait).  The array must be
+// smaller than 4 GiB (check_tiled).
+template <typename T>
+__device__ __forceinline__ T at32(const T* base, int idx) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (uint64_t)((uint32_t)idx * (uint32_t)sizeof(T)));
+}
+template <typename T>
+__device__ __forceinline__ void put32(T* base, int idx, T v) {
+  *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + (uint64_t)((uint32_t)idx * (uint32_t)sizeof(T))) = v;
+}
+
 struct TSetA {            // what phases A and D need of one set
   const uint16_t* a_la;
   const int32_t* tile_sptr;
@@ -149,7 +161,7 @@ __device__ __forceinline__ int batch_desc_load(const TSetA& T, int c_base, int n
   static_assert(U * W <= kWave, "a batch's descriptors must fit one wave-wide load");
   const int32_t* desc = reinterpret_cast<const int32_t*>(T.chunk_desc);
   const int u_l = min(lane / W, U - 1), k_l = lane % W;
-  return desc[(int64_t)(c_base + min(c0 + u_l, n_chunks - 1)) * W + k_l];
+  return at32(desc, (c_base + min(c0 + u_l, n_chunks - 1)) * W + k_l);
 }
 
 template <bool WIDE, int U>
@@ -206,7 +218,7 @@ __device__ __forceinline__ void scatter_batches(const TSetA& T, const float* lds
     const int cc = min(c, n_chunks - 1);                      // past the end: a harmless re-load of the last chunk
     word = batch_desc_load<WIDE, kU>(T, c_base, n_chunks, cc, lane);   // first: the slots wait on it
 #pragma unroll
-    for (int u = 0; u < kU; ++u) la[u] = T.a_la[min(seg0 + (cc + u) * kWave + lane, seg1 - 1)];
+    for (int u = 0; u < kU; ++u) la[u] = at32(T.a_la, min(seg0 + (cc + u) * kWave + lane, seg1 - 1));
   };
   auto stage2 = [&](int c, int word, const int (&la)[kU]) {
     int slot[kU];
@@ -214,7 +226,7 @@ __device__ __forceinline__ void scatter_batches(const TSetA& T, const float* lds
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
       const int i = seg0 + (c + u) * kWave + lane;
-      if ((c + u < n_chunks) && (i < seg1)) T.val[slot[u]] = lds_x[la[u]];
+      if ((c + u < n_chunks) && (i < seg1)) put32(T.val, slot[u], lds_x[la[u]]);
     }
   };
   int c0 = wave * kU;
@@ -280,7 +292,7 @@ __device__ __forceinline__ void gather_set(const TSetA& T, fx_t* lds_acc, uint32
     const int cc = min(c, n_chunks - 1);                      // past the end: a harmless re-load of the last chunk
     word = batch_desc_load<WIDE, kU>(T, c_base, n_chunks, cc, lane);
 #pragma unroll
-    for (int u = 0; u < kU; ++u) la[u] = T.a_la[min(seg0 + (cc + u) * kWave + lane, seg1 - 1)];
+    for (int u = 0; u < kU; ++u) la[u] = at32(T.a_la, min(seg0 + (cc + u) * kWave + lane, seg1 - 1));
   };
   auto values = [&](int c, int word, float (&v)[kU]) {        // the batch's value loads (issued, not waited for)
     int slot[kU];
@@ -289,7 +301,7 @@ __device__ __forceinline__ void gather_set(const TSetA& T, fx_t* lds_acc, uint32
     for (int u = 0; u < kU; ++u) {
       const int i = seg0 + (c + u) * kWave + lane;
       const bool ok = (c + u < n_chunks) && (i < seg1);
-      v[u] = T.val[ok ? slot[u] : 0];
+      v[u] = at32(T.val, ok ? slot[u] : 0);
     }
   };
   auto add = [&](int c, const int (&la)[kU], const float (&v)[kU]) {

@@ -888,6 +888,9 @@ static int check_tiled(const gj_plan* plan) {
     if (!S.blk_v0 || !S.blk_e0 || !S.tile_sptr || !S.tile_jpos || !S.chunk_ptr) return GJ_E_NULL;
     if (plan->sets[s].n_edges > 0 && (!S.e_lv || !S.a_la || !S.val || !S.chunk_desc)) return GJ_E_NULL;
     if (S.max_block_venues < 1 || S.max_block_venues > 65536) return GJ_E_PLAN;
+    // phases A and D address val / a_la / chunk_desc with 32-bit byte offsets: < 2^30 edges per set (a larger set
+    // is split over several edge sets of the same venue type)
+    if (plan->sets[s].n_edges >= ((int64_t)1 << 30) - 8 * (int64_t)S.n_blocks) return GJ_E_RANGE;
     if (S.ell_k) {   // direct form of pass 2: 16-bit venue ids, one 2/4/8/16-byte row per agent
       if (S.ell_k != 2 && S.ell_k != 4 && S.ell_k != 8) return GJ_E_PLAN;
       if (!S.ell) return GJ_E_NULL;
