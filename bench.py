@@ -188,15 +188,18 @@ def _es(n):
     return edge_set_of(n)
 
 
+STEP_KERNEL_SOURCES = ("gj_device.h", "gj_tiled.h", "gradjune_hip.hip")
+
+
 def csrc_hash() -> str:
-    """sha256 over the kernel sources and the ABI header (what a PMC profile is valid for)."""
+    """sha256 over the sources of the step's kernels (what a PMC profile is valid for; the graph-compile kernels of
+    gj_compile.hip and the declarations in the header do not change the step's traffic)."""
     import hashlib
 
     h = hashlib.sha256()
-    paths = sorted(os.path.join(ROOT, "gradabm-june_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "gradabm-june_amd", "csrc")))
-    for path in paths + [os.path.join(ROOT, "include", "gradjune_hip.h")]:
-        with open(path, "rb") as f:
-            h.update(os.path.basename(path).encode() + b"\0" + f.read())
+    for name in STEP_KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "gradabm-june_amd", "csrc", name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()
 
 

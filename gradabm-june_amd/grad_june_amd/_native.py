@@ -10,7 +10,7 @@ import ctypes as C
 import os
 from typing import Optional
 
-GJ_ABI_VERSION = 2
+GJ_ABI_VERSION = 3
 GJ_MAX_SETS = 12
 GJ_MAX_NETS = 16
 GJ_MAX_NETS_PER_SET = 8
@@ -210,6 +210,38 @@ SYMBOLS = {
     "gj_event_elapsed_ms": (C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),
     "gj_event_destroy": (C.c_int, [_vp]),
 }
+
+# ---- graph compile on the device (include/gradjune_hip.h, "graph compile") ----
+GJ_COMPILE_COUNTS = 8
+GJ_CC_BLOCKS, GJ_CC_SLOTS, GJ_CC_CHUNKS, GJ_CC_MULTI, GJ_CC_OWNED_EDGES, GJ_CC_MAX_DEGREE, GJ_CC_ERROR = 0, 1, 2, 3, 4, 5, 7
+
+
+class CompileSet(C.Structure):
+    _fields_ = [
+        ("agent", _vp), ("venue", _vp), ("agent_class", _vp),
+        ("n_edges", C.c_int64), ("n_agents", C.c_int64), ("n_ext_agents", C.c_int64),
+        ("n_venues", C.c_int32), ("n_slices", C.c_int32), ("slice_agents", C.c_int32),
+        ("sv_max", C.c_int32), ("eb_target", C.c_int32), ("n_blocks", C.c_int32),
+    ]
+
+
+class CompileOut(C.Structure):
+    _fields_ = [
+        ("blk_e0", _vp), ("e_lv", _vp), ("e_cls", _vp), ("a_la", _vp), ("tile_sptr", _vp), ("tile_jpos", _vp),
+        ("chunk_ptr", _vp), ("chunk_desc", _vp), ("slots_cap", C.c_int64), ("chunks_cap", C.c_int64),
+    ]
+
+
+_i64p = C.POINTER(C.c_int64)
+SYMBOLS.update({
+    "gj_compile_capacity": (C.c_int, [C.POINTER(CompileSet), _i64p, _i64p, _i64p]),
+    "gj_compile_workspace_bytes": (C.c_int, [C.POINTER(CompileSet), _i64p]),
+    "gj_compile_blocks": (C.c_int, [C.POINTER(CompileSet), _vp, C.c_int32, _vp, _vp, C.c_int64, _vp]),
+    "gj_compile_tiles": (C.c_int, [C.POINTER(CompileSet), _vp, C.POINTER(CompileOut), _vp, _vp, C.c_int64, _vp]),
+    "gj_compile_wide_descriptors": (C.c_int, [C.POINTER(CompileSet), C.POINTER(CompileOut), C.c_int32, _vp, _vp, _vp]),
+    "gj_compile_ell_degrees": (C.c_int, [C.POINTER(CompileSet), _vp, _vp, _vp]),
+    "gj_compile_ell": (C.c_int, [C.POINTER(CompileSet), C.c_int32, C.c_int64, _vp, _vp, _vp, C.c_int64, _vp]),
+})
 
 _lib: Optional[C.CDLL] = None
 

@@ -52,7 +52,7 @@ class SingleGpuHotPath:
                  split_epilogue: bool = False, device_compile: bool = False, **plan_kw):
         self.device = torch.device(device)
         self.layout = layout
-        if device_compile:           # build the tiled arrays on the GPU (tiling_device), not with numpy on the host
+        if device_compile:           # build the tiled arrays on the GPU (the compile kernels, tiling_native), not with numpy on the host
             plan_kw["device"] = self.device
         host = compile_plan(world["n_agents"], world["edge_sets"], age=world["age"], sex=world["sex"],
                             layout=layout, progress=progress, **plan_kw)

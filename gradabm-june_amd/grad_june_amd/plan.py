@@ -95,22 +95,14 @@ def _host(a) -> np.ndarray:
     return np.asarray(a)
 
 
-def _edge_set_on_device(name: str, es: dict, n_ext: int, device) -> HostEdgeSet:
-    """compile_edge_set(csr=False) with the range checks done where the edge lists live."""
-    import torch
-
+def _edge_set_on_device(name: str, es: dict, n_ext: int) -> HostEdgeSet:
+    """compile_edge_set(csr=False) for a set whose edge lists stay on the device (the index range checks are part of
+    the compile kernels, tiling_native)."""
     people = _host(es["people"])
     n_venues = int(len(people))
-    t = lambda a: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))).to(device)
-    agent, venue = t(es["agent"]).reshape(-1), t(es["venue"]).reshape(-1)
-    E = int(agent.numel())
+    E = int(es["agent"].numel() if hasattr(es["agent"], "numel") else np.asarray(es["agent"]).size)
     if E >= 2**31 or n_ext >= 2**31 or n_venues >= 2**31:
         raise ValueError("edge set exceeds int32 indexing")
-    if E:
-        if int(agent.min()) < 0 or int(agent.max()) >= n_ext:
-            raise ValueError(f"{name}: agent index out of range")
-        if int(venue.min()) < 0 or int(venue.max()) >= n_venues:
-            raise ValueError(f"{name}: venue index out of range")
     return HostEdgeSet(name, n_venues, E, None, None, p_contact(people), None, None)
 
 
@@ -265,8 +257,9 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
     nets_per_set: infection networks that may be active on a set at once (a venue block keeps one
     8-byte LDS sum per venue and network; default 1, and 6 for the leisure sets).
     desc_wide: chunk descriptor format of the tiled layout (None: per set, from its tile sizes).
-    device: build the tiled arrays with torch ops on this device (tiling_device.build_tiled_device: the
-    same arrays, born in HBM); the edge lists may then be torch tensors.  Default: numpy on the host.
+    device: build the tiled arrays on this HIP device with the library's compile kernels (tiling_native /
+    csrc/gj_compile.hip: the same arrays, born in HBM); the edge lists may then be torch tensors.  Default: numpy on
+    the host (tiling.py, the specification).
     direct: which sets take pass 2 in the "direct" form (tiling.build_ell: phase C skipped, phase D reads the
     venues' cum from an LDS table).  None = every set whose sizes allow it (tiling.direct_eligible), False =
     none, or a collection of set names (must be eligible).
@@ -287,7 +280,7 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
     slot = 0
     for sid, (name, es) in enumerate(edge_sets.items()):
         if device is not None and not want_csr:
-            hs = _edge_set_on_device(name, es, n_ext, device)
+            hs = _edge_set_on_device(name, es, n_ext)
         else:
             hs = compile_edge_set(name, _host(es["agent"]), _host(es["venue"]), _host(es["people"]), n_agents, n_ext,
                                   csr=want_csr)
@@ -296,14 +289,11 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
             k = (nets_per_set or {}).get(name, 6 if name in leisure_sets else 1)
             use_cls = cls_all if (name in leisure_sets and cls_all is not None) else None
             if device is not None:
-                import torch
+                from .tiling_native import build_tiled_native
 
-                from .tiling_device import build_tiled_device
-
-                dev_t = lambda a: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))).to(device)
-                hs.tiled = build_tiled_device(name, dev_t(es["agent"]), dev_t(es["venue"]), hs.n_venues, hs.v_pcontact,
-                                              S, SA, agent_class=None if use_cls is None else dev_t(use_cls),
-                                              sv_max=max(16, sv_max // max(1, k)), eb_target=eb_target, wide=desc_wide)
+                hs.tiled = build_tiled_native(name, es["agent"], es["venue"], hs.n_venues, hs.v_pcontact, S, SA,
+                                              agent_class=use_cls, sv_max=max(16, sv_max // max(1, k)),
+                                              eb_target=eb_target, wide=desc_wide, device=device, n_ext_agents=n_ext)
             else:
                 hs.tiled = TL.build_tiled(name, es["agent"], es["venue"], hs.n_venues, hs.v_pcontact, S, SA,
                                           agent_class=use_cls, sv_max=max(16, sv_max // max(1, k)),
@@ -346,14 +336,12 @@ def _attach_ell(t: TL.TiledEdgeSet, es: dict, n_agents: int, slice_agents: int, 
     if direct is False or t.n_edges == 0:
         return
     n_owned_slices = max(1, -(-n_agents // slice_agents))
+    builder = None
     if device is not None:
-        import torch
+        from .tiling_native import EllBuilder
 
-        from .tiling_device import build_ell_device, ell_degree_max
-
-        dev_t = lambda a: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))).to(device)
-        agent, venue = dev_t(es["agent"]), dev_t(es["venue"])
-        e_owned, dmax = ell_degree_max(agent, n_agents)
+        builder = EllBuilder(es["agent"], es["venue"], t.n_venues, n_agents, slice_agents, device)
+        e_owned, dmax = builder.degrees()
     else:
         agent = np.asarray(_host(es["agent"]), dtype=np.int64).ravel()
         venue = _host(es["venue"])
@@ -366,8 +354,8 @@ def _attach_ell(t: TL.TiledEdgeSet, es: dict, n_agents: int, slice_agents: int, 
         raise ValueError(f"edge set {t.name}: not eligible for the direct form of pass 2")
     if not ok or (direct is not None and not forced):
         return
-    if device is not None:
-        t.ell, t.ell_k = build_ell_device(agent, venue, n_agents, n_owned_slices, slice_agents)
+    if builder is not None:
+        t.ell, t.ell_k = builder.build(dmax)
     else:
         t.ell, t.ell_k = TL.build_ell(agent, venue, n_agents, n_owned_slices, slice_agents)
 

@@ -1,0 +1,169 @@
+"""The tiled layout of an edge set built ON THE DEVICE by the library's compile kernels (row f4 of SURVEY section 8:
+"native graph compile"; ``csrc/gj_compile.hip``, C ABI ``gj_compile_*``).
+
+``build_tiled_native`` is ``tiling.build_tiled`` and ``build_ell_native`` is ``tiling.build_ell`` with every O(E)
+step a HIP kernel (key construction, rocPRIM radix sort and scans, scatter of the 16-bit local indices, chunk
+descriptors, the greedy venue-block walk): the reference's unsorted COO ``edge_index`` goes in as it lies in HBM, the
+arrays of ``gj_tiled_set`` come out in HBM, bit-identical to the numpy specification
+(tests/test_gpu_compile_native.py).  A 15 M-edge set compiles in ~20 ms instead of ~2 s of numpy.  torch is used for
+what the tier allows it: device memory (the output buffers, the workspace) and the stream.
+
+16-bit fields are returned as int16 tensors holding the uint16 bit patterns (torch has no uint16 arithmetic),
+which is also how the numpy build's arrays are uploaded.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _native as N
+from . import tiling as TL
+
+_ERRORS = {1: "agent index out of range", 2: "venue index out of range", 3: "more venue blocks than expected",
+           4: "too many venue blocks for the wide descriptor's j0 field"}
+
+
+def _i64(t: torch.Tensor, device) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        t = torch.from_numpy(np.ascontiguousarray(np.asarray(t, dtype=np.int64)))
+    return t.reshape(-1).to(device=device, dtype=torch.int64).contiguous()
+
+
+class _Session:
+    """One edge set's compile: the ctypes argument block, the counts and the workspace."""
+
+    def __init__(self, agent, venue, n_venues, n_agents, n_ext, n_slices, slice_agents, sv_max, eb_target, agent_class,
+                 device):
+        self.dev = torch.device(device)
+        if self.dev.type != "cuda":
+            raise RuntimeError("the native graph compile runs on a HIP device (host build: tiling.build_tiled)")
+        self.lib = N.load()
+        self.agent, self.venue = _i64(agent, self.dev), _i64(venue, self.dev)
+        if self.agent.numel() != self.venue.numel():
+            raise ValueError("agent / venue index lengths differ")
+        self.cls = None
+        if agent_class is not None:
+            c = agent_class if isinstance(agent_class, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(agent_class))
+            self.cls = c.to(device=self.dev, dtype=torch.uint8).contiguous()
+        self.set = N.CompileSet(N.ptr(self.agent), N.ptr(self.venue), N.ptr(self.cls), self.agent.numel(), int(n_agents),
+                                int(n_ext), int(n_venues), int(n_slices), int(slice_agents), int(sv_max), int(eb_target), 0)
+        self.counts = torch.zeros(N.GJ_COMPILE_COUNTS, dtype=torch.int32, device=self.dev)
+        self.ws = None
+
+    def workspace(self):
+        need = C.c_int64(0)
+        N.check(self.lib.gj_compile_workspace_bytes(C.byref(self.set), C.byref(need)), "gj_compile_workspace_bytes")
+        if self.ws is None or self.ws.numel() < need.value:
+            self.ws = None
+            self.ws = torch.empty(need.value, dtype=torch.uint8, device=self.dev)
+        return self.ws
+
+    def read_counts(self, name: str):
+        c = self.counts.cpu().numpy()
+        if c[N.GJ_CC_ERROR]:
+            raise ValueError(f"{name}: {_ERRORS.get(int(c[N.GJ_CC_ERROR]), 'compile error')}")
+        return c
+
+
+def build_tiled_native(name: str, agent_index, venue_index, n_venues: int, v_pcontact, n_slices: int, slice_agents: int,
+                       agent_class=None, sv_max: int = TL.SV_MAX, eb_target: int = TL.EB_TARGET,
+                       wide: Optional[bool] = None, device=None, n_ext_agents: Optional[int] = None) -> TL.TiledEdgeSet:
+    if slice_agents > 65536 or sv_max > 65536:
+        raise ValueError("local indices are 16-bit")
+    dev = torch.device(device if device is not None else agent_index.device)
+    v_pc = (torch.as_tensor(np.asarray(v_pcontact, dtype=np.float32)) if not isinstance(v_pcontact, torch.Tensor)
+            else v_pcontact.to(torch.float32)).to(dev)
+    S = int(n_slices)
+    n_ext = S * int(slice_agents) if n_ext_agents is None else int(n_ext_agents)
+    se = _Session(agent_index, venue_index, n_venues, 0, n_ext, S, slice_agents, sv_max, eb_target, agent_class, dev)
+    E = se.agent.numel()
+    i32 = lambda n: torch.empty(max(int(n), 1), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        st = N.current_stream()
+        lib = se.lib
+        blk_cap, slots_cap, chunks_cap = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        N.check(lib.gj_compile_capacity(C.byref(se.set), C.byref(blk_cap), None, None), "gj_compile_capacity")
+        blk_v0 = i32(blk_cap.value + 1)
+        ws = se.workspace()
+        N.check(lib.gj_compile_blocks(C.byref(se.set), N.ptr(blk_v0), blk_cap.value, N.ptr(se.counts), N.ptr(ws),
+                                      ws.numel(), st), "gj_compile_blocks")
+        c = se.read_counts(name)
+        J = int(c[N.GJ_CC_BLOCKS])
+        if J == 0:
+            z = torch.zeros(1, dtype=torch.int32, device=dev)
+            return TL.TiledEdgeSet(name, n_venues, 0, S, 0, z, z, torch.zeros(0, dtype=torch.int16, device=dev), None,
+                                   torch.zeros(0, dtype=torch.int16, device=dev), z.clone(),
+                                   torch.zeros(0, dtype=torch.int32, device=dev), v_pc, 0,
+                                   torch.zeros(S + 1, dtype=torch.int32, device=dev),
+                                   torch.zeros((0, 4), dtype=torch.int32, device=dev))
+        se.set.n_blocks = J
+        N.check(lib.gj_compile_capacity(C.byref(se.set), None, C.byref(slots_cap), C.byref(chunks_cap)),
+                "gj_compile_capacity")
+        blk_e0, sptr, jpos, chunk_ptr = i32(J + 1), i32(S * J + 1), i32(S * J), i32(S + 1)
+        e_lv = torch.empty(slots_cap.value, dtype=torch.int16, device=dev)
+        e_cls = torch.empty(slots_cap.value, dtype=torch.uint8, device=dev) if se.cls is not None else None
+        a_la = torch.empty(max(E, 1), dtype=torch.int16, device=dev)
+        desc = i32(chunks_cap.value * 4)
+        out = N.CompileOut(N.ptr(blk_e0), N.ptr(e_lv), N.ptr(e_cls), N.ptr(a_la), N.ptr(sptr), N.ptr(jpos),
+                           N.ptr(chunk_ptr), N.ptr(desc), slots_cap.value, chunks_cap.value)
+        ws = se.workspace()
+        N.check(lib.gj_compile_tiles(C.byref(se.set), N.ptr(blk_v0), C.byref(out), N.ptr(se.counts), N.ptr(ws),
+                                     ws.numel(), st), "gj_compile_tiles")
+        c = se.read_counts(name)
+        n_slots, n_chunks, n_multi = int(c[N.GJ_CC_SLOTS]), int(c[N.GJ_CC_CHUNKS]), int(c[N.GJ_CC_MULTI])
+        if wide is None:
+            wide = n_chunks > 0 and (n_multi / n_chunks) > TL.WIDE_MIN_SHARE
+        if wide:
+            desc = i32(n_chunks * 8)
+            N.check(lib.gj_compile_wide_descriptors(C.byref(se.set), C.byref(out), n_chunks, N.ptr(desc),
+                                                    N.ptr(se.counts), st), "gj_compile_wide_descriptors")
+            se.read_counts(name)
+            chunk_desc = desc[: n_chunks * 8].reshape(n_chunks, 8)
+        else:
+            chunk_desc = desc[: n_chunks * 4].reshape(n_chunks, 4).clone()      # (drops the upper-bound tail)
+        se.ws = None
+    return TL.TiledEdgeSet(
+        name=name, n_venues=n_venues, n_edges=E, n_slices=S, n_blocks=J,
+        blk_v0=blk_v0[: J + 1].clone(), blk_e0=blk_e0, e_lv=e_lv[:n_slots].clone(),
+        e_cls=None if e_cls is None else e_cls[:n_slots].clone(), a_la=a_la[:E],
+        tile_sptr=sptr, tile_jpos=jpos, v_pcontact=v_pc, n_slots=n_slots,
+        chunk_ptr=chunk_ptr, chunk_desc=chunk_desc.contiguous(), desc_wide=bool(wide))
+
+
+class EllBuilder:
+    """The ELL rows of the direct form of pass 2, in two steps: ``degrees()`` (what tiling.direct_eligible needs),
+    then ``build()`` if the set qualifies."""
+
+    def __init__(self, agent_index, venue_index, n_venues: int, n_agents: int, slice_agents: int, device):
+        n_owned_slices = max(1, -(-int(n_agents) // int(slice_agents)))
+        self.rows = n_owned_slices * int(slice_agents)
+        self.n_agents = int(n_agents)
+        # (sv_max / eb_target / n_slices do not matter for the ELL stages; n_slices bounds the agent ids)
+        self.se = _Session(agent_index, venue_index, n_venues, n_agents, n_agents, n_owned_slices, slice_agents,
+                           TL.SV_MAX, TL.EB_TARGET, None, device)
+        self.degree = torch.empty(self.n_agents + 1, dtype=torch.int32, device=self.se.dev)
+
+    def degrees(self):
+        """(edges of owned agents, their maximum degree)."""
+        se = self.se
+        with torch.cuda.device(se.dev):
+            N.check(se.lib.gj_compile_ell_degrees(C.byref(se.set), N.ptr(self.degree), N.ptr(se.counts),
+                                                  N.current_stream()), "gj_compile_ell_degrees")
+        c = se.counts.cpu().numpy()
+        return int(c[N.GJ_CC_OWNED_EDGES]), int(c[N.GJ_CC_MAX_DEGREE])
+
+    def build(self, degree_max: int):
+        """(int16 [planes, rows, 2] holding uint16 bit patterns, K) - after degrees()."""
+        se = self.se
+        K = TL.direct_columns(max(1, degree_max))
+        ell = torch.empty((K // 2, self.rows, 2), dtype=torch.int16, device=se.dev)
+        with torch.cuda.device(se.dev):
+            ws = se.workspace()
+            N.check(se.lib.gj_compile_ell(C.byref(se.set), K, self.rows, N.ptr(self.degree), N.ptr(ell), N.ptr(ws),
+                                          ws.numel(), N.current_stream()), "gj_compile_ell")
+            torch.cuda.current_stream().synchronize()
+        se.ws = None
+        return ell, K

@@ -22,7 +22,7 @@ _CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 
 #: device layout the API mirrors compile worlds into: "tiled" (LDS-tiled fast path, default) or "csr"
 DEFAULT_LAYOUT = os.environ.get("GRAD_JUNE_AMD_LAYOUT", "tiled")
-#: compile the contact graph on the GPU (tiling_device) instead of numpy on the host: worlds of 10^7+ agents
+#: compile the contact graph on the GPU (gj_compile_* kernels, tiling_native) instead of numpy on the host: worlds of 10^7+ agents
 #: then compile in about a second.  Opt-in (GRAD_JUNE_AMD_DEVICE_COMPILE=1 or set this flag); same arrays.
 DEVICE_COMPILE = os.environ.get("GRAD_JUNE_AMD_DEVICE_COMPILE", "0") == "1"
 

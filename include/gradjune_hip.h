@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GJ_ABI_VERSION 2
+#define GJ_ABI_VERSION 3
 
 #define GJ_MAX_SETS 12        /* distinct agent<->venue edge sets in a world (reference: 6)   */
 #define GJ_MAX_NETS 16        /* infection networks active in one step (reference: <= 11)      */
@@ -394,6 +394,71 @@ int gj_clock_advance(gj_clock* clock, float delta_now, void* stream);
  * unpack: dst[index[i]] = in[i]             for i < n      (halo slots of remote agents)   */
 int gj_pack_f32(int64_t n, const int32_t* index, const float* src, float* out, void* stream);
 int gj_unpack_f32(int64_t n, const int32_t* index, const float* in, float* dst, void* stream);
+
+/* ================= graph compile on the device ("native graph compile") =================
+ * The tiled layout of ONE edge set (the arrays of gj_tiled_set) built in HBM from the reference's data format:
+ * the unsorted COO `data["attends_<set>"].edge_index` (int64 [2, E]; grad_june/ has no compile step of its own -
+ * torch_geometric walks this COO on every propagate, infection_networks/base.py:78-80).  Same arrays, bit for bit, as
+ * the numpy specification grad_june_amd/tiling.py (build_tiled, wide_descriptors, build_ell), which documents them.
+ * Kernels: key construction, rocPRIM radix sort / scans (hipcub), scatter of the 16-bit local indices, chunk
+ * descriptors.  The library allocates nothing: the caller passes every output at its upper-bound size and one
+ * workspace (gj_compile_workspace_bytes), reads `counts` (device int32[GJ_COMPILE_COUNTS]) after a stage and trims.
+ *   1. gj_compile_blocks        venue degrees, range checks, the venue blocks         -> counts[GJ_CC_BLOCKS] = J
+ *   2. gj_compile_tiles         everything else, with 4-word chunk descriptors        -> SLOTS, CHUNKS, MULTI
+ *   3. gj_compile_wide_descriptors   (optional) the 8-word descriptor format for sets with small tiles
+ *   4. gj_compile_ell_degrees / gj_compile_ell    the ELL rows of the direct form of pass 2
+ * counts[GJ_CC_ERROR] != 0 after a stage: 1 agent index out of range, 2 venue index out of range, 3 more venue
+ * blocks than blk_cap, 4 wide descriptor field overflow.                                                           */
+#define GJ_COMPILE_COUNTS 8
+#define GJ_CC_BLOCKS 0       /* J: venue blocks                                                        */
+#define GJ_CC_SLOTS 1        /* length of the block-major arrays (every block padded to 8 slots)       */
+#define GJ_CC_CHUNKS 2       /* 64-edge chunks of the slice-major order                                */
+#define GJ_CC_MULTI 3        /* chunks that span more than two tiles (share > 1 %: use wide descriptors) */
+#define GJ_CC_OWNED_EDGES 4  /* edges whose agent is owned (< n_agents)                                */
+#define GJ_CC_MAX_DEGREE 5   /* largest number of edges of one owned agent                             */
+#define GJ_CC_ERROR 7
+
+typedef struct gj_compile_set {
+  const int64_t* agent;        /* [n_edges] edge_index[0]: agent ids, owned then halo, < n_ext_agents            */
+  const int64_t* venue;        /* [n_edges] edge_index[1]: venue ids < n_venues                                  */
+  const uint8_t* agent_class;  /* [owned + halo agents] or NULL; non-NULL: e_cls is written (leisure sets)        */
+  int64_t n_edges;             /* < 2^30                                                                         */
+  int64_t n_agents;            /* owned agents (the ELL rows)                                                    */
+  int64_t n_ext_agents;        /* owned + halo agents, <= n_slices * slice_agents                                */
+  int32_t n_venues;
+  int32_t n_slices, slice_agents;   /* S, SA <= 65536                                                            */
+  int32_t sv_max, eb_target;        /* venues per block <= 65536, edges per block aimed for                      */
+  int32_t n_blocks;                 /* J, as stage 1 returned it (stage 1 itself: ignored)                       */
+} gj_compile_set;
+
+typedef struct gj_compile_out {       /* device buffers at their upper-bound sizes, see gj_compile_capacity      */
+  int32_t* blk_e0;       /* [J + 1]                                                                              */
+  uint16_t* e_lv;        /* [slots_cap]   0xFFFF = pad                                                            */
+  uint8_t* e_cls;        /* [slots_cap] or NULL                                                                   */
+  uint16_t* a_la;        /* [n_edges]                                                                             */
+  int32_t* tile_sptr;    /* [S * J + 1]                                                                           */
+  int32_t* tile_jpos;    /* [S * J]                                                                               */
+  int32_t* chunk_ptr;    /* [S + 1]                                                                               */
+  int32_t* chunk_desc;   /* [chunks_cap * 4]                                                                      */
+  int64_t slots_cap, chunks_cap;
+} gj_compile_out;
+
+/* Upper bounds for the caller's allocations: blocks (before stage 1), slots and chunks (J known or not).          */
+int gj_compile_capacity(const gj_compile_set* set, int64_t* blk_cap, int64_t* slots_cap, int64_t* chunks_cap);
+/* Bytes of workspace that suffice for every stage of this set (J = set->n_blocks, or its upper bound when 0).      */
+int gj_compile_workspace_bytes(const gj_compile_set* set, int64_t* bytes);
+int gj_compile_blocks(const gj_compile_set* set, int32_t* blk_v0 /* [blk_cap + 1] */, int32_t blk_cap,
+                      int32_t* counts, void* workspace, int64_t workspace_bytes, void* stream);
+int gj_compile_tiles(const gj_compile_set* set, const int32_t* blk_v0, const gj_compile_out* out, int32_t* counts,
+                     void* workspace, int64_t workspace_bytes, void* stream);
+int gj_compile_wide_descriptors(const gj_compile_set* set, const gj_compile_out* out, int32_t n_chunks,
+                                int32_t* desc8 /* [n_chunks * 8] */, int32_t* counts, void* stream);
+/* degree[a] (int32 [n_agents + 1], caller-owned) = edges of owned agent a; counts[OWNED_EDGES], counts[MAX_DEGREE]. */
+int gj_compile_ell_degrees(const gj_compile_set* set, int32_t* degree, int32_t* counts, void* stream);
+/* ell: uint16 [ell_k / 2 planes][rows][2] (gj_tiled_set.ell), rows = owned slices * slice_agents; `degree` as
+ * returned by gj_compile_ell_degrees.                                                                              */
+int gj_compile_ell(const gj_compile_set* set, int32_t ell_k, int64_t rows, const int32_t* degree, uint16_t* ell,
+                   void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Average device time of the last-timed dominant kernel is measured by the caller with
  * hipEvents; these two helpers let a ctypes caller do that on the stream it launches on

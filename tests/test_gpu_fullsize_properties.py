@@ -321,7 +321,7 @@ def test_step_is_capturable_in_a_hip_graph(device):
 
 
 def test_device_compiled_plan_is_identical(device):
-    """The contact graph compiled on the GPU (tiling_device, row f4) equals the numpy-compiled one array for
+    """The contact graph compiled on the GPU (gj_compile_* kernels, row f4) equals the numpy-compiled one array for
     array, and a step on it gives bitwise the same state."""
     from grad_june_amd.plan import _host, compile_plan
 

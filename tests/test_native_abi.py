@@ -65,7 +65,8 @@ def test_ctypes_layout_equals_what_a_c_compiler_sees(tmp_path):
         pytest.skip("no C compiler")
     pairs = {"gj_edge_set": N.EdgeSet, "gj_tiled_set": N.TiledSet, "gj_tiled": N.Tiled, "gj_plan": N.Plan,
              "gj_network": N.Network, "gj_step_params": N.StepParams, "gj_agent_state": N.AgentState,
-             "gj_step_io": N.StepIO, "gj_symptoms_params": N.SymptomsParams}
+             "gj_step_io": N.StepIO, "gj_symptoms_params": N.SymptomsParams, "gj_compile_set": N.CompileSet,
+             "gj_compile_out": N.CompileOut}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void) {"]
     for cname, ct in pairs.items():
         lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
@@ -88,3 +89,13 @@ def test_argument_errors_do_not_need_a_gpu(lib):
     assert lib.gj_step(None, None, None, None, None) == -1
     assert lib.gj_sample_infect(-1, None, None, 0, 0, 0, 0.0, None, None, None, None, None) == -2
     assert lib.gj_pack_f32(0, None, None, None, None) == 0
+    # graph compile: argument checks come before any device work
+    assert lib.gj_compile_capacity(None, None, None, None) == -1
+    cs = N.CompileSet(None, None, None, 0, 0, 0, 0, 1, 64, 16, 16, 0)
+    cap = [ctypes.c_int64(0) for _ in range(3)]
+    assert lib.gj_compile_capacity(ctypes.byref(cs), *[ctypes.byref(c) for c in cap]) == 0
+    assert cap[0].value >= 1 and cap[2].value >= 1
+    cs.slice_agents = 70000                                   # local agent indices are 16-bit
+    assert lib.gj_compile_capacity(ctypes.byref(cs), None, None, None) == -2
+    cs.slice_agents, cs.n_edges = 64, 5                       # edges without edge lists
+    assert lib.gj_compile_blocks(ctypes.byref(cs), None, 1, None, None, 0, None) == -1

@@ -103,43 +103,12 @@ def test_empty_set_and_slice_choice():
     assert b.tolist() == [0, 2, 3, 5]
 
 
-@pytest.mark.parametrize("A,V,E,sa,svmax,eb,wide", [(5000, 700, 20000, 512, 128, 3000, None), (300, 5, 4000, 64, 65536, 1 << 30, None),
-                                                    (2000, 3000, 6000, 64, 16, 16, True), (3000, 600, 30000, 128, 32, 600, None),
-                                                    (64, 1, 10, 64, 16, 16, False), (10000, 9000, 15000, 1024, 4096, 2000, True)])
-def test_device_build_equals_numpy_build(A, V, E, sa, svmax, eb, wide):
-    """tiling_device.build_tiled_device (torch ops; here on CPU tensors) is bit-identical to build_tiled."""
-    import torch
-
-    from grad_june_amd.tiling_device import build_tiled_device
-
-    rng = np.random.default_rng(A * 7 + V)
-    agent, venue = random_set(rng, A, V, E, big=E // 3)
-    S = -(-A // sa)
-    pc = rng.random(V).astype(np.float32)
-    cls = rng.integers(0, 200, A).astype(np.uint8)
-    ref = build_tiled("x", agent, venue, V, pc, S, sa, agent_class=cls, sv_max=svmax, eb_target=eb, wide=wide)
-    got = build_tiled_device("x", torch.from_numpy(agent), torch.from_numpy(venue), V, pc, S, sa,
-                             agent_class=torch.from_numpy(cls), sv_max=svmax, eb_target=eb, wide=wide)
-    assert (got.n_blocks, got.n_slots, got.n_edges, got.desc_wide) == (ref.n_blocks, ref.n_slots, ref.n_edges, ref.desc_wide)
-    for k in ("blk_v0", "blk_e0", "tile_sptr", "tile_jpos", "chunk_ptr", "chunk_desc", "e_cls", "v_pcontact"):
-        assert np.array_equal(getattr(got, k).numpy(), getattr(ref, k)), k
-    for k in ("e_lv", "a_la"):
-        assert np.array_equal(getattr(got, k).numpy().view(np.uint16), getattr(ref, k)), k
-    # and the empty set
-    e = build_tiled_device("e", torch.zeros(0, dtype=torch.int64), torch.zeros(0, dtype=torch.int64), 0,
-                           np.zeros(0, np.float32), 4, 64)
-    assert e.n_blocks == 0 and e.n_edges == 0
-
-
 @pytest.mark.parametrize("A,V,E,sa,owned", [(5000, 700, 9000, 512, 5000), (300, 5, 400, 64, 300), (1000, 65534, 1500, 128, 700),
                                             (64, 1, 64, 64, 64)])
 def test_ell_form_of_pass2(A, V, E, sa, owned):
-    """tiling.build_ell (and its torch twin) + the emulation of phase D's direct form against bincount sums:
+    """tiling.build_ell + the emulation of phase D's direct form against bincount sums:
     agents beyond ``owned`` are halo agents and get no row; groups of venues give the same result."""
-    import torch
-
     from grad_june_amd.tiling import build_ell, direct_columns, direct_eligible, ell_rows, emulate_direct_pass2
-    from grad_june_amd.tiling_device import build_ell_device, ell_degree_max
 
     rng = np.random.default_rng(A + E)
     agent = np.concatenate([np.arange(min(A, E)), rng.integers(0, A, max(0, E - A))])    # degree 1 or 2, some 3+
@@ -154,9 +123,6 @@ def test_ell_form_of_pass2(A, V, E, sa, owned):
     assert ((ell != 0xFFFF).sum(1)[:owned] == deg).all() and (ell[owned:] == 0xFFFF).all()
     for a in (0, owned // 2, owned - 1):       # COO order inside a row
         assert np.array_equal(ell[a][: deg[a]], venue[agent == a])
-    got, Kd = build_ell_device(torch.from_numpy(agent), torch.from_numpy(venue), owned, S_owned, sa)
-    assert Kd == K and np.array_equal(got.numpy().view(np.uint16), ell3)
-    assert ell_degree_max(torch.from_numpy(agent), owned) == (int((agent < owned).sum()), int(deg.max()))
     cum = rng.random(V).astype(np.float32)
     ref = np.bincount(agent[agent < owned], weights=cum[venue[agent < owned]].astype(np.float64), minlength=owned)
     for gv in (None, max(1, V // 3)):

@@ -44,7 +44,7 @@ def lib_of(label):
 def build(label, defs):
     os.makedirs(VAR, exist_ok=True)
     cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), *FLAGS, *[f"-D{d}" for d in defs], "-o", lib_path(label),
-           os.path.join(CSRC, "gradjune_hip.hip")]
+           os.path.join(CSRC, "gradjune_hip.hip"), os.path.join(CSRC, "gj_compile.hip")]
     subprocess.run(cmd, check=True)
 
 
