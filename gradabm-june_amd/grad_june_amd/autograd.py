@@ -56,14 +56,11 @@ def _transposed_passes(engine, p, bufs, scratch, x, nets, betas, cum_fwd):
     [d loss / d log_beta per network of ``nets``]).  ``scratch`` is the transmission buffer of ``bufs``."""
     plan = engine.plan
     n = plan.host.n_agents
-    # The tiled passes sum in fixed point (2^-40 / 2^-36 resolution, |value| < 4e6 / 7e7): scales chosen for the
+    # The tiled passes sum in fixed point (2^-36 / 2^-32 resolution, |value| <= 16384 / 262144): scales chosen for the
     # forward's transmissions.  A cotangent has whatever magnitude the user's loss gives it (an MSE on case counts:
     # 1e5; a normalised loss: 1e-10), so x is brought to max |x| in [0.5, 1) by a power of two first and the results
     # are scaled back - exact, the passes being linear - without a host synchronisation.
-    peak = x.abs().max()
-    scale = torch.where((peak > 0) & torch.isfinite(peak), torch.exp2(torch.ceil(torch.log2(peak.clamp_min(1e-45)))),
-                        torch.ones_like(peak))
-    scale = torch.where(torch.isfinite(scale) & (scale > 0), scale, torch.ones_like(scale))
+    scale = _power_of_two_scale(x.abs().max())
     scratch[:n].copy_(x / scale)
     tbar = torch.empty(n, dtype=torch.float32, device=plan.device)
     io_t = engine.io(trans_susc=tbar)
@@ -72,24 +69,41 @@ def _transposed_passes(engine, p, bufs, scratch, x, nets, betas, cum_fwd):
         engine.quarantine_transmission(bufs, p)                # q * x for the masked sets
         for phase in (1, 5):
             engine.step_phase(bufs, p, io_t, phase)
-        grads: List[torch.Tensor] = []
-        per_set_k = {}
-        for net in nets:
-            es = plan.networks[net.name].edge_set
-            k = per_set_k.get(es, 0)
-            per_set_k[es] = k + 1
-            i = plan.host.set_index[es]
-            pc = plan.keep[i]["v_pc"].double()
-            beta = float(betas[net.name])
-            prod = cum_fwd[es][:, k].double() * plan.cum_of(es)[:, k].double()
-            dot = (torch.where(pc > 0, prod / (beta * pc), torch.zeros_like(prod)).sum() if beta != 0.0
-                   else prod.sum() * 0)
-            grads.append((dot * scale.double() * math.log(10.0)).to(torch.float32))
+        grads = [g.to(torch.float32) for g in _beta_gradients(plan, nets, betas, cum_fwd, scale)]
         for phase in (6, 4):
             engine.step_phase(bufs, p, io_t, phase)            # tbar = d loss / d transmission (of x / scale)
     finally:
         p.transpose = 0
     return tbar * scale, grads
+
+
+def _beta_gradients(plan, nets, betas, cum_fwd, scale, weights_of=None) -> List[torch.Tensor]:
+    """ln(10) * sum_v cum_n[v] * cum'_n[v] / (beta_n * p_contact[v]) per network, from the forward's and the
+    transposed pass's per-venue sums (``plan.cum_of`` holds the latter).  ``weights_of(edge set)``: this rank's
+    weight of every venue (multi-GPU: the ranks' values are summed by the caller)."""
+    grads: List[torch.Tensor] = []
+    per_set_k = {}
+    for net in nets:
+        es = plan.networks[net.name].edge_set
+        k = per_set_k.get(es, 0)
+        per_set_k[es] = k + 1
+        i = plan.host.set_index[es]
+        pc = plan.keep[i]["v_pc"].double()
+        beta = float(betas[net.name])
+        prod = cum_fwd[es][:, k].double() * plan.cum_of(es)[:, k].double()
+        w = weights_of(es) if weights_of is not None else None
+        if w is not None:
+            prod = prod * w
+        dot = (torch.where(pc > 0, prod / (beta * pc), torch.zeros_like(prod)).sum() if beta != 0.0
+               else prod.sum() * 0)
+        grads.append(dot * scale.double() * math.log(10.0))
+    return grads
+
+
+def _power_of_two_scale(peak: torch.Tensor) -> torch.Tensor:
+    scale = torch.where((peak > 0) & torch.isfinite(peak), torch.exp2(torch.ceil(torch.log2(peak.clamp_min(1e-45)))),
+                        torch.ones_like(peak))
+    return torch.where(torch.isfinite(scale) & (scale > 0), scale, torch.ones_like(scale))
 
 
 def _param_grads(nets, grads):
@@ -163,6 +177,114 @@ class HotPathStep(torch.autograd.Function):
                                             N.ptr(grad_inf), N.ptr(grad_time), N.current_stream()),
                 "gj_adjoint_transmission")
         return (None, grad_susc, grad_inf, grad_time, *_param_grads(nets, grads))
+
+
+class DistributedHotPathStep(torch.autograd.Function):
+    """``HotPathStep`` on one rank of a multi-GPU job (``distributed.DistributedHotPath``): the same inputs and
+    outputs for the rank's OWNED agents.  The forward is the multi-rank launch sequence; the backward runs the
+    transposed passes with the forward's communication pattern (the cotangents of halo agents travel by the same
+    all-to-all as their transmissions, the transposed per-venue sums by the same all-reduce), and ends with one
+    all-reduce of the step's d loss / d log_beta - so every rank's ``log_beta.grad`` is the whole world's gradient,
+    equal to the single-GPU run's.  Every rank must back-propagate the same graph (a loss built from the rank-summed
+    result series: ``distributed_api.DistributedRunner``)."""
+
+    @staticmethod
+    def forward(ctx, env, susc, inf, time, *log_betas):
+        hp, params_of, fixed, stage, exp_noise = (env[k] for k in ("hp", "params_of", "fixed", "stage", "exp_noise"))
+        plan = hp.engine.plan
+        n = plan.host.n_agents
+        out_s, out_i, out_t = (t.detach().to(torch.float32).clone().contiguous() for t in (susc, inf, time))
+        new_inf = torch.empty(n, dtype=torch.float32, device=plan.device)
+        bufs = AgentBuffers(plan, **fixed, infection_time=out_t, is_infected=out_i, susceptibility=out_s,
+                            transmission=hp.state["transmission"], q_transmission=hp.state["q_transmission"],
+                            current_stage=stage)
+        hp.run_step(bufs, hp.engine.io(new_infected=new_inf, exp_noise=exp_noise), params_of)
+        ctx.env = env
+        ctx.save_for_backward(susc.detach().to(torch.float32).contiguous(), inf.detach().to(torch.float32).contiguous(),
+                              time.detach().to(torch.float32).contiguous())
+        return out_s, out_i, out_t, new_inf
+
+    @staticmethod
+    def backward(ctx, g_susc, g_inf, g_time, g_new):
+        env = ctx.env
+        hp, params_of, fixed, stage, exp_noise, nets = (env[k] for k in ("hp", "params_of", "fixed", "stage",
+                                                                          "exp_noise", "nets"))
+        susc0, inf0, time0 = ctx.saved_tensors
+        engine = hp.engine
+        plan, lib, dev = engine.plan, N.load(), engine.plan.device
+        n, n_ext = plan.host.n_agents, plan.host.n_ext_agents
+        p = params_of(None)
+
+        def f32(g):
+            return None if g is None else g.detach().to(torch.float32).contiguous()
+
+        g_susc, g_inf, g_time, g_new = f32(g_susc), f32(g_inf), f32(g_time), f32(g_new)
+        ones = torch.ones(n, dtype=torch.float32, device=dev)
+        scratch = torch.zeros(n_ext, dtype=torch.float32, device=dev)
+        scratch_q = torch.zeros(n_ext, dtype=torch.float32, device=dev) if p.has_quarantine else None
+        acc = torch.empty(n, dtype=torch.float32, device=dev)
+        bufs = AgentBuffers(plan, **fixed, infection_time=time0, is_infected=inf0, susceptibility=ones,
+                            transmission=scratch, q_transmission=scratch_q, current_stage=stage)
+        cum_fwd = {}
+
+        def keep_forward_sums():
+            for net in nets:
+                es = plan.networks[net.name].edge_set
+                if es not in cum_fwd:
+                    cum_fwd[es] = plan.cum_of(es).clone()
+
+        # ---- recompute the forward of the two passes from the saved pre-state, across the ranks ---------------
+        p.transpose = 0
+        engine.step_phase(bufs, p, engine.io(trans_susc=acc), 0)              # transmission (+ q * transmission)
+        hp.sparse_passes(bufs, engine.io(trans_susc=acc), p, between=keep_forward_sums)
+        # ---- elementwise adjoint of epilogue + sampler + infect_people (owned agents) ----------------------------
+        x = torch.empty(n, dtype=torch.float32, device=dev)
+        grad_susc = torch.empty(n, dtype=torch.float32, device=dev)
+        grad_time = torch.empty(n, dtype=torch.float32, device=dev)
+        N.check(lib.gj_adjoint_sample(n, N.ptr(susc0), N.ptr(time0), N.ptr(acc), N.ptr(exp_noise), int(p.seed),
+                                      int(p.step), int(p.agent_offset), float(p.now), float(p.delta_time),
+                                      N.ptr(g_susc), N.ptr(g_inf), N.ptr(g_time), N.ptr(g_new), N.ptr(x),
+                                      N.ptr(grad_susc), N.ptr(grad_time), N.current_stream()), "gj_adjoint_sample")
+        # ---- transposed passes on x = susc0 * ts_bar: one scale for the whole world -------------------------------
+        scale = _power_of_two_scale(hp.all_reduce_max(x.abs().max().reshape(1)).reshape(()))
+        scratch.zero_()
+        scratch[:n].copy_(x / scale)
+        tbar = torch.empty(n, dtype=torch.float32, device=dev)
+        grads: List[torch.Tensor] = []
+
+        def beta_gradients():
+            grads.extend(_beta_gradients(plan, nets, env["betas"], cum_fwd, scale, weights_of=hp.venue_weights))
+
+        p.transpose = 1
+        try:
+            engine.quarantine_transmission(bufs, p)                            # q * x for the masked sets
+            hp.sparse_passes(bufs, engine.io(trans_susc=tbar), p, between=beta_gradients)
+        finally:
+            p.transpose = 0
+        tbar = tbar * scale
+        total = hp.all_reduce_sum(torch.stack(grads)) if grads else None        # fp64: the world's gradient
+        grads32 = [total[i].to(torch.float32) for i in range(len(grads))]
+        # ---- through the transmission profile (owned agents) --------------------------------------------------------
+        grad_inf = torch.empty(n, dtype=torch.float32, device=dev)
+        st0 = AgentBuffers(plan, **fixed, infection_time=time0, is_infected=inf0, susceptibility=ones,
+                           transmission=scratch)
+        N.check(lib.gj_adjoint_transmission(n, C.byref(st0.c), float(p.now), N.ptr(tbar), N.ptr(g_inf),
+                                            N.ptr(grad_inf), N.ptr(grad_time), N.current_stream()),
+                "gj_adjoint_transmission")
+        return (None, grad_susc, grad_inf, grad_time, *_param_grads(nets, grads32))
+
+
+class AllReduceSum(torch.autograd.Function):
+    """Sum of a tensor over the ranks whose gradient is the identity: every rank evaluates the SAME loss on the
+    summed value, so d loss / d (this rank's term) = d loss / d sum, which every rank already holds."""
+
+    @staticmethod
+    def forward(ctx, hp, x):
+        return hp.all_reduce_sum(x.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, g
 
 
 class NetworksForward(torch.autograd.Function):

@@ -401,6 +401,7 @@ class DistributedHotPath:
         self.log = EventLog()
         self.graph = None
         self._clock_ptr = None
+        self._venue_weights: Dict[str, torch.Tensor] = {}
 
     def params(self, only=None):
         """only: None = every network; "halo" / "partial" = the networks on sets of that exchange mode;
@@ -528,6 +529,74 @@ class DistributedHotPath:
                 r.wait()
             e.step_phase(bufs, p_g, io, 6)                                # C of the group
         e.step_phase(bufs, p_all, io, 3)                                  # D + epilogue: all sets
+
+    # ---- what the differentiable step (autograd.DistributedHotPathStep) needs -------------------------------
+    def sparse_passes(self, bufs, io, p, between=None) -> None:
+        """The two sparse passes of one step on ``bufs``' extended transmission arrays, in sequence and WITHOUT the
+        decision: halo all-to-all, phases A + B, all-reduce of the partial sums, ``between()`` (every set's complete
+        per-venue sums are in ``plan.cum_of`` then), phases C + D (the per-agent sums go to ``io.trans_susc``).
+        With ``p.transpose = 1`` this is the adjoint of the same operator - its communication pattern is the
+        forward's, the cotangents of the halo agents travel like their transmissions."""
+        e = self.engine
+        if self.halo is not None:
+            self.halo.exchange(bufs.tensors["transmission"])
+            if self.exchange_q and p.has_quarantine:
+                self.halo.exchange(bufs.tensors["q_transmission"], which=1)
+        e.step_phase(bufs, p, io, 1)
+        e.step_phase(bufs, p, io, 5)
+        if self.halo is not None:
+            self._all_reduce(False)
+        if between is not None:
+            between()
+        e.step_phase(bufs, p, io, 6)
+        e.step_phase(bufs, p, io, 4)
+
+    def venue_weights(self, set_name: str) -> Optional[torch.Tensor]:
+        """Weight of this rank's copy of every venue of a set in a sum over the WORLD's venues (the gradient of a
+        network's beta is such a sum): a partition of unity over the ranks.  Partial-sum sets hold every venue
+        complete on every rank after the all-reduce - rank 0 counts them; a halo set's venue lives on every rank
+        that owns one of its attendees - the rank owning the attendee with the smallest id counts it.
+        None = weight 1 everywhere (a single rank)."""
+        if self.world_size == 1 or self.halo is None:
+            return None
+        w = self._venue_weights.get(set_name)
+        if w is None:
+            rw = self.rw
+            V = len(rw.edge_sets[set_name]["people"])
+            if rw.modes[set_name] == "partial":
+                w = torch.full((V,), 1.0 if self.rank == 0 else 0.0, dtype=torch.float64, device=self.device)
+            else:
+                es = rw.edge_sets[set_name]
+                ext = np.asarray(es["agent"], dtype=np.int64)
+                gid = np.where(ext < rw.n_local, ext + self.a0,
+                               rw.halo_global[np.clip(ext - rw.n_local_pad, 0, max(0, rw.n_halo - 1))] if rw.n_halo
+                               else ext + self.a0)
+                first = np.full(V, np.iinfo(np.int64).max, dtype=np.int64)
+                np.minimum.at(first, np.asarray(es["venue"], dtype=np.int64), gid)
+                mine = (first >= self.a0) & (first < self.a0 + rw.n_local)
+                w = torch.from_numpy(mine.astype(np.float64)).to(self.device)
+            self._venue_weights[set_name] = w
+        return w
+
+    def all_reduce_max(self, x: torch.Tensor) -> torch.Tensor:
+        return self._reduce_small(x, "max")
+
+    def all_reduce_sum(self, x: torch.Tensor) -> torch.Tensor:
+        return self._reduce_small(x, "sum")
+
+    def _reduce_small(self, x: torch.Tensor, op: str) -> torch.Tensor:
+        import torch.distributed as dist
+
+        if self.halo is None or self.world_size == 1 or not dist.is_initialized():
+            return x
+        rop = dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM
+        if dist.get_backend(self.group) == "gloo":
+            tmp = x.cpu()
+            dist.all_reduce(tmp, op=rop, group=self.group)
+            return tmp.to(x.device)
+        x = x.clone()
+        dist.all_reduce(x, op=rop, group=self.group)
+        return x
 
     def reset_timers(self):
         self.log.clear()

@@ -8,8 +8,10 @@ multi-rank launch sequence of ``distributed.DistributedHotPath.run_step`` (halo 
 all-reduce), with timer, policies and ``log_beta`` evaluated per step exactly as ``GradJune`` does.  Per-agent
 work (symptoms, state updates) is local; the per-step result series are summed over the ranks once, after the
 loop.  Sampling noise is Philox keyed by the GLOBAL agent id and sums are fixed-point, so the series equal the
-single-GPU run's for the same seed (tests/test_gpu_distributed_virtual.py).  Forward simulation only: the
-differentiable mode stays single-GPU.
+single-GPU run's for the same seed (tests/test_gpu_distributed_virtual.py).  Differentiable like the single-GPU
+``Runner`` (example_scripts/run_model.py:9-11): with a ``log_beta`` that requires grad the step is the autograd node
+``autograd.DistributedHotPathStep`` and the result series are summed over the ranks on the graph, so a loss on
+``results`` back-propagated on EVERY rank leaves the whole world's gradient in every rank's ``log_beta.grad``.
 
     torch.manual_seed(seed)                    # the same seed on every rank
     runner = DistributedRunner.from_parameters(params)          # params["system"]["device"] = this rank's GPU
@@ -86,9 +88,9 @@ class DistributedGradJune(GradJune):
             raise RuntimeError("call partition(data) first")
         nets = self.infection_networks
         active = nets.active_networks(timer, self.policies)
-        if torch.is_grad_enabled() and any(isinstance(n.log_beta, torch.Tensor) and n.log_beta.requires_grad
-                                           for n in active):
-            raise NotImplementedError("the multi-GPU step is forward-only; differentiable runs use one GPU")
+        differentiable = torch.is_grad_enabled() and (
+            any(isinstance(n.log_beta, torch.Tensor) and n.log_beta.requires_grad for n in active)
+            or any(data["agent"][k].requires_grad for k in ("susceptibility", "is_infected", "infection_time")))
         self.policies.apply(timer=timer, data=data)
         engine, dev, n = hp.engine, hp.device, hp.rw.n_local
         for net in active:
@@ -103,13 +105,18 @@ class DistributedGradJune(GradJune):
         self.n_steps += 1
         day_type = 0 if timer.day_type == "weekday" else 1
 
+        now, duration, seed = timer.now, timer.duration, self.rng_seed      # (the backward pass calls params_of later)
+        q_threshold = qp.threshold if has_q else math.inf
+
         def params_of(sets):
             names = [net.name for net in active if sets is None or net.edge_set in sets]
-            return engine.params(now=timer.now, delta_time=timer.duration, day_type=day_type, active=names, betas=betas,
-                                 has_quarantine=has_q, q_threshold=qp.threshold if has_q else math.inf,
-                                 seed=self.rng_seed, step=step, agent_offset=hp.a0)
+            return engine.params(now=now, delta_time=duration, day_type=day_type, active=names, betas=betas,
+                                 has_quarantine=has_q, q_threshold=q_threshold, seed=seed, step=step,
+                                 agent_offset=hp.a0)
 
         ag = data["agent"]
+        if differentiable:
+            return self._hot_path_differentiable(data, hp, params_of, active, betas, has_q, exp_noise, want_probs)
 
         def f32(t):
             if t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
@@ -137,6 +144,33 @@ class DistributedGradJune(GradJune):
         return new_infected, probs
 
 
+    def _hot_path_differentiable(self, data, hp, params_of, active, betas, has_q, exp_noise, want_probs):
+        """Row f3 across the ranks: the step as the autograd node ``autograd.DistributedHotPathStep``."""
+        from .autograd import DistributedHotPathStep
+
+        if want_probs:
+            raise NotImplementedError("want_probs is not available in differentiable mode")
+        dev, n = hp.device, hp.rw.n_local
+        ag = data["agent"]
+        f = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        ip = ag["infection_parameters"]
+        fixed = {k: f(ip[k]) for k in ("max_infectiousness", "shape", "rate", "shift")}
+        stage = f(ag["symptoms"]["current_stage"]).clone() if has_q else None
+        if exp_noise is not None:
+            exp_noise = exp_noise.to(device=dev, dtype=torch.float32).reshape(2, -1)
+            if exp_noise.shape[1] != n:
+                exp_noise = exp_noise[:, hp.a0:hp.a0 + n]
+            exp_noise = exp_noise.contiguous()
+        env = {"hp": hp, "params_of": params_of, "fixed": fixed, "stage": stage, "exp_noise": exp_noise,
+               "nets": list(active), "betas": dict(betas)}
+        state = [ag[k] if ag[k].dtype == torch.float32 else ag[k].to(torch.float32) for k in
+                 ("susceptibility", "is_infected", "infection_time")]
+        susc, inf, time, new_infected = DistributedHotPathStep.apply(env, *state, *[n_.log_beta for n_ in active])
+        ag.susceptibility, ag.is_infected, ag.infection_time = susc, inf, time
+        ag.transmission = hp.state["transmission"][:n]
+        return new_infected, None
+
+
 class DistributedRunner(Runner):
     """``Runner`` for one rank; see the module docstring."""
 
@@ -157,6 +191,13 @@ class DistributedRunner(Runner):
         runner.n_agents_total = n_total
         runner.group, runner.collectives = group, collectives
         return runner
+
+    def _reduce_differentiable(self, series: torch.Tensor) -> torch.Tensor:
+        from .autograd import AllReduceSum
+
+        if not self.collectives:
+            return series
+        return AllReduceSum.apply(self.model._hp, series)
 
     def _finalize_series(self, n_rows: int) -> None:
         import torch.distributed as dist

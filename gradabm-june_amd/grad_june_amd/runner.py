@@ -211,7 +211,7 @@ class Runner(torch.nn.Module):
         self._finalize_series(row + 1)
         series = self._series[: row + 1].to(torch.float32)
         if differentiable:
-            series = torch.stack(diff_rows).to(torch.float32)
+            series = self._reduce_differentiable(torch.stack(diff_rows).to(torch.float32))
         cases_per_timestep = series[:, 0]
         data["results"]["deaths_per_timestep"] = series[:, 1 + n_bins]
         results = {
@@ -232,6 +232,10 @@ class Runner(torch.nn.Module):
 
     def _finalize_series(self, n_rows: int) -> None:
         """Hook: a partitioned run sums the ranks' per-step reductions here (distributed_api.DistributedRunner)."""
+
+    def _reduce_differentiable(self, series: torch.Tensor) -> torch.Tensor:
+        """Hook: the same for the series kept on the autograd graph in a differentiable run."""
+        return series
 
     def save_results(self, results, is_infected):
         import pandas as pd

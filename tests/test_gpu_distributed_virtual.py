@@ -315,3 +315,86 @@ def test_two_ranks_reproduce_the_reference_trajectory(device):
     out = mp.get_context("spawn").Array("i", [0] * R)
     mp.spawn(_golden_chain_worker, args=(R, 29700 + os.getpid() % 90, out), nprocs=R, join=True)
     assert list(out) == [1] * R
+
+
+def _grad_worker(rank, R, port, out, modes):
+    """DistributedRunner in differentiable mode on one rank: every log_beta an nn.Parameter, a loss on the
+    rank-summed series back-propagated on every rank."""
+    import itertools
+    import os
+
+    import torch.distributed as dist
+
+    import grad_june_amd as G
+    from grad_june_amd import distributed as D
+    from grad_june_amd import infection
+    from grad_june_amd.defaults import default_parameters
+    from grad_june_amd.distributed_api import DistributedRunner
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=R)
+    try:
+        def params():
+            p = default_parameters("cuda:0")
+            p["timer"]["total_days"] = 6
+            p["infection_seed"]["log_fraction_initial_cases"] = -1.3
+            for n in p["networks"]:
+                p["networks"][n]["log_beta"] += 0.6
+            p["policies"]["quarantine"] = {
+                "quarantine": {1: {"start_date": "2022-02-03", "end_date": "2022-02-20", "stage_threshold": 4}}}
+            return p
+
+        def run(runner):
+            nets = runner.model.infection_networks.networks
+            for n in nets.values():
+                n.log_beta = torch.nn.Parameter(n.log_beta.detach().clone())
+            results, _ = runner()
+            w = torch.linspace(0.5, 1.5, results["cases_per_timestep"].numel(), device=results["cases_per_timestep"].device)
+            loss = (results["cases_per_timestep"] * w).sum() + 3.0 * results["deaths_per_timestep"].sum() \
+                + 0.25 * results["cases_by_age_65"].sum()
+            loss.backward()
+            return results, {k: (None if n.log_beta.grad is None else float(n.log_beta.grad)) for k, n in nets.items()}
+
+        if modes:        # exercise both exchange modes on this small world (default: by mean venue size)
+            real = D.mode_of
+            D.mode_of = lambda n_edges, n_venues, world_size: modes[0] if n_venues > 50 else modes[1]
+        torch.manual_seed(33)
+        res, grads = run(DistributedRunner.from_parameters(params()))
+        if modes:
+            D.mode_of = real
+        gathered = [None] * R
+        dist.all_gather_object(gathered, grads)
+        assert gathered[0] == gathered[1], "every rank holds the whole gradient"
+        if rank == 0:
+            torch.manual_seed(33)
+            infection._philox_step = itertools.count(1 << 40)
+            ref_res, ref = run(G.Runner.from_parameters(params()))
+            assert torch.equal(res["cases_per_timestep"].detach().cpu(), ref_res["cases_per_timestep"].detach().cpu())
+            assert torch.equal(res["deaths_per_timestep"].detach().cpu(), ref_res["deaths_per_timestep"].detach().cpu())
+            nonzero = 0
+            for k, g in ref.items():
+                if g is None:
+                    assert grads[k] is None, k
+                    continue
+                # one sum order differs (the ranks' dot products are added in fp64): relative 1e-5
+                assert grads[k] == pytest.approx(g, rel=2e-5, abs=1e-7), (k, grads[k], g)
+                nonzero += g != 0.0
+            assert nonzero >= 5
+            out[0] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("modes", [None, ("halo", "halo"), ("partial", "partial")], ids=["default", "all-halo", "all-partial"])
+def test_two_ranks_gradients_match_single_gpu(device, modes):
+    """example_scripts/run_model.py:9-11 on two ranks: the gradients of a loss on the case / death series w.r.t.
+    every network's log_beta equal the single-GPU run's (same seed; 11 networks, quarantine window, symptoms) and
+    are the same on every rank."""
+    import os
+
+    import torch.multiprocessing as mp
+
+    R = 2
+    out = mp.get_context("spawn").Array("i", [0])
+    mp.spawn(_grad_worker, args=(R, 29400 + os.getpid() % 90, out, modes), nprocs=R, join=True)
+    assert out[0] == 1
