@@ -27,6 +27,7 @@ import torch
 
 from . import _native as N
 from .engine import AgentBuffers
+from .plan import SPLIT_SUFFIX
 
 
 def _forward_sums(engine, p, bufs, acc, nets, compute_transmission: bool):
@@ -77,26 +78,34 @@ def _transposed_passes(engine, p, bufs, scratch, x, nets, betas, cum_fwd):
     return tbar * scale, grads
 
 
+def _names_with_twins(plan, nets):
+    """(network, [its name and - on a set the multi-GPU partition split - its twin's]) for every network."""
+    return [(net, [nm for nm in (net.name, net.name + SPLIT_SUFFIX) if nm in plan.networks]) for net in nets]
+
+
 def _beta_gradients(plan, nets, betas, cum_fwd, scale, weights_of=None) -> List[torch.Tensor]:
     """ln(10) * sum_v cum_n[v] * cum'_n[v] / (beta_n * p_contact[v]) per network, from the forward's and the
     transposed pass's per-venue sums (``plan.cum_of`` holds the latter).  ``weights_of(edge set)``: this rank's
     weight of every venue (multi-GPU: the ranks' values are summed by the caller)."""
     grads: List[torch.Tensor] = []
     per_set_k = {}
-    for net in nets:
-        es = plan.networks[net.name].edge_set
-        k = per_set_k.get(es, 0)
-        per_set_k[es] = k + 1
-        i = plan.host.set_index[es]
-        pc = plan.keep[i]["v_pc"].double()
+    for net, names in _names_with_twins(plan, nets):
         beta = float(betas[net.name])
-        prod = cum_fwd[es][:, k].double() * plan.cum_of(es)[:, k].double()
-        w = weights_of(es) if weights_of is not None else None
-        if w is not None:
-            prod = prod * w
-        dot = (torch.where(pc > 0, prod / (beta * pc), torch.zeros_like(prod)).sum() if beta != 0.0
-               else prod.sum() * 0)
-        grads.append(dot * scale.double() * math.log(10.0))
+        total = None
+        for name in names:
+            es = plan.networks[name].edge_set
+            k = per_set_k.get(es, 0)
+            per_set_k[es] = k + 1
+            i = plan.host.set_index[es]
+            pc = plan.keep[i]["v_pc"].double()
+            prod = cum_fwd[es][:, k].double() * plan.cum_of(es)[:, k].double()
+            w = weights_of(es) if weights_of is not None else None
+            if w is not None:
+                prod = prod * w
+            dot = (torch.where(pc > 0, prod / (beta * pc), torch.zeros_like(prod)).sum() if beta != 0.0
+                   else prod.sum() * 0)
+            total = dot if total is None else total + dot
+        grads.append(total * scale.double() * math.log(10.0))
     return grads
 
 
@@ -228,10 +237,11 @@ class DistributedHotPathStep(torch.autograd.Function):
         cum_fwd = {}
 
         def keep_forward_sums():
-            for net in nets:
-                es = plan.networks[net.name].edge_set
-                if es not in cum_fwd:
-                    cum_fwd[es] = plan.cum_of(es).clone()
+            for _, names in _names_with_twins(plan, nets):
+                for name in names:
+                    es = plan.networks[name].edge_set
+                    if es not in cum_fwd:
+                        cum_fwd[es] = plan.cum_of(es).clone()
 
         # ---- recompute the forward of the two passes from the saved pre-state, across the ranks ---------------
         p.transpose = 0

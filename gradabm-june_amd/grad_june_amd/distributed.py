@@ -12,6 +12,8 @@ per edge set one of two exchanges is used (decided once, identically on every ra
 * ``partial`` (venues that span ranks: schools, leisure, ...): each rank sums its own attendees and
   the per-venue partial sums of all such sets - one flat fp32 buffer - are combined by ONE
   ``all_reduce``; volume is bounded by the number of venues, not by the attendees.
+A heavy-tailed set (power-law venue sizes) is ``split`` into a halo half (its small venues) and a partial-sum half
+(its large ones), see ``mode_of``.
 
 Per step:  transmission -> [all_to_all halo] -> phase A, phase B -> [all_reduce partial sums]
            -> phase C, phase D.   Pass 2 and the epilogue are purely local.
@@ -26,8 +28,10 @@ import numpy as np
 import torch
 
 from . import tiling as TL
+from .plan import SPLIT_SUFFIX
 
 HALO_MAX_MEAN_DEGREE = 8.0     # sets whose venues average more attendees use partial sums
+SPLIT_MIN_WEIGHTED_SIZE = 64.0  # venue size seen by the average EDGE of a small-mean set above which the set is split
 PIPELINE_MIN_EDGES = 20_000_000  # set-edges per rank from which the largest partial-sum set gets its own all-reduce
 
 
@@ -50,11 +54,7 @@ def choose_modes(world: dict, world_size: int, override: Optional[Dict[str, str]
     """Exchange mode per edge set - a function of global sizes only, so all ranks agree."""
     modes = {}
     for name, es in world["edge_sets"].items():
-        if world_size == 1:
-            modes[name] = "local"
-        else:
-            V = max(1, len(es["people"]))
-            modes[name] = "halo" if len(es["agent"]) / V <= HALO_MAX_MEAN_DEGREE else "partial"
+        modes[name] = mode_of(len(es["agent"]), len(es["people"]), world_size, es["people"])
     if override:
         modes.update(override)
     return modes
@@ -84,11 +84,25 @@ class RankWorld:
         return len(self.halo_global)
 
 
-def mode_of(n_edges: int, n_venues: int, world_size: int) -> str:
-    """Exchange mode of ONE edge set from its global sizes (what choose_modes applies to every set)."""
+def mode_of(n_edges: int, n_venues: int, world_size: int, people=None) -> str:
+    """Exchange mode of ONE edge set from its global sizes (what choose_modes applies to every set).
+
+    "halo" pays per remote attendee of a touched venue, "partial" per venue.  A heavy-tailed set (power-law venue
+    sizes, BASELINE config 5: most venues hold one or two agents, most EDGES lie in venues of thousands) is wrong
+    for both as a whole - in halo mode one 50 000-attendee venue makes everybody a halo agent of every rank, in
+    partial-sum mode the millions of tiny venues become a per-step all-reduce of hundreds of MB - so it is "split"
+    (``people`` = the venues' sizes): venues of up to HALO_MAX_MEAN_DEGREE attendees go the halo way, the larger ones
+    the partial-sum way, as two edge sets (``RankPartitioner.add_set``)."""
     if world_size == 1:
         return "local"
-    return "halo" if n_edges / max(1, n_venues) <= HALO_MAX_MEAN_DEGREE else "partial"
+    if n_edges / max(1, n_venues) > HALO_MAX_MEAN_DEGREE:
+        return "partial"
+    if people is not None and n_edges:
+        sizes = np.asarray(people, dtype=np.float64)
+        if float((sizes * sizes).sum() / max(1.0, sizes.sum())) > SPLIT_MIN_WEIGHTED_SIZE \
+                and (sizes > HALO_MAX_MEAN_DEGREE).any() and (sizes <= HALO_MAX_MEAN_DEGREE).any():
+            return "split"
+    return "halo"
 
 
 class RankPartitioner:
@@ -114,10 +128,23 @@ class RankPartitioner:
         agent = np.asarray(agent, dtype=np.int64).ravel()
         venue = np.asarray(venue, dtype=np.int64).ravel()
         people = np.asarray(people)
-        mode = self.mode_override.get(name) or mode_of(len(agent), len(people), self.world_size)
-        self.modes[name] = mode
+        mode = self.mode_override.get(name) or mode_of(len(agent), len(people), self.world_size, people)
         self.total_edges += len(agent)
         self.sizes[name] = (len(agent), len(people))
+        if mode == "split":
+            # two edge sets with venue numberings of their own: the small venues exchange halo transmissions, the
+            # large ones partial sums; every network on the set gets a twin on the second (expand_split_networks)
+            big = people > HALO_MAX_MEAN_DEGREE
+            e_big = big[venue]
+            for part, sel_v, sel_e, m in ((name, ~big, ~e_big, "halo"), (name + SPLIT_SUFFIX, big, e_big, "partial")):
+                remap = np.cumsum(sel_v) - 1
+                self._add_part(part, agent[sel_e], remap[venue[sel_e]], people[sel_v], m)
+            return mode
+        self._add_part(name, agent, venue, people, mode)
+        return mode
+
+    def _add_part(self, name: str, agent: np.ndarray, venue: np.ndarray, people: np.ndarray, mode: str) -> None:
+        self.modes[name] = mode
         b = self.bounds
         if len(self.ranks) > 2:
             # every rank's own edges with one stable sort by owner (COO order kept inside a rank)
@@ -144,7 +171,6 @@ class RankPartitioner:
             self.local_sets[r][name] = {"agent_global": ag, "venue": remap[venue[keep]], "people": people[vg]}
             self.venue_global[r][name] = vg
             self.halo_lists[r].append(np.unique(ag[(ag < b[r]) | (ag >= b[r + 1])]))
-        return mode
 
     def finish(self, age, sex, slice_agents: Optional[int] = None) -> Dict[int, "RankWorld"]:
         age, sex = np.asarray(age), np.asarray(sex)
@@ -237,6 +263,52 @@ def stream_rank_share(pieces, rank: int, world_size: int, reorder: Optional[str]
              "n_agents": header["n_agents"], "total_edges": total_edges, "sizes": sizes,
              "original_id": (np.arange(a0, a1) if order is None else order[a0:a1])}
     return rw, share
+
+
+def with_twins(names, set_of, twin_of):
+    """Network names in accumulation order with the twins of split sets put in: the networks of one edge set stay
+    adjacent (the launch groups them by set), so a run of networks on one set is followed by the run of their twins."""
+    out, run, run_set = [], [], None
+
+    def flush():
+        out.extend(run)
+        out.extend(t for t in (twin_of(n) for n in run) if t is not None)
+
+    for n in names:
+        s = set_of(n)
+        if run and s != run_set:
+            flush()
+            run = []
+        run.append(n)
+        run_set = s
+    flush()
+    return out
+
+
+def expand_split_networks(specs, networks, betas, edge_sets):
+    """Networks of a world whose partition split some edge sets (``mode_of`` "split"): behind every network on a
+    split set comes its twin on the set's partial-sum half - same beta, mask and table, so that the two together
+    are the original network (sums over a set's venues are sums over both halves).  Returns (specs, network names
+    in accumulation order, betas)."""
+    from .plan import NetworkSpec
+
+    twins = {s[: -len(SPLIT_SUFFIX)] for s in edge_sets if s.endswith(SPLIT_SUFFIX)}
+    if not twins:
+        return list(specs), list(networks), dict(betas)
+    out_specs, by_name = [], {}
+    for sp in specs:
+        out_specs.append(sp)
+        if sp.edge_set in twins:
+            tw = NetworkSpec(sp.name + SPLIT_SUFFIX, sp.edge_set + SPLIT_SUFFIX, sp.mask_kind, sp.table)
+            out_specs.append(tw)
+            by_name[sp.name] = tw.name
+    out_betas = dict(betas)
+    for n, t in by_name.items():
+        if n in betas:
+            out_betas[t] = betas[n]
+    base_set = {sp.name: sp.edge_set for sp in specs}
+    out_names = with_twins(networks, base_set.get, lambda n: by_name.get(n))
+    return out_specs, out_names, out_betas
 
 
 class HaloExchange:
@@ -336,9 +408,12 @@ class DistributedHotPath:
         self.rank, self.world_size, self.group = rank, world_size, group
         rw = self.rw = rank_world if rank_world is not None else build_rank_world(world, rank, world_size, modes,
                                                                                   progress=progress)
+        specs, networks, betas = expand_split_networks(specs, world["networks"], betas, rw.edge_sets)
+        leisure = tuple(s for s in rw.edge_sets if s.split(SPLIT_SUFFIX)[0] == "leisure")
         host = compile_plan(rw.n_local, rw.edge_sets, age=rw.age, sex=rw.sex, n_ext_agents=rw.n_ext,
                             layout="tiled", slices=(rw.n_slices, rw.slice_agents), progress=progress,
-                            device=self.device if device_compile else None)
+                            device=self.device if device_compile else None, leisure_sets=leisure or ("leisure",))
+        self.set_of = {sp.name: sp.edge_set for sp in specs}
         nets_on = {}
         for sp in specs:
             nets_on[sp.edge_set] = nets_on.get(sp.edge_set, 0) + 1
@@ -361,7 +436,7 @@ class DistributedHotPath:
             self.group_cum.append(self.flat_cum[lo:hi])
         self.exchange_sets = [n for n in rw.edge_sets if rw.modes[n] != "partial"]   # halo or local
         self._params_cache = {}
-        self.networks = list(world["networks"])
+        self.networks = networks
         self.betas, self.seed = betas, seed
         a0, a1 = int(rw.bounds[rank]), int(rw.bounds[rank + 1])
         own = (lambda v: v) if rank_world is not None else (lambda v: v[a0:a1])
@@ -407,8 +482,7 @@ class DistributedHotPath:
         """only: None = every network; "halo" / "partial" = the networks on sets of that exchange mode;
         a collection of edge-set names = the networks on those sets.  The struct is built once per
         selection and only its clock fields change from step to step (this sits on the launch path)."""
-        from .synthetic import edge_set_of
-
+        edge_set_of = self.set_of.__getitem__
         key = only if (only is None or isinstance(only, str)) else tuple(only)
         p = self._params_cache.get(key)
         if p is None:

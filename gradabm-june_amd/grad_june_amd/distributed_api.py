@@ -25,10 +25,11 @@ from typing import Optional
 import numpy as np
 import torch
 
-from .distributed import DistributedHotPath, world_from_data
+from .distributed import DistributedHotPath, with_twins, world_from_data
 from .engine import AgentBuffers
 from .graph import HeteroData
 from .model import GradJune
+from .plan import SPLIT_SUFFIX
 from .runner import Runner
 from .timer import Timer
 from .world import require_hip
@@ -99,6 +100,7 @@ class DistributedGradJune(GradJune):
         qp = self.policies.quarantine_policies
         has_q = bool(qp)
         betas = {net.name: net.beta_value(self.policies, timer) for net in active}
+        betas.update({k + SPLIT_SUFFIX: v for k, v in list(betas.items())})
         if self.rng_seed is None:
             self.rng_seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
         step = self.n_steps
@@ -109,7 +111,12 @@ class DistributedGradJune(GradJune):
         q_threshold = qp.threshold if has_q else math.inf
 
         def params_of(sets):
-            names = [net.name for net in active if sets is None or net.edge_set in sets]
+            # a network on a set the partition split runs on both halves (its twin: same beta)
+            nets_by_name = {net.name: net for net in active}
+            names = with_twins([net.name for net in active], lambda n: nets_by_name[n].edge_set,
+                               lambda n: n + SPLIT_SUFFIX if n + SPLIT_SUFFIX in engine.plan.networks else None)
+            if sets is not None:
+                names = [n for n in names if engine.plan.networks[n].edge_set in sets]
             return engine.params(now=now, delta_time=duration, day_type=day_type, active=names, betas=betas,
                                  has_quarantine=has_q, q_threshold=q_threshold, seed=seed, step=step,
                                  agent_offset=hp.a0)

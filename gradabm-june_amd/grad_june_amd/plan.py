@@ -154,6 +154,11 @@ def build_schedule(v_rowptr: np.ndarray, set_id: int, slot_base: int = 0,
     return b, lr, slot - slot_base
 
 
+#: suffix of the partial-sum half of an edge set that the multi-GPU partition split in two (distributed.mode_of
+#: "split"), and of the twin networks that run on it
+SPLIT_SUFFIX = "~big"
+
+
 @dataclass
 class NetworkSpec:
     """One configured infection network (reference: an ``InfectionNetwork`` subclass instance)."""

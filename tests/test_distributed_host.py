@@ -91,6 +91,53 @@ def test_partition_matches_single_rank(R):
             assert np.allclose(accs[name], acc_ref[lo:hi], rtol=1e-5, atol=1e-6), name
 
 
+@pytest.mark.parametrize("R", [2, 5])
+def test_heavy_tailed_sets_are_split(R):
+    """BASELINE config 5's power-law venues: a set whose mean venue is small but whose edges lie in huge venues is cut
+    into a halo half (venues of <= 8 attendees) and a partial-sum half; per agent the two halves add up to the
+    single-rank pass, and no rank's halo is blown up by a big venue."""
+    from grad_june_amd.distributed import SPLIT_SUFFIX, mode_of
+
+    world = make_world("c5", n_agents=6000, seed=2)
+    world["state"]["transmission"] = np.random.default_rng(1).random(6000).astype(np.float32)
+    x = world["state"]["transmission"]
+    ref = reference_pass(world, x)
+    modes = choose_modes(world, R)
+    assert set(modes.values()) == {"split"}
+    assert mode_of(15, 10, R, np.array([1, 1, 1, 1, 1, 1, 1, 1, 1, 6])) == "halo"          # small mean, no tail
+    assert mode_of(15_000_000, 6_000_000, R) == "halo" and mode_of(100, 5, R) == "partial" and mode_of(1, 1, 1) == "local"
+    rws = [build_rank_world(world, r, R, slice_agents=256) for r in range(R)]
+    b = partition_bounds(world["n_agents"], R)
+    xs = []
+    for rw in rws:
+        assert set(rw.edge_sets) == {n + sfx for n in world["edge_sets"] for sfx in ("", SPLIT_SUFFIX)}
+        for n in world["edge_sets"]:
+            assert rw.modes[n] == "halo" and rw.modes[n + SPLIT_SUFFIX] == "partial"
+            assert rw.edge_sets[n]["people"].max() <= 8 and rw.edge_sets[n + SPLIT_SUFFIX]["people"].min() > 8
+        xe = np.zeros(rw.n_ext, dtype=np.float32)
+        xe[: rw.n_local] = x[b[rw.rank]:b[rw.rank + 1]]
+        xs.append(xe)
+    emulate_exchange(rws, xs)
+    hosts = [compile_plan(rw.n_local, rw.edge_sets, age=rw.age, sex=rw.sex, n_ext_agents=rw.n_ext, layout="tiled",
+                          slices=(rw.n_slices, rw.slice_agents), sv_max=512, eb_target=4096) for rw in rws]
+    pre = {}
+    for rw, host, xe in zip(rws, hosts, xs):
+        for s in host.sets:
+            if rw.modes[s.name] == "partial":
+                pad = np.pad(xe, (0, host.n_slices * host.slice_agents - len(xe)))
+                pre.setdefault(s.name, []).append(emulate_pass1(s.tiled, pad, host.slice_agents, beta=1.0)[1])
+    total = {n: np.sum(v, axis=0) for n, v in pre.items()}
+    for rw, host, xe in zip(rws, hosts, xs):
+        _, accs = rank_pass(rw, host, xe, lambda name, c: total[name])
+        lo, hi = b[rw.rank], b[rw.rank + 1]
+        for name in world["edge_sets"]:
+            both = accs[name] + accs[name + SPLIT_SUFFIX]
+            assert np.allclose(both, ref[name][1][lo:hi], rtol=1e-5, atol=1e-6), name
+    # what the split buys: the halo of rank 0 against the same world with every set forced into halo mode
+    forced = build_rank_world(world, 0, R, {n: "halo" for n in world["edge_sets"]}, slice_agents=256)
+    assert rws[0].n_halo < 0.8 * forced.n_halo
+
+
 def test_single_rank_is_all_local():
     world = small_world(2000)
     rw = build_rank_world(world, 0, 1)

@@ -48,10 +48,10 @@ def reference_world(device):
     return world
 
 
-@pytest.mark.parametrize("R,source", [(2, "c3"), (4, "c3"), (3, "reference-769"), (3, "c3-quarantine")])
+@pytest.mark.parametrize("R,source", [(2, "c3"), (4, "c3"), (3, "reference-769"), (3, "c3-quarantine"), (3, "c5-split")])
 def test_virtual_ranks_match_single_rank(device, R, source):
     world = (reference_world(device) if source == "reference-769"
-             else make_world("c3", n_agents=40_000, seed=3, infected_fraction=0.05))
+             else make_world("c5" if source == "c5-split" else "c3", n_agents=40_000, seed=3, infected_fraction=0.05))
     specs, betas = B.network_specs(world), B.betas_of(world)
     betas = {k: 3.0 * v for k, v in betas.items()} if source == "reference-769" else betas
     kw, modes = {}, None
@@ -67,6 +67,10 @@ def test_virtual_ranks_match_single_rank(device, R, source):
              for r in range(R)]
     assert all(rk.exchange_q == (source == "c3-quarantine") for rk in ranks)
     assert {m for rk in ranks for m in rk.rw.modes.values()} == {"halo", "partial"}
+    if source == "c5-split":     # power-law venues: every set cut into a halo half and a partial-sum half, networks twinned
+        halves = [n for n in ranks[0].rw.edge_sets if n.endswith("~big")]
+        assert len(halves) >= 4 and len(ranks[0].rw.edge_sets) == len(world["edge_sets"]) + len(halves)
+        assert len(ranks[0].networks) > len(world["networks"]) and all(n + "~big" in ranks[0].networks for n in ("household", "school"))
     b = partition_bounds(world["n_agents"], R)
     for step in range(3):
         single.step()
@@ -357,7 +361,13 @@ def _grad_worker(rank, R, port, out, modes):
 
         if modes:        # exercise both exchange modes on this small world (default: by mean venue size)
             real = D.mode_of
-            D.mode_of = lambda n_edges, n_venues, world_size: modes[0] if n_venues > 50 else modes[1]
+            def forced(n_edges, n_venues, world_size, people=None):
+                m = modes[0] if n_venues > 50 else modes[1]
+                if m == "split" and not ((np.asarray(people) > 8).any() and (np.asarray(people) <= 8).any()):
+                    m = "partial"
+                return m
+
+            D.mode_of = forced
         torch.manual_seed(33)
         res, grads = run(DistributedRunner.from_parameters(params()))
         if modes:
@@ -385,11 +395,12 @@ def _grad_worker(rank, R, port, out, modes):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("modes", [None, ("halo", "halo"), ("partial", "partial")], ids=["default", "all-halo", "all-partial"])
+@pytest.mark.parametrize("modes", [None, ("halo", "halo"), ("partial", "partial"), ("split", "split")],
+                         ids=["default", "all-halo", "all-partial", "split"])
 def test_two_ranks_gradients_match_single_gpu(device, modes):
     """example_scripts/run_model.py:9-11 on two ranks: the gradients of a loss on the case / death series w.r.t.
     every network's log_beta equal the single-GPU run's (same seed; 11 networks, quarantine window, symptoms) and
-    are the same on every rank."""
+    are the same on every rank - whatever the exchange modes, "split" sets with their twin networks included."""
     import os
 
     import torch.multiprocessing as mp
