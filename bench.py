@@ -80,6 +80,8 @@ def parse():
                     help="second, short timed region on the same world re-seeded at this infected fraction (0 = skip): "
                          "k_transmission skips uninfected agents' parameter lines and phase D rewrites state only where it "
                          "changes, so the headline state (1 %% infected, SURVEY 8d) is the cheap end")
+    ap.add_argument("--work-order", default=None, choices=["heavy", "light", "mixed", "set"],
+                    help="experiments: order of the venue launch's (set, block) work list (default: heaviest first)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
     return ap.parse_args()
@@ -245,6 +247,8 @@ def main():
     sys.stdout.flush()
     result_fd = os.dup(1)
     os.dup2(2, 1)
+    if args.work_order:
+        os.environ["GJ_WORK_ORDER"] = args.work_order
     rank = int(os.environ.get("RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

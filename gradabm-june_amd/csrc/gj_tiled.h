@@ -416,8 +416,33 @@ struct Slots8 {           // 8 consecutive block-major slots: 16 bytes of local 
   __device__ __forceinline__ int lv(int q) const { return (w[q >> 1] >> ((q & 1) * 16)) & 0xFFFF; }
 };
 
+#ifdef GJ_DIAG_STAMPS
+// timing diagnostics (tools/venue_timeline.py): start / end time and XCD of every workgroup of the last venue launch
+constexpr int kDiagVenueSlots = 8192;
+__device__ unsigned long long gj_diag_venue[3 * kDiagVenueSlots];
+struct VenueStamp {
+  unsigned long long t0;
+  __device__ VenueStamp() : t0(__builtin_amdgcn_s_memrealtime()) {}      // the constant 100 MHz counter: one clock for the chip
+  __device__ ~VenueStamp() {                                            // (s_memtime counts per XCD, unsynchronised)
+    if (threadIdx.x == 0 && blockIdx.x < kDiagVenueSlots) {
+      gj_diag_venue[3 * blockIdx.x] = t0;
+      gj_diag_venue[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+      gj_diag_venue[3 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF;     // HW_REG_XCC_ID
+    }
+  }
+};
+#endif
+
+// One workgroup per (set, venue block) work item, heaviest first.  (Measured with per-workgroup timestamps,
+// tools/venue_timeline.py: 1 899 workgroups of 10-80 us on 512 slots, ~80 % of the slot-time used - a finished
+// workgroup's slot idles for a few us until its successor's 16 waves are up.  Persistent workgroups that work through
+// several items each closed those gaps and took as long: with every slot busy the items stretch, the launch is bound
+// by the memory system at ~4.8 TB/s of measured traffic, not by the slots.)
 __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B) {
   extern __shared__ __align__(16) float lds_s[];
+#ifdef GJ_DIAG_STAMPS
+  VenueStamp gj_stamp;
+#endif
   const int tid = threadIdx.x;
   const int set = B.work[2 * blockIdx.x], j = B.work[2 * blockIdx.x + 1];
   const TSetB& T = B.sets[set];

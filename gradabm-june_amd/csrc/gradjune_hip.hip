@@ -1130,6 +1130,13 @@ static int tiled_agents(const gj_plan* plan, const gj_agent_state* st, const gj_
 // ------------------------------------------------------------------------------------------
 extern "C" {
 
+#ifdef GJ_DIAG_STAMPS
+// diagnostics build only: the venue launch's per-workgroup timestamps, [3 * 8192] uint64 (start, end, XCD) to host memory
+int gj_diag_venue_stamps(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(gj::gj_diag_venue), sizeof(unsigned long long) * 3 * gj::kDiagVenueSlots);
+}
+#endif
+
 int gj_version(void) { return GJ_ABI_VERSION; }
 
 const char* gj_error_string(int code) {

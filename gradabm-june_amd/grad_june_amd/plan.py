@@ -21,6 +21,8 @@ uploads it and owns the per-step workspaces.
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence
@@ -329,6 +331,14 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
         if len(cls) != n_ext:
             raise ValueError("age/sex must cover owned + halo agents")
     work.sort(key=lambda w: -w[0])
+    order = os.environ.get("GJ_WORK_ORDER", "heavy")       # experiments (bench.py --work-order): the default is heaviest first
+    if order == "light":
+        work.reverse()
+    elif order == "mixed":                                  # heavy, light, heavy, light ...
+        h, l = work[: (len(work) + 1) // 2], work[(len(work) + 1) // 2:][::-1]
+        work = [w for pair in zip(h, l + [None] * (len(h) - len(l))) for w in pair if w is not None]
+    elif order == "set":
+        work.sort(key=lambda w: (w[1], w[2]))
     work_arr = np.array([(w[1], w[2]) for w in work], dtype=np.int32).reshape(-1, 2)
     return HostPlan(n_agents, n_ext, sets, cls, np.ascontiguousarray(blocks), long_rows, slot,
                     {s.name: i for i, s in enumerate(sets)}, layout=layout,

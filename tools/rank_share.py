@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""What ONE rank of an N-GPU run does, measured on one GPU: the rank's share of the benchmark world is built exactly
+as `bench.py --gpus N` builds it (streamed set by set, household-major order, exchange modes by `distributed.mode_of`),
+compiled, and stepped WITHOUT the collectives (halo slots and remote partial sums stay zero: the kernels' work does
+not depend on the values).  Prints one JSON line: the rank's kernel time per step, its halo and partial-sum volumes
+(what the two collectives would move) and the host memory the set-up needed.
+
+    python tools/rank_share.py --preset c5 --agents 100000000 --of 8 [--rank 0] [--steps 20]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import resource
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "gradabm-june_amd"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--preset", default="c3")
+    ap.add_argument("--agents", type=int, default=None)
+    ap.add_argument("--of", type=int, default=8, help="ranks of the run")
+    ap.add_argument("--rank", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--seed", type=int, default=1234)
+    a = ap.parse_args()
+    import torch
+
+    import __graft_entry__ as entry
+    import bench as B
+    from grad_june_amd.distributed import DistributedHotPath, stream_rank_share
+    from grad_june_amd.synthetic import iter_world
+
+    entry.build()
+    dev = torch.device("cuda:0")
+    t0 = time.time()
+
+    def progress(msg):
+        print(f"[rank_share {time.time() - t0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    rw, share = stream_rank_share(iter_world(a.preset, n_agents=a.agents, seed=a.seed, infected_fraction=0.01,
+                                             progress=progress),
+                                  a.rank, a.of, reorder="household", progress=progress)
+    t_part = time.time() - t0
+    world = {"n_agents": share["n_agents"], "networks": share["networks"], "state": share["state"],
+             "edge_sets": {k: {"n_edges": e, "n_venues": v} for k, (e, v) in share["sizes"].items()}}
+    specs, betas = B.network_specs(world), B.betas_of(world)
+    hp = DistributedHotPath(world, specs, betas, dev, a.rank, a.of, seed=a.seed, collectives=False, progress=progress,
+                            rank_world=rw, total_edges=share["total_edges"], device_compile=True)
+    t_setup = time.time() - t0
+    for _ in range(3):
+        hp.step()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(a.steps):
+        hp.step()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t1) / a.steps
+    hp.reset_timers()
+    for _ in range(max(4, a.steps // 4)):
+        hp.step(timed=True)
+    torch.cuda.synchronize()
+    out = {
+        "what": f"rank {a.rank} of {a.of}: kernels of one step on its share, collectives not executed",
+        "preset": a.preset, "n_agents_world": share["n_agents"], "n_owned": int(rw.n_local), "n_halo": int(rw.n_halo),
+        "modes": rw.modes,
+        "local_set_edges": {k: int(len(v["agent"])) for k, v in rw.edge_sets.items()},
+        "halo_all_to_all_bytes_in_per_step": 4 * int(rw.n_halo),
+        "partial_sum_all_reduce_bytes_per_step": 4 * int(hp.flat_cum.numel()) if hp.flat_cum is not None else 0,
+        "kernel_ms_per_step": ms, "kernel_ms": hp.kernel_ms(),
+        "setup_s": {"stream_and_partition": t_part, "total": t_setup},
+        "host_peak_rss_mb": resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0,
+    }
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
