@@ -21,6 +21,7 @@ Sampling noise is Philox keyed by the GLOBAL agent id, so results do not depend 
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
@@ -184,7 +185,11 @@ class RankPartitioner:
             halo_from = np.bincount(owner, minlength=self.world_size).astype(np.int64)   # sorted ids => grouped by owner
             sa = slice_agents
             if sa is None:
-                _, sa = TL.choose_slices(n_local + len(halo_global))
+                # (slices sized for owned + halo agents.  Sized for the owned agents alone - phase D runs one workgroup
+                # per OWNED slice, 120 of them for C3 at 8 ranks - phase D gains 9 us and the venue launch loses 11:
+                # tools/rank_share.py, GJ_RANK_SLICES=owned)
+                _, sa = TL.choose_slices(n_local if os.environ.get("GJ_RANK_SLICES", "ext") == "owned"
+                                         else n_local + len(halo_global))
             n_local_pad = -(-n_local // sa) * sa if len(halo_global) else n_local
             n_ext = n_local_pad + len(halo_global)
             n_slices = max(1, -(-n_ext // sa))
@@ -395,7 +400,7 @@ class DistributedHotPath:
                  seed: int = 0, group=None, modes: Optional[Dict[str, str]] = None, collectives: bool = True,
                  progress=None, min_group_floats: int = 1 << 16, production_at_one_rank: bool = False,
                  quarantine_threshold: Optional[float] = None, rank_world: Optional[RankWorld] = None,
-                 total_edges: Optional[int] = None, device_compile: bool = False):
+                 total_edges: Optional[int] = None, device_compile: bool = False, plan_kw: Optional[dict] = None):
         """``world``: the whole world (this rank's part is cut out of it), or - with ``rank_world`` - only
         {"networks": [...], "state": {name: this rank's OWNED agents' arrays}} next to the prebuilt part and the
         world's ``total_edges`` (what ``RankPartitioner`` hands over when the world is streamed)."""
@@ -412,7 +417,8 @@ class DistributedHotPath:
         leisure = tuple(s for s in rw.edge_sets if s.split(SPLIT_SUFFIX)[0] == "leisure")
         host = compile_plan(rw.n_local, rw.edge_sets, age=rw.age, sex=rw.sex, n_ext_agents=rw.n_ext,
                             layout="tiled", slices=(rw.n_slices, rw.slice_agents), progress=progress,
-                            device=self.device if device_compile else None, leisure_sets=leisure or ("leisure",))
+                            device=self.device if device_compile else None, leisure_sets=leisure or ("leisure",),
+                            **(plan_kw or {}))
         self.set_of = {sp.name: sp.edge_set for sp in specs}
         nets_on = {}
         for sp in specs:

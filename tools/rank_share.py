@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--rank", type=int, default=0)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--eb-target", type=int, default=None)
+    ap.add_argument("--sv-max", type=int, default=None)
     a = ap.parse_args()
     import torch
 
@@ -52,7 +54,8 @@ def main():
              "edge_sets": {k: {"n_edges": e, "n_venues": v} for k, (e, v) in share["sizes"].items()}}
     specs, betas = B.network_specs(world), B.betas_of(world)
     hp = DistributedHotPath(world, specs, betas, dev, a.rank, a.of, seed=a.seed, collectives=False, progress=progress,
-                            rank_world=rw, total_edges=share["total_edges"], device_compile=True)
+                            rank_world=rw, total_edges=share["total_edges"], device_compile=True,
+                            plan_kw={k: v for k, v in (("eb_target", a.eb_target), ("sv_max", a.sv_max)) if v})
     t_setup = time.time() - t0
     for _ in range(3):
         hp.step()
@@ -68,6 +71,7 @@ def main():
     torch.cuda.synchronize()
     out = {
         "what": f"rank {a.rank} of {a.of}: kernels of one step on its share, collectives not executed",
+        "geometry": {"slice_agents": int(rw.slice_agents), "n_slices": int(rw.n_slices), "eb_target": a.eb_target, "sv_max": a.sv_max},
         "preset": a.preset, "n_agents_world": share["n_agents"], "n_owned": int(rw.n_local), "n_halo": int(rw.n_halo),
         "modes": rw.modes,
         "local_set_edges": {k: int(len(v["agent"])) for k, v in rw.edge_sets.items()},
