@@ -384,10 +384,10 @@ def main():
     runner.reset_timers()
     t0 = time.perf_counter()
     # One GPU: launches are bracketed by HIP events (on the launch stream) INSIDE the timed region - on every
-    # `events_every`-th step: an event between two launches costs the GPU ~4 us (measured: 19 us per step of five
+    # `events_every`-th step (every 4th; from 32 steps on, 8 of them): an event between two launches costs the GPU ~4 us (measured: 19 us per step of five
     # events, 3 % of the default workload's step and 10 % of C2's), which the production call (gj_step, no events)
     # does not pay.  N > 1: the production step overlaps collectives with compute and cannot be bracketed.
-    events_every = 1 if (args.steps < 12 or distributed) else 4
+    events_every = 1 if (args.steps < 12 or distributed) else max(4, args.steps // 8)     # at least 8 bracketed steps from 32 on
     if args.no_events:
         events_every = 1 << 30
     for i in range(args.steps):

@@ -420,6 +420,16 @@ class DistributedHotPath:
                             device=self.device if device_compile else None, leisure_sets=leisure or ("leisure",),
                             **(plan_kw or {}))
         self.set_of = {sp.name: sp.edge_set for sp in specs}
+        # The production step scatters the partial-sum sets (phase A) while the halo all-to-all may still be writing the
+        # halo part of the transmission array: safe because those sets keep only the rank's OWN agents' edges, i.e. no
+        # chunk of theirs lies in a halo slice.  Checked here, once, on the compiled plan.
+        first_halo_slice = rw.n_local_pad // rw.slice_agents
+        for hs in host.sets:
+            if rw.modes[hs.name] == "partial" and hs.tiled is not None and hs.tiled.n_blocks:
+                cp = hs.tiled.chunk_ptr
+                tail = cp[first_halo_slice:] if first_halo_slice < len(cp) else cp[-1:]
+                if int(tail[-1]) != int(tail[0]):
+                    raise RuntimeError(f"edge set {hs.name}: a partial-sum set holds edges of halo agents")
         nets_on = {}
         for sp in specs:
             nets_on[sp.edge_set] = nets_on.get(sp.edge_set, 0) + 1
