@@ -423,9 +423,9 @@ class DistributedHotPath:
         # The production step scatters the partial-sum sets (phase A) while the halo all-to-all may still be writing the
         # halo part of the transmission array: safe because those sets keep only the rank's OWN agents' edges, i.e. no
         # chunk of theirs lies in a halo slice.  Checked here, once, on the compiled plan.
-        first_halo_slice = rw.n_local_pad // rw.slice_agents
+        first_halo_slice = rw.n_local_pad // rw.slice_agents          # (with a halo, n_local_pad is a slice boundary)
         for hs in host.sets:
-            if rw.modes[hs.name] == "partial" and hs.tiled is not None and hs.tiled.n_blocks:
+            if rw.n_halo and rw.modes[hs.name] == "partial" and hs.tiled is not None and hs.tiled.n_blocks:
                 cp = hs.tiled.chunk_ptr
                 tail = cp[first_halo_slice:] if first_halo_slice < len(cp) else cp[-1:]
                 if int(tail[-1]) != int(tail[0]):
