@@ -257,3 +257,34 @@ def test_streamed_partition_equals_the_in_memory_one(R, reorder):
             assert np.array_equal(share["original_id"], world["original_id"][a0:a1])
     with pytest.raises(ValueError):
         stream_rank_share(iter_world(**kw), 0, 2, reorder="school")
+
+
+def test_twin_networks_of_split_sets():
+    """expand_split_networks / with_twins: every network on a split set gets a twin on the set's partial-sum half (same
+    beta, mask and table), the networks of one edge set stay adjacent (the launch groups networks by set), and sets
+    that were not split are left alone."""
+    from grad_june_amd import _native as N
+    from grad_june_amd.distributed import SPLIT_SUFFIX, expand_split_networks, with_twins
+    from grad_june_amd.plan import NetworkSpec
+
+    tab = np.ones((2, 2, 100), np.float32)
+    specs = [NetworkSpec("school", "school", N.MASK_Q, None), NetworkSpec("pub", "leisure", N.MASK_QL, tab),
+             NetworkSpec("gym", "leisure", N.MASK_QL, 2 * tab), NetworkSpec("household", "household", N.MASK_RAW, None)]
+    names = ["school", "pub", "gym", "household"]
+    betas = {"school": 0.5, "pub": 0.1, "gym": 0.2, "household": 0.4}
+    sets = {"school": 0, "school" + SPLIT_SUFFIX: 0, "leisure": 0, "leisure" + SPLIT_SUFFIX: 0, "household": 0}
+    s2, n2, b2 = expand_split_networks(specs, names, betas, sets)
+    assert n2 == ["school", "school~big", "pub", "gym", "pub~big", "gym~big", "household"]
+    by = {sp.name: sp for sp in s2}
+    assert set(by) == set(n2) and by["gym~big"].edge_set == "leisure~big" and by["gym~big"].mask_kind == N.MASK_QL
+    assert by["gym~big"].table is by["gym"].table and b2["gym~big"] == 0.2 and b2["school~big"] == 0.5 and "household~big" not in b2
+    seen = []
+    for n in n2:                                   # adjacency: a set's networks form one run
+        es = by[n].edge_set
+        assert es not in seen[:-1] or seen[-1] == es
+        if not seen or seen[-1] != es:
+            seen.append(es)
+    # nothing split: unchanged
+    s3, n3, b3 = expand_split_networks(specs, names, betas, {"school": 0, "leisure": 0, "household": 0})
+    assert n3 == names and len(s3) == len(specs) and b3 == betas
+    assert with_twins(["a", "b"], {"a": "x", "b": "y"}.get, lambda n: None) == ["a", "b"]
