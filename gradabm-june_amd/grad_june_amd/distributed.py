@@ -185,11 +185,12 @@ class RankPartitioner:
             halo_from = np.bincount(owner, minlength=self.world_size).astype(np.int64)   # sorted ids => grouped by owner
             sa = slice_agents
             if sa is None:
-                # (slices sized for owned + halo agents.  Sized for the owned agents alone - phase D runs one workgroup
-                # per OWNED slice, 120 of them for C3 at 8 ranks - phase D gains 9 us and the venue launch loses 11:
-                # tools/rank_share.py, GJ_RANK_SLICES=owned)
-                _, sa = TL.choose_slices(n_local if os.environ.get("GJ_RANK_SLICES", "ext") == "owned"
-                                         else n_local + len(halo_global))
+                # slices sized for the OWNED agents: phase D runs one workgroup per owned slice, and a rank whose halo
+                # is as large as its share (C3 at 8 ranks: 1.25 M owned, 1.4 M halo) would otherwise keep half of the
+                # CUs idle there (measured, tools/rank_share.py: 0.126 -> 0.121 ms per step with the venue blocks sized
+                # by the owned slices too, DistributedHotPath; GJ_RANK_SLICES=ext is the old rule)
+                _, sa = TL.choose_slices(n_local + len(halo_global) if os.environ.get("GJ_RANK_SLICES", "owned") == "ext"
+                                         else n_local)
             n_local_pad = -(-n_local // sa) * sa if len(halo_global) else n_local
             n_ext = n_local_pad + len(halo_global)
             n_slices = max(1, -(-n_ext // sa))
@@ -414,11 +415,14 @@ class DistributedHotPath:
         rw = self.rw = rank_world if rank_world is not None else build_rank_world(world, rank, world_size, modes,
                                                                                   progress=progress)
         specs, networks, betas = expand_split_networks(specs, world["networks"], betas, rw.edge_sets)
+        plan_kw = dict(plan_kw or {})
+        if os.environ.get("GJ_RANK_SLICES", "owned") != "ext":     # venue blocks for the owned slices' tiles (see finish())
+            plan_kw.setdefault("eb_target", TL.choose_block_edges(max(1, -(-rw.n_local // rw.slice_agents))))
         leisure = tuple(s for s in rw.edge_sets if s.split(SPLIT_SUFFIX)[0] == "leisure")
         host = compile_plan(rw.n_local, rw.edge_sets, age=rw.age, sex=rw.sex, n_ext_agents=rw.n_ext,
                             layout="tiled", slices=(rw.n_slices, rw.slice_agents), progress=progress,
                             device=self.device if device_compile else None, leisure_sets=leisure or ("leisure",),
-                            **(plan_kw or {}))
+                            **plan_kw)
         self.set_of = {sp.name: sp.edge_set for sp in specs}
         # The production step scatters the partial-sum sets (phase A) while the halo all-to-all may still be writing the
         # halo part of the transmission array: safe because those sets keep only the rank's OWN agents' edges, i.e. no
