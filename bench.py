@@ -45,8 +45,8 @@ def parse():
     ap.add_argument("--slice-agents", type=int, default=None, help="tiled: agents per slice (multiple of 64)")
     ap.add_argument("--device-compile", action="store_true", help="(default; kept for old command lines)")
     ap.add_argument("--host-compile", action="store_true",
-                    help="compile the contact graph with numpy on the host instead of on the GPU (torch ops; the same "
-                         "arrays, ~13 s instead of ~1 s for the default workload)")
+                    help="compile the contact graph with numpy on the host instead of by the library's compile kernels on "
+                         "the GPU (the same arrays, ~13 s instead of ~0.5 s for the default workload)")
     ap.add_argument("--tune", default="auto", choices=["auto", "on", "off"],
                     help="measure candidate tile geometries at set-up and keep the fastest "
                          "(auto: single-GPU worlds of at most 4e7 set-edges, where compiling takes seconds)")
