@@ -22,9 +22,10 @@ _CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 
 #: device layout the API mirrors compile worlds into: "tiled" (LDS-tiled fast path, default) or "csr"
 DEFAULT_LAYOUT = os.environ.get("GRAD_JUNE_AMD_LAYOUT", "tiled")
-#: compile the contact graph on the GPU (gj_compile_* kernels, tiling_native) instead of numpy on the host: worlds of 10^7+ agents
-#: then compile in about a second.  Opt-in (GRAD_JUNE_AMD_DEVICE_COMPILE=1 or set this flag); same arrays.
-DEVICE_COMPILE = os.environ.get("GRAD_JUNE_AMD_DEVICE_COMPILE", "0") == "1"
+#: where the contact graph is compiled: "auto" (default) = by the library's compile kernels (gj_compile_*, tiling_native)
+#: when the world's edge lists already live on the HIP device - what Runner.get_data leaves behind - else with numpy on
+#: the host; "1" / "0" force one or the other.  The plans are identical array for array.
+DEVICE_COMPILE = os.environ.get("GRAD_JUNE_AMD_DEVICE_COMPILE", "auto")
 
 
 def _np(x) -> np.ndarray:
@@ -111,7 +112,9 @@ def engine_for(data, specs: Sequence[NetworkSpec], device) -> InfectionEngine:
     sex = _np(agent["sex"]) if "sex" in agent else None
     if age is None and any(n.table is not None for n in specs):
         raise KeyError("leisure networks need data['agent'].age and .sex")
-    if DEVICE_COMPILE and DEFAULT_LAYOUT == "tiled":
+    on_device = all(isinstance(v["_ei"], torch.Tensor) and v["_ei"].device.type == "cuda" for v in sets.values())
+    use_device = DEVICE_COMPILE in ("1", True) or (DEVICE_COMPILE == "auto" and on_device and len(sets) > 0)
+    if use_device and DEFAULT_LAYOUT == "tiled":
         on_dev = {k: {"agent": v["_ei"][0], "venue": v["_ei"][1], "people": v["people"]} for k, v in sets.items()}
         host = compile_plan(n_agents, on_dev, age=age, sex=sex, layout="tiled", device=device)
     else:

@@ -469,7 +469,8 @@ def test_locality_order_gives_the_same_probabilities(G, device):
 
 
 def test_api_with_device_side_compile(G, device):
-    """world.DEVICE_COMPILE: the Runner's plan compiled on the GPU gives the same run as the host-compiled one."""
+    """world.DEVICE_COMPILE: the Runner's plan compiled on the GPU by the library's compile kernels (the default when the
+    world's edge lists are on the device) gives the same run as the host-compiled one."""
     from grad_june_amd import world as W
 
     def run():
@@ -484,10 +485,15 @@ def test_api_with_device_side_compile(G, device):
             res, inf = runner()
         return res["cases_per_timestep"].cpu(), inf.cpu()
 
-    ref = run()
-    W.DEVICE_COMPILE = True
+    assert W.DEVICE_COMPILE == "auto"
     try:
+        W.DEVICE_COMPILE = "0"
+        ref = run()
+        W.DEVICE_COMPILE = "1"
         got = run()
+        W.DEVICE_COMPILE = "auto"
+        auto = run()
     finally:
-        W.DEVICE_COMPILE = False
+        W.DEVICE_COMPILE = "auto"
     assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and ref[0][-1] > 0
+    assert torch.equal(auto[0], ref[0]) and torch.equal(auto[1], ref[1])
