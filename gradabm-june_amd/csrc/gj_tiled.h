@@ -685,7 +685,11 @@ __device__ __forceinline__ void direct_load(const TileDArgs& D, const TDirect& T
   const uint8_t* cls = D.cls + base;
 #pragma unroll
   for (int u = 0; u < kQuadsPerLane; ++u) {
-    const unsigned q = min((unsigned)(tid + u * kTileThreads), last_quad);     // clamped: unconditional, all in flight
+    unsigned q = min((unsigned)(tid + u * kTileThreads), last_quad);           // clamped: unconditional, all in flight
+    // (opaque to the optimiser: hipcc otherwise hoists the five 64-bit class addresses out of the item loop as
+    // invariants and pays for the ten registers with scratch spills - 144 bytes per lane, more than the XCD's L2 holds
+    // for its 32 workgroups, i.e. HBM traffic)
+    asm volatile("" : "+v"(q));
     const uint4 r = *reinterpret_cast<const uint4*>(ell + 8u * q);
     b.w[u][0] = r.x;
     b.w[u][1] = r.y;
@@ -732,7 +736,11 @@ __device__ __forceinline__ void direct_add(const TileDArgs& D, const TDirect& T,
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int c = 0; c < K; ++c) x[j][c] = 0.0f;
-      for (int k = 0; k < nk; ++k) {            // per entry: sum over the set's networks, in network order
+      // (fully unrolled with a uniform early exit: network k is then a constant offset of the LDS reads; as a rolled
+      // loop hipcc keeps a dozen strength-reduced address registers alive across it and spills around it)
+#pragma unroll
+      for (int k = 0; k < GJ_MAX_NETS_PER_SET; ++k) {   // per entry: sum over the set's networks, in network order
+        if (k >= nk) break;
         float w[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) w[j] = wtab[k * 200 + ((b.cls[u] >> (8 * j)) & 0xFF)];
@@ -982,7 +990,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
     float sq[kQ][4];
 #pragma unroll
     for (int m = 0; m < kQ; ++m) {
-      const int i0 = 4 * (tid + m * kTileThreads);
+      int i0 = 4 * (tid + m * kTileThreads);
+      asm volatile("" : "+v"(i0));          // (computed here, not carried through the direct sets as five 64-bit addresses)
 #pragma unroll
       for (int j = 0; j < 4; ++j) sq[m][j] = 0.0f;
       if (i0 < n_local) load_quad(D.susceptibility, base + i0, n_local - i0, vec, sq[m]);
