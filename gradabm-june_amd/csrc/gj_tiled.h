@@ -353,7 +353,10 @@ __device__ __forceinline__ void gather_set(const TSetA& T, fx_t* lds_acc, uint32
 }
 
 // ---- phase A: scatter the slice's transmissions to every edge, in block-major tile order -------
-__global__ __launch_bounds__(kTileThreads) void k_tile_scatter(const TileAArgs A) {
+#ifndef GJ_SCATTER_WAVES_PER_SIMD
+#define GJ_SCATTER_WAVES_PER_SIMD 4      // 8: two workgroups per CU (<= 64 VGPRs; the slice's 80 KB of LDS allow it)
+#endif
+__global__ __launch_bounds__(kTileThreads, GJ_SCATTER_WAVES_PER_SIMD) void k_tile_scatter(const TileAArgs A) {
   extern __shared__ __align__(16) float lds_x[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid / kWave), lane = tid % kWave;
