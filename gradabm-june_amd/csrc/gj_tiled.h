@@ -1071,6 +1071,26 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
   // the whole slice instead of one per quad that holds a new case (a wave covers 256 agents per iteration: at one
   // new case per thousand agents a quarter of the iterations would wait on these loads)
   GJ_STAMP(6);
+#ifndef GJ_TAIL_BATCHED
+  // Each lane takes its new cases one after the other: one memory round trip per case of the wave's busiest lane (a wave
+  // of 1 280 agents has a handful of new cases per step, two in one lane are rare), three loads issued together, ~30
+  // instructions.  (The batched form below - every (quad, agent) slot of the lane loaded straight-line, idle slots
+  // reading the slice's first agent - pays one round trip too, but 60 loads, 60 predicated stores and their address
+  // selects per lane whether there is a case or not: 8 % of the launch.)
+  if (__builtin_amdgcn_ballot_w64(infected != 0u) != 0ull) {
+    uint32_t todo = infected;
+    while (todo) {
+      const int k = __builtin_ctz(todo);
+      todo &= todo - 1u;
+      const int64_t a = base + 4 * (tid + (k >> 2) * kTileThreads) + (k & 3);
+      float sc = D.susceptibility[a], inf = D.is_infected[a], tinf = D.infection_time[a];
+      infect(1.0f, now, sc, inf, tinf);
+      D.susceptibility[a] = sc;
+      D.is_infected[a] = inf;
+      D.infection_time[a] = tinf;
+    }
+  }
+#else
   if (__builtin_amdgcn_ballot_w64(infected != 0u) != 0ull) {
     // straight-line loads: a lane without a case at (m, j) reads the slice's first agent instead (one line for the
     // whole wave) - a load under its own branch would be waited for on its own
@@ -1100,6 +1120,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
       }
     }
   }
+#endif
   GJ_STAMP(5);
 }
 
