@@ -28,6 +28,40 @@ DEFAULT_LAYOUT = os.environ.get("GRAD_JUNE_AMD_LAYOUT", "tiled")
 DEVICE_COMPILE = os.environ.get("GRAD_JUNE_AMD_DEVICE_COMPILE", "auto")
 
 
+#: tile geometry of mid-size worlds: "auto" (default) = when the plan is compiled on the device (milliseconds per
+#: candidate) and the world has 2e5 .. 4e7 set-edges, compile it under a few candidate geometries, time the two
+#: sparse passes on dummy data and keep the fastest - the size-based defaults of tiling.py are right for ~1.5
+#: memberships per agent and set, denser worlds (BASELINE's C2: 5) want larger tiles (0.156 -> 0.110 ms per step);
+#: "0" = always the defaults.  The geometry never changes a result: the passes sum in fixed point / in ELL order.
+TUNE = os.environ.get("GRAD_JUNE_AMD_TUNE", "auto")
+TUNE_CANDIDATES = ({}, {"eb_target": 131072, "sv_max": 16384}, {"eb_target": 65536, "sv_max": 16384})
+TUNE_MIN_EDGES, TUNE_MAX_EDGES = 200_000, 40_000_000
+N_MAX_TUNE_NETS = 16
+
+
+def _time_passes(engine: InfectionEngine, specs, steps: int = 8) -> float:
+    """ms per (scatter, venues, agents without decision) on dummy data - what the tuner compares."""
+    import time
+
+    plan = engine.plan
+    dev = plan.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    bufs = AgentBuffers(plan, susceptibility=torch.ones(plan.host.n_agents, dtype=torch.float32, device=dev),
+                        transmission=torch.rand(plan.host.n_ext_agents, dtype=torch.float32, device=dev, generator=g))
+    names = [n.name for n in specs]
+    p = engine.params(now=1.0, delta_time=1.0, day_type=0, active=names, betas=dict.fromkeys(names, 1.0))
+    io = engine.io(not_infected_probs=torch.empty(plan.host.n_agents, dtype=torch.float32, device=dev))
+    for it in range(steps + 2):
+        if it == 2:
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+        for phase in (1, 2, 4):
+            engine.step_phase(bufs, p, io, phase)
+    torch.cuda.synchronize(dev)
+    return 1e3 * (time.perf_counter() - t0) / steps
+
+
 def _np(x) -> np.ndarray:
     if isinstance(x, torch.Tensor):
         return x.detach().cpu().numpy()
@@ -116,6 +150,23 @@ def engine_for(data, specs: Sequence[NetworkSpec], device) -> InfectionEngine:
     use_device = DEVICE_COMPILE in ("1", True) or (DEVICE_COMPILE == "auto" and on_device and len(sets) > 0)
     if use_device and DEFAULT_LAYOUT == "tiled":
         on_dev = {k: {"agent": v["_ei"][0], "venue": v["_ei"][1], "people": v["people"]} for k, v in sets.items()}
+        n_edges = sum(int(v["_ei"].shape[1]) for v in sets.values())
+        best = None
+        if TUNE == "auto" and TUNE_MIN_EDGES <= n_edges <= TUNE_MAX_EDGES and len(specs) <= N_MAX_TUNE_NETS:
+            with torch.cuda.device(device):
+                for cand in TUNE_CANDIDATES:
+                    h = compile_plan(n_agents, on_dev, age=age, sex=sex, layout="tiled", device=device, **cand)
+                    e = InfectionEngine(DevicePlan(h, [n for n in specs if n.edge_set in h.set_index], device))
+                    ms = _time_passes(e, [n for n in specs if n.edge_set in h.set_index])
+                    if best is None or ms < best[0]:
+                        best = (ms, h, e)
+                    del h, e
+        if best is not None:
+            host, engine = best[1], best[2]
+            if len(per_data) >= 4:
+                per_data.pop(next(iter(per_data)))
+            per_data[sig] = engine
+            return engine
         host = compile_plan(n_agents, on_dev, age=age, sex=sex, layout="tiled", device=device)
     else:
         host = compile_plan(n_agents, {k: {kk: vv for kk, vv in v.items() if kk != "_ei"} for k, v in sets.items()},

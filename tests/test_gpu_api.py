@@ -497,3 +497,54 @@ def test_api_with_device_side_compile(G, device):
         W.DEVICE_COMPILE = "auto"
     assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and ref[0][-1] > 0
     assert torch.equal(auto[0], ref[0]) and torch.equal(auto[1], ref[1])
+
+
+def test_api_geometry_tuning_changes_speed_not_results(G, device):
+    """world.TUNE: a mid-size world compiled through the API mirrors (edge lists on the device) is compiled under a few
+    tile geometries and the fastest kept; whichever it is, a step gives bitwise the same state as with the defaults."""
+    import bench as B
+    from grad_june_amd import world as W
+    from grad_june_amd.engine import AgentBuffers
+    from grad_june_amd.synthetic import make_world
+
+    world = make_world("c2", n_agents=1_000_000, seed=5, infected_fraction=0.05)      # BASELINE configs[1]
+
+    def data_of():
+        d = G.HeteroData()
+        ag = d["agent"]
+        ag.id = torch.arange(world["n_agents"])
+        ag.age, ag.sex = torch.from_numpy(world["age"]), torch.from_numpy(world["sex"])
+        for s, es in world["edge_sets"].items():
+            d[s].id = torch.arange(len(es["people"]))
+            d[s].people = torch.from_numpy(es["people"])
+            d["agent", "attends_" + s, s].edge_index = torch.vstack((torch.from_numpy(es["agent"]), torch.from_numpy(es["venue"])))
+        return d.to(device)
+
+    specs, betas = B.network_specs(world), B.betas_of(world)
+
+    def step_with(tune):
+        W.TUNE = tune
+        try:
+            data = data_of()
+            eng = W.engine_for(data, specs, device)
+        finally:
+            W.TUNE = "auto"
+        st = {k: torch.from_numpy(v).to(device) for k, v in world["state"].items()}
+        n = world["n_agents"]
+        new = torch.empty(n, device=device)
+        bufs = AgentBuffers(eng.plan, max_infectiousness=st["max_infectiousness"], shape=st["shape"], rate=st["rate"],
+                            shift=st["shift"], infection_time=st["infection_time"], is_infected=st["is_infected"],
+                            susceptibility=st["susceptibility"], transmission=torch.zeros(n, device=device))
+        p = eng.params(now=1.0, delta_time=1.0, day_type=0, active=[s.name for s in specs], betas=betas, seed=3, step=0)
+        eng.step(bufs, p, eng.io(new_infected=new))
+        torch.cuda.synchronize()
+        geo = tuple((s.name, s.tiled.n_blocks) for s in eng.plan.host.sets)
+        return st, new, geo, W._time_passes(eng, specs)
+
+    st0, new0, geo0, ms0 = step_with("0")
+    st1, new1, geo1, ms1 = step_with("auto")
+    for k in ("is_infected", "susceptibility", "infection_time"):
+        assert torch.equal(st0[k], st1[k]), k
+    assert torch.equal(new0, new1) and float(new0.sum()) > 0
+    assert ms1 <= ms0 * 1.10            # the tuner keeps the defaults unless another geometry measured faster
+    print(f"defaults {ms0:.3f} ms {geo0}; tuned {ms1:.3f} ms {geo1}")
