@@ -63,10 +63,18 @@ def parse():
     ap.add_argument("--direct", default="auto", choices=["auto", "off"],
                     help="pass 2 of sets with few venues straight from an LDS table of venue values (auto) or, like the "
                          "other sets, through the per-edge workspace (off)")
-    ap.add_argument("--graph", action="store_true",
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"], nargs="?", const="on",
                     help="N > 1: capture the production step (kernels + RCCL collectives) in a hipGraph after the warm-up "
-                         "and replay it per timed step (13.5 us of host time per step instead of ~100; verified under RCCL "
-                         "with one rank only, hence opt-in)")
+                         "and replay it per timed step (13.5 us of host time per step instead of ~100).  auto (default): "
+                         "capture, replay ONE step against an eager step from the same state and keep the graph only if "
+                         "every rank's state agrees bit for bit - otherwise the eager step is timed and the JSON says why")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the K-step timed region is run this many times back to back; `value` is the FIRST region, the "
+                         "others give min / median / max (one 11 ms region per run is a noisy round-over-round figure)")
+    ap.add_argument("--backward", action="store_true",
+                    help="row f3: time forward and backward of a T-step differentiable run (the eight log_beta as "
+                         "nn.Parameter, loss = cases of the last step) instead of the forward-only hot path")
+    ap.add_argument("--backward-steps", type=int, default=4, help="--backward: timesteps on the autograd graph")
     ap.add_argument("--no-events", action="store_true",
                     help="diagnostic: time the K steps as plain gj_step calls, without HIP events between the launches")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -83,7 +91,9 @@ def parse():
     ap.add_argument("--work-order", default=None, choices=["heavy", "light", "mixed", "set"],
                     help="experiments: order of the venue launch's (set, block) work list (default: heaviest first)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=150.0,
+                    help="wall-clock bound of the CPU baseline (SURVEY 8d protocol: 3 warm-up + 10 timed steps, no_grad "
+                         "and autograd on; a leg that would exceed the bound stops early and says so in `sample`)")
     return ap.parse_args()
 
 
@@ -145,7 +155,10 @@ def kernel_bytes(world, networks):
 
 
 def cpu_baseline(world, networks, betas, tables, budget_s):
-    """The CPU oracle (= the reference's ATen op sequence) timed on this host, bounded sample."""
+    """The CPU oracle (= the reference's ATen op sequence) timed on this host.  Protocol of SURVEY 8d: 3 warm-up
+    + 10 timed steps of the same workload, once under no_grad and once with autograd on (the reference's default:
+    the state is chained functionally, model.py:103-110, and every step stays on the graph of the log_beta
+    parameters).  ``value`` is the no_grad figure - the faster of the two."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import gj_oracle as O
 
@@ -158,30 +171,52 @@ def cpu_baseline(world, networks, betas, tables, budget_s):
     torch.set_num_threads(cores)
     w = {"n_agents": world["n_agents"], "age": torch.from_numpy(world["age"]), "sex": torch.from_numpy(world["sex"]),
          "edge_sets": {k: {kk: torch.from_numpy(vv) for kk, vv in v.items()} for k, v in world["edge_sets"].items()}}
-    st = {k: torch.from_numpy(v.copy()) for k, v in world["state"].items()}
     tabs = {k: torch.from_numpy(v) for k, v in tables.items()}
-    kw = dict(delta_time=1.0, day_type=0, active=networks, betas=betas, leisure_tables=tabs,
-              quarantine_thresholds=None)
-    times = []
-    with torch.no_grad():
-        t0 = time.perf_counter()
-        out = O.hot_path_step(w, st, now=1.0, **kw)           # warm-up (also first-touch)
-        first = time.perf_counter() - t0
-        n = 0
-        t_start = time.perf_counter()
-        while n < 10 and (time.perf_counter() - t_start + first) < budget_s:
-            for k in ("susceptibility", "is_infected", "infection_time"):
-                st[k] = out[k]
-            t0 = time.perf_counter()
-            out = O.hot_path_step(w, st, now=2.0 + n, **kw)
-            times.append(time.perf_counter() - t0)
-            n += 1
-    if not times:
-        times = [first]
-    sps = 1.0 / float(np.mean(times))
+    t_begin = time.perf_counter()
+
+    def leg(autograd: bool, deadline: float):
+        st = {k: torch.from_numpy(v.copy()) for k, v in world["state"].items()}
+        if autograd:
+            # what example_scripts/run_model.py:5-8 does: every log_beta an nn.Parameter, beta = 10 ** log_beta
+            logb = {n: torch.nn.Parameter(torch.tensor(DEFAULT_LOG_BETA[n])) for n in networks}
+            b = {n: 10.0 ** logb[n] for n in networks}
+        else:
+            b = betas
+        kw = dict(delta_time=1.0, day_type=0, active=networks, betas=b, leisure_tables=tabs,
+                  quarantine_thresholds=None)
+        times, warm = [], 0
+        with torch.enable_grad() if autograd else torch.no_grad():
+            for i in range(13):
+                t0 = time.perf_counter()
+                out = O.hot_path_step(w, st, now=1.0 + i, **kw)
+                dt = time.perf_counter() - t0
+                for k in ("susceptibility", "is_infected", "infection_time"):
+                    st[k] = out[k]            # chained: with autograd on the graph grows step by step, as in the reference
+                if i < 3:
+                    warm += 1
+                else:
+                    times.append(dt)
+                if time.perf_counter() + dt > deadline and len(times) >= 2:
+                    break
+        return times, warm
+
+    half = t_begin + 0.45 * budget_s
+    t_ng, w_ng = leg(False, half)
+    t_ag, w_ag = leg(True, t_begin + budget_s)
+    sps = 1.0 / float(np.mean(t_ng))
+    sps_ag = 1.0 / float(np.mean(t_ag))
+    n_edges = sum(len(world["edge_sets"][_es(n_)]["agent"]) for n_ in networks)
     return {"value": sps, "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": f"{len(times)} full steps of the same workload (after 1 warm-up step), torch CPU ops, no_grad",
-            "edges_per_s": sps * sum(len(world["edge_sets"][_es(n_)]["agent"]) for n_ in networks)}
+            "sample": f"{len(t_ng)} timed full steps of the same workload after {w_ng} warm-up steps, torch CPU ops, "
+                      f"no_grad (wall-clock bound {budget_s:g} s for both legs)",
+            "edges_per_s": sps * n_edges,
+            "ms_per_step": {"mean": 1e3 * float(np.mean(t_ng)), "min": 1e3 * float(np.min(t_ng)),
+                            "max": 1e3 * float(np.max(t_ng))},
+            "autograd_on": {"value": sps_ag, "unit": "steps/s", "edges_per_s": sps_ag * n_edges,
+                            "sample": f"{len(t_ag)} timed steps after {w_ag} warm-up steps, log_beta as nn.Parameter, "
+                                      "state chained on the autograd graph (forward only; the reference's default mode)",
+                            "ms_per_step": {"mean": 1e3 * float(np.mean(t_ag)), "min": 1e3 * float(np.min(t_ag)),
+                                            "max": 1e3 * float(np.max(t_ag))}}}
 
 
 def _es(n):
@@ -240,8 +275,168 @@ def cached_world(args, progress, make_world):
     return w
 
 
+def backward_bench(args, world, specs, networks, dev, progress):
+    """Row f3 measured (example_scripts/run_model.py:5-11: every log_beta an nn.Parameter, ``cases.backward()``):
+    T chained differentiable steps (autograd.HotPathStep: the fused forward step + a hand-written backward that
+    recomputes the two sparse passes and runs them transposed) and the backward through all of them."""
+    from types import SimpleNamespace
+
+    from grad_june_amd.autograd import HotPathStep
+    from grad_june_amd.benchrun import SingleGpuHotPath
+    from grad_june_amd.synthetic import algorithmic_bytes, network_edges
+
+    betas = betas_of(world)
+    r = SingleGpuHotPath(world, specs, betas, dev, seed=args.seed, device_compile=not args.host_compile,
+                         progress=progress)
+    logb = {n: torch.nn.Parameter(torch.tensor(DEFAULT_LOG_BETA[n], device=dev)) for n in networks}
+    nets = [SimpleNamespace(name=n, log_beta=logb[n]) for n in networks]
+    fixed = {k: r.state[k] for k in ("max_infectiousness", "shape", "rate", "shift")}
+    T = args.backward_steps
+    state0 = [r.state[k].clone() for k in ("susceptibility", "is_infected", "infection_time")]
+
+    def once():
+        for v in logb.values():
+            v.grad = None
+        s, i, t = state0
+        torch.cuda.synchronize()
+        t_a = time.perf_counter()
+        for k in range(T):
+            params = r.engine.params(now=1.0 + k, delta_time=1.0, day_type=0, active=networks, betas=betas,
+                                     seed=args.seed, step=k)
+            env = {"engine": r.engine, "params": params, "fixed": fixed, "stage": None, "exp_noise": None,
+                   "nets": nets, "betas": betas}
+            s, i, t, _new = HotPathStep.apply(env, s, i, t, *[n.log_beta for n in nets])
+        loss = i.sum()                      # cases after the last step (runner.py:167)
+        torch.cuda.synchronize()
+        t_b = time.perf_counter()
+        loss.backward()
+        torch.cuda.synchronize()
+        t_c = time.perf_counter()
+        return 1e3 * (t_b - t_a) / T, 1e3 * (t_c - t_b) / T, float(loss), [float(v.grad) for v in logb.values()]
+
+    for _ in range(max(1, args.warmup // 2)):
+        once()
+    runs = [once() for _ in range(max(3, args.repeats))]
+    fwd = float(np.median([x[0] for x in runs]))
+    bwd = float(np.median([x[1] for x in runs]))
+    b_step = algorithmic_bytes(world, networks)
+    kb = kernel_bytes(world, networks)
+    A = world["n_agents"]
+    # a backward step = the forward's two sparse passes recomputed (no decision) + the same two passes transposed
+    # + three elementwise adjoints (sampler/epilogue: ~13 arrays, transmission profile: ~9, q-transmission) and the
+    # per-venue dot products of d/d log_beta (two reads of every cum)
+    sparse = kb["tile_scatter"] + kb["tile_venues"] + (kb["tile_agents"] - 32 * A)
+    b_bwd = 2 * sparse + kb["transmission"] + (13 + 9) * 4 * A
+    return {
+        "metric": "differentiable simulation steps/sec (forward + backward)", "value": 1e3 / (fwd + bwd),
+        "unit": "steps/s", "n_gpus": 1, "steps": T, "warmup": max(1, args.warmup // 2), "ms_per_step": fwd + bwd,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.preset}: {A} agents, {len(networks)} infection networks, "
+                               f"{network_edges(world, networks)} network-edges, {T} chained differentiable steps, "
+                               f"loss = cases after the last step, d/d log_beta of every network"},
+        "forward_ms_per_step": fwd, "backward_ms_per_step": bwd, "backward_over_forward": bwd / fwd,
+        "runs": [{"forward_ms": x[0], "backward_ms": x[1]} for x in runs],
+        "algorithmic_bytes": {"forward_step": b_step, "backward_step": b_bwd},
+        "roofline": {"bound": "hbm", "kernel": "backward step (all launches)", "achieved": b_bwd / (bwd * 1e-3) / 1e9,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b_bwd / (bwd * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "traffic": None},
+        "loss": runs[-1][2], "grad_log_beta": dict(zip(networks, runs[-1][3])),
+    }
+
+
+def auto_parts(n_agents: int) -> int:
+    """One GPU: agent partitions stepped in turn (distributed.PartitionedHotPath) once a single partition's tiles get
+    too small.  Threshold and partition size from the sweep in profiles/ ("size scaling")."""
+    return 1 if n_agents <= 48_000_000 else -(-n_agents // 16_000_000)
+
+
+def self_launch(args) -> int:
+    """``python bench.py --gpus N`` (N > 1) outside a torch.distributed environment: start the N ranks as CHILD
+    processes (``python -m torch.distributed.run``, one rank per GPU, rendezvous on 127.0.0.1), relay rank 0's JSON
+    line and return the children's exit code.  This process never touches the GPU (torch.cuda.device_count() does
+    not initialise it) and never replaces itself with another program."""
+    import socket
+    import subprocess
+
+    if args.backend == "nccl":
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus:
+            print(f"bench.py --gpus {args.gpus}: this node shows {n_dev} GPU(s); one rank per GPU is needed "
+                  f"(diagnostics with ranks sharing a GPU: --backend gloo)", file=sys.stderr)
+            return 2
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:       # a free rendezvous port
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this pool
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, args.gpus))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    print(f"[bench] starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:                      # rank 0 prints exactly one JSON line; anything else goes to stderr
+        try:
+            if "metric" in json.loads(out):
+                line = out
+                continue
+        except ValueError:
+            pass
+        sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    elif rc == 0:
+        print("bench.py: the ranks exited without a result line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+def capture_validated(runner, dev, backend, dist):
+    """N > 1: capture the production step in a hipGraph and keep it only if ONE replayed step reproduces an eager
+    step from the same state bit for bit on every rank.  Returns (graph in use, reason).  Whatever the outcome the
+    state has advanced by exactly one step."""
+    if backend != "nccl":
+        runner.step()
+        return False, "gloo backend: collectives are staged through the host and cannot be captured"
+    keys = [k for k in ("is_infected", "susceptibility", "infection_time", "transmission", "q_transmission")
+            if runner.state.get(k) is not None]
+    saved = {k: runner.state[k].clone() for k in keys}
+    t_saved = runner.t
+    runner.step()                                   # the eager production step
+    torch.cuda.synchronize()
+    ref = {k: runner.state[k].clone() for k in keys}
+    ref_new = runner.new_infected.clone()
+    for k in keys:
+        runner.state[k].copy_(saved[k])
+    runner.t = t_saved
+    ok, reason = True, "replay of one step == the eager step, every rank"
+    try:
+        runner.capture()
+        runner.step()                               # first replay: the same step again
+        torch.cuda.synchronize()
+        if not (all(torch.equal(runner.state[k], ref[k]) for k in keys) and torch.equal(runner.new_infected, ref_new)):
+            ok, reason = False, "the replayed step differs from the eager step"
+    except Exception as e:                          # capture is not supported for something in the step
+        ok, reason = False, f"capture failed: {type(e).__name__}: {e}"
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)     # every rank takes the same path
+    if int(flag.item()) == 0:
+        if ok:
+            reason = "another rank's replay differed or failed"
+        runner.drop_graph()
+        for k in keys:                              # the eager step's result, so that every rank continues from one state
+            runner.state[k].copy_(ref[k])
+        runner.t = t_saved + 1
+        return False, reason
+    return True, reason
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     # stdout carries exactly ONE line, the JSON result: libraries that print to fd 1 (RCCL's version banner
     # at init, for one) are sent to stderr for the duration of the run
     sys.stdout.flush()
@@ -253,8 +448,8 @@ def main():
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world_size:
-        if world_size == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: start bench.py plainly (it launches its "
+                         f"ranks itself) or under torch.distributed.run with --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU path)")
     if args.backend == "gloo":
@@ -267,6 +462,7 @@ def main():
     if rank == 0:
         entry.build()
     distributed = world_size > 1 or args.force_distributed
+    dist = None
     if distributed:
         import torch.distributed as dist
 
@@ -313,6 +509,13 @@ def main():
     tables = {s.name: s.table for s in specs if s.table is not None}
     t_gen = time.time() - t0
 
+    if args.backward:
+        if distributed:
+            raise SystemExit("--backward is a single-GPU measurement")
+        out = backward_bench(args, world, specs, networks, dev, progress)
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+        return
+
     if distributed:
         from grad_june_amd.distributed import DistributedHotPath, choose_modes
 
@@ -323,7 +526,8 @@ def main():
         runner = DistributedHotPath(world, specs, betas, dev, rank, world_size, seed=args.seed, modes=modes,
                                     progress=progress, quarantine_threshold=args.quarantine, rank_world=rw,
                                     total_edges=None if share is None else share["total_edges"],
-                                    device_compile=device_compile)
+                                    device_compile=device_compile,
+                                    production_at_one_rank=world_size == 1)   # diagnostic: the overlapped multi-rank step
         extra = {"exchange": {"modes": runner.rw.modes, "halo_agents_rank0": int(runner.rw.n_halo),
                               "halo_bytes_per_step_rank0": runner.halo.bytes_per_step if runner.halo else 0,
                               "partial_sum_floats": int(runner.flat_cum.numel()) if runner.flat_cum is not None else 0}}
@@ -343,8 +547,7 @@ def main():
             if args.slice_agents:
                 sa = args.slice_agents
                 kw["slices"] = (-(-world["n_agents"] // sa), sa)
-        parts = args.parts if args.parts > 0 else (1 if world["n_agents"] <= 48_000_000
-                                                   else -(-world["n_agents"] // 16_000_000))
+        parts = args.parts if args.parts > 0 else auto_parts(world["n_agents"])
         if parts > 1 and args.layout == "tiled":
             from grad_june_amd.distributed import PartitionedHotPath
 
@@ -375,14 +578,17 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    graph_on, graph_reason = False, "single GPU: the step is one gj_step call"
+    want_graph = distributed and hasattr(runner, "capture") and args.graph != "off" and args.warmup > 0
+    for _ in range(args.warmup - (1 if want_graph else 0)):
         runner.step()
     sync()
-    if args.graph and distributed and hasattr(runner, "capture"):
-        runner.capture()
+    if want_graph:          # the last warm-up step is the eager step the first replay is compared with
+        graph_on, graph_reason = capture_validated(runner, dev, args.backend, dist)
         sync()
+    elif distributed:
+        graph_reason = "--graph off" if args.graph == "off" else "no warm-up step to validate a captured step against"
     runner.reset_timers()
-    t0 = time.perf_counter()
     # One GPU: launches are bracketed by HIP events (on the launch stream) INSIDE the timed region - on every
     # `events_every`-th step (every 4th; from 32 steps on, 8 of them): an event between two launches costs the GPU ~4 us (measured: 19 us per step of five
     # events, 3 % of the default workload's step and 10 % of C2's), which the production call (gj_step, no events)
@@ -390,10 +596,20 @@ def main():
     events_every = 1 if (args.steps < 12 or distributed) else max(4, args.steps // 8)     # at least 8 bracketed steps from 32 on
     if args.no_events:
         events_every = 1 << 30
-    for i in range(args.steps):
-        runner.step(timed=not distributed and i % events_every == 0)
-    sync()
-    elapsed = time.perf_counter() - t0
+
+    def region():
+        """EXACTLY K steps between two (barrier + device synchronise) pairs; max over ranks taken later."""
+        t_a = time.perf_counter()
+        for i in range(args.steps):
+            runner.step(timed=not distributed and i % events_every == 0)
+        t_issue = time.perf_counter() - t_a           # host time to issue the K steps (nothing waited for yet)
+        sync()
+        return time.perf_counter() - t_a, t_issue
+
+    elapsed, issue = region()
+    repeats = [elapsed]
+    for _ in range(max(0, args.repeats - 1)):         # the same region again, back to back: run-to-run spread
+        repeats.append(region()[0])
     if args.no_events and not distributed:
         for _ in range(args.steps):
             runner.step(timed=True)
@@ -409,10 +625,12 @@ def main():
     peak_rss_mb = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0     # this process: set-up included
     infected_local = float(runner.state["is_infected"].double().sum())
     if distributed:
-        t = torch.tensor([elapsed, peak_rss_mb], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        red_dev = dev if args.backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed, peak_rss_mb, issue] + repeats, dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, peak_rss_mb = float(t[0].item()), float(t[1].item())
-        t = torch.tensor([infected_local], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        elapsed, peak_rss_mb, issue = float(t[0].item()), float(t[1].item()), float(t[2].item())
+        repeats = [float(x) for x in t[3:].tolist()]
+        t = torch.tensor([infected_local], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         infected_local = float(t.item())
 
@@ -420,30 +638,55 @@ def main():
         dist.destroy_process_group()
         return
 
-    high = None
-    if not distributed and hasattr(runner, "load_state") and args.high_prevalence > 0:
-        from grad_june_amd.synthetic import epidemic_state
-
-        kept = {k: v.clone() for k, v in runner.state.items()}
-        kept_t = runner.t
-        runner.load_state(epidemic_state(world["n_agents"], args.high_prevalence, args.seed + 1))
-        n_hi = max(10, args.steps // 2)
-        for _ in range(3):
+    def second_region(n, pre=3, **changes):
+        """n steps under changed step parameters (runner attributes), HIP events around every launch."""
+        kept_attr = {k: getattr(runner, k) for k in changes}
+        for k, v in changes.items():
+            setattr(runner, k, v)
+        for _ in range(pre):
             runner.step()
         torch.cuda.synchronize()
         runner.reset_timers()
-        t0 = time.perf_counter()
-        for _ in range(n_hi):
+        t_a = time.perf_counter()
+        for _ in range(n):
             runner.step(timed=True)
         torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        high = {"infected_fraction_at_start": args.high_prevalence, "steps": n_hi, "ms_per_step": 1e3 * el / n_hi,
-                "steps_per_s": n_hi / el, "kernel_ms": runner.kernel_ms(),
-                "infected_fraction_at_end": float(runner.state["is_infected"].clamp(max=1).mean())}
+        el = time.perf_counter() - t_a
+        res = {"steps": n, "ms_per_step": 1e3 * el / n, "steps_per_s": n / el, "kernel_ms": runner.kernel_ms()}
+        for k, v in kept_attr.items():
+            setattr(runner, k, v)
+        runner.reset_timers()
+        return res
+
+    high = policies = None
+    single = not distributed and hasattr(runner, "load_state")
+    if single:
+        kept = {k: v.clone() for k, v in runner.state.items()}
+        kept_t = runner.t
+    if single and args.quarantine is None:
+        # second configuration of SURVEY 8d: a quarantine policy (quarantine_policies.py:13-33: agents at or beyond the
+        # stage threshold neither transmit nor receive outside their household) and social distancing
+        # (interaction_policies.py:25-31: beta factors) both active, same world, same state
+        factors = {n: (1.0 if n == "household" else 0.5) for n in networks}
+        policies = second_region(max(10, args.steps // 2), q_thr=4.0,
+                                 betas={n: betas[n] * factors[n] for n in networks})
+        policies.update({"quarantine_stage_threshold": 4.0, "beta_factors": factors,
+                         "what": "quarantine (stage >= 4 masked outside the household) + social distancing "
+                                 "(beta x 0.5 on every network but household) active in every step"})
+        for k, v in kept.items():
+            runner.state[k].copy_(v)
+        runner.t = kept_t
+    if single and args.high_prevalence > 0:
+        from grad_june_amd.synthetic import epidemic_state
+
+        runner.load_state(epidemic_state(world["n_agents"], args.high_prevalence, args.seed + 1))
+        high = second_region(max(10, args.steps // 2))
+        high.update({"infected_fraction_at_start": args.high_prevalence,
+                     "infected_fraction_at_end": float(runner.state["is_infected"].clamp(max=1).mean())})
         for k, v in kept.items():                      # back to the headline run's state for what follows
             runner.state[k].copy_(v)
         runner.t = kept_t
-        runner.reset_timers()
+    if single:
         del kept
 
     full = None
@@ -453,14 +696,14 @@ def main():
         for _ in range(3):
             runner.full_step()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        t_a = time.perf_counter()
         n_full = max(10, args.steps // 2)
         for _ in range(n_full):
             runner.full_step()
         torch.cuda.synchronize()
-        el = time.perf_counter() - t0
+        el = time.perf_counter() - t_a
         full = {"steps_per_s": n_full / el, "ms_per_step": 1e3 * el / n_full, "steps": n_full,
-                "includes": "hot path a1-a9 + symptoms kernel (f1) + per-step result reductions (f2)"}
+                "includes": "hot path a1-a9 + symptoms and per-step result reductions in one kernel (f1 + f2)"}
 
     # what the timed steps computed: variants of one kernel must agree on these (tools/ab.py prints them)
     checksum = {"infected": infected_local}      # summed over the ranks
@@ -474,8 +717,9 @@ def main():
     b_step = algorithmic_bytes(world, networks)
     kb = kernel_bytes(world, networks)
     dom = max((k for k in kt if k in kb), key=kt.get)
-    share = 1.0 / world_size         # each rank streams its own partition
-    achieved = kb[dom] * share / (kt[dom] * 1e-3) / 1e9
+    share_f = 1.0 / world_size         # each rank streams its own partition
+    achieved = kb[dom] * share_f / (kt[dom] * 1e-3) / 1e9
+    rep_ms = [1e3 * r / args.steps for r in repeats]
     out = {
         "metric": "simulation steps/sec",
         "value": sps,
@@ -501,18 +745,37 @@ def main():
         "step_roofline_frac": b_step * sps / (HBM_PEAK_GBS * 1e9 * world_size),
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "algorithmic_bytes_per_launch": kb[dom] * share, "ms_per_launch": kt[dom]},
+                     "algorithmic_bytes_per_launch": kb[dom] * share_f, "ms_per_launch": kt[dom]},
         "kernel_ms": kt,
-        "kernel_ms_method": f"HIP events around every launch of every {events_every}th step of the timed region",
+        "kernel_ms_method": (f"HIP events around every launch of every {events_every}th step of the {len(repeats)} timed "
+                             f"regions" if not distributed else
+                             "HIP events around every launch and collective of K further steps run in sequence"),
+        # the K-step region run `repeats` times back to back: `value` / `ms_per_step` are the FIRST one
+        "repeats": {"regions": len(rep_ms), "ms_per_step": rep_ms, "min": min(rep_ms),
+                    "median": float(np.median(rep_ms)), "max": max(rep_ms)},
+        "host_us_per_step": 1e6 * issue / args.steps,     # host time to ISSUE a step (launches / graph replay), first region
         "state_checksum": checksum,
         "host_peak_rss_mb": peak_rss_mb,     # max over ranks: a rank streams the world and keeps only its share
         "setup_s": {"generate": t_gen, "total": t_setup},
     }
+    if distributed:
+        kernels_only = sum(v for k, v in kt.items() if k not in ("halo_all_to_all", "partial_all_reduce"))
+        out["rccl_ranks"] = dist.get_world_size() if args.backend == "nccl" else 0
+        out["backend"] = args.backend
+        out["graph"] = graph_on
+        out["graph_reason"] = graph_reason
+        out["collective_ms_sequential"] = {k: kt[k] for k in ("halo_all_to_all", "partial_all_reduce") if k in kt}
+        # what the production step (collectives overlapped with the phases that do not need them) takes beyond
+        # this rank's kernels run back to back: collective time that did not hide + launch gaps
+        out["exposed_collective_ms_per_step"] = max(0.0, 1e3 * elapsed / args.steps - kernels_only)
+        out["kernels_ms_per_step_rank0"] = kernels_only
     out.update(extra)
     if full:
         out["full_step"] = full
     if high:
         out["high_prevalence"] = high
+    if policies:
+        out["quarantine_social_distancing"] = policies
     # HBM traffic of the dominant kernel from the committed PMC profile of this exact workload AND these exact kernel
     # sources (tools/pmc_traffic.py stamps the profile with a hash of csrc/ + the ABI header): a profile of other
     # kernels is not reported

@@ -122,7 +122,7 @@ int main(void) {
   const int64_t rows = (int64_t)S * SA;
   uint16_t* ell = (uint16_t*)dmalloc((size_t)rows * K * 2);
   CHECK(ell);
-  CHECK_GJ(gj_compile_ell(&cs, K, rows, degree, ell, ws, ws_bytes, stream));
+  CHECK_GJ(gj_compile_ell(&cs, K, rows, degree, ell, ws, ws_bytes, counts, stream));
   CHECK_HIP(hipStreamSynchronize(stream));
   uint16_t* h_ell = (uint16_t*)malloc((size_t)rows * K * 2);
   CHECK_HIP(hipMemcpy(h_ell, ell, (size_t)rows * K * 2, hipMemcpyDeviceToHost));

@@ -251,11 +251,16 @@ __global__ void k_ell_keys(const int64_t* agent, int64_t E, int64_t n_agents, ui
 }
 
 __global__ void k_ell_fill(const uint32_t* keys, const uint32_t* order, int64_t E, int64_t n_agents,
-                           const int32_t* rowptr, const int64_t* venue, int64_t rows, uint16_t* ell) {
+                           const int32_t* rowptr, const int64_t* venue, int64_t rows, int32_t ell_k, uint16_t* ell,
+                           int32_t* counts) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E; i += (int64_t)gridDim.x * blockDim.x) {
     const uint32_t a = keys[i];
     if ((int64_t)a >= n_agents) continue;
     const int col = (int)i - rowptr[a];                     // the agent's col-th edge in COO order (stable sort)
+    if (col < 0 || col >= ell_k) {                          // ell_k too small for this agent (or a stale `degree`):
+      if (counts) counts[GJ_CC_ERROR] = 5;                  // never a write outside the caller's table
+      continue;
+    }
     ell[((int64_t)(col >> 1) * rows + a) * 2 + (col & 1)] = (uint16_t)venue[order[i]];
   }
 }
@@ -377,7 +382,8 @@ static int check_set(const gj_compile_set* c) {
   if (!c) return GJ_E_NULL;
   if (c->n_edges < 0 || c->n_edges >= ((int64_t)1 << 30) || c->n_venues < 0 || c->n_agents < 0) return GJ_E_RANGE;
   if (c->n_slices < 1 || c->slice_agents < 1 || c->slice_agents > 65536) return GJ_E_RANGE;
-  if (c->sv_max < 1 || c->sv_max > 65536 || c->eb_target < 1) return GJ_E_RANGE;
+  // local venue indices are 16-bit and 0xFFFF marks a pad slot: at most 65535 venues per block (local ids 0..65534)
+  if (c->sv_max < 1 || c->sv_max > 65535 || c->eb_target < 1) return GJ_E_RANGE;
   if (c->n_edges > 0 && (!c->agent || !c->venue)) return GJ_E_NULL;
   if (c->n_agents > c->n_ext_agents || c->n_ext_agents > (int64_t)c->n_slices * c->slice_agents) return GJ_E_RANGE;
   return 0;
@@ -515,7 +521,7 @@ int gj_compile_ell_degrees(const gj_compile_set* set, int32_t* degree, int32_t* 
 }
 
 int gj_compile_ell(const gj_compile_set* set, int32_t ell_k, int64_t rows, const int32_t* degree, uint16_t* ell,
-                   void* workspace, int64_t workspace_bytes, void* stream) {
+                   void* workspace, int64_t workspace_bytes, int32_t* counts, void* stream) {
   if (const int rc = gjc::check_set(set)) return rc;
   if (!degree || !ell || !workspace) return GJ_E_NULL;
   if (ell_k < 2 || (ell_k & (ell_k - 1)) || rows < set->n_agents || set->n_venues > 65535) return GJ_E_RANGE;
@@ -531,7 +537,7 @@ int gj_compile_ell(const gj_compile_set* set, int32_t ell_k, int64_t rows, const
                                               std::min(32, gjc::bits_for((uint64_t)g.n_agents + 1)), st));
   if (const int rc = gjc::exclusive_scan(w.temp, w.temp_bytes, degree, w.rowptr, g.n_agents + 1, st)) return rc;
   gjc::k_ell_fill<<<gjc::grid_for(g.E), gjc::kThreads, 0, st>>>(w.keys_b, w.vals_b, g.E, g.n_agents, w.rowptr, set->venue,
-                                                               rows, ell);
+                                                               rows, ell_k, ell, counts);
   return (int)hipGetLastError();
 }
 

@@ -441,7 +441,7 @@ struct VenueStamp {
 // workgroup's slot idles for a few us until its successor's 16 waves are up.  Persistent workgroups that work through
 // several items each closed those gaps and took as long: with every slot busy the items stretch, the launch is bound
 // by the memory system at ~4.8 TB/s of measured traffic, not by the slots.)
-__global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B) {
+__global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B) {   // 8 waves per SIMD: two workgroups per CU (<= 64 VGPRs)
   extern __shared__ __align__(16) float lds_s[];
 #ifdef GJ_DIAG_STAMPS
   VenueStamp gj_stamp;
@@ -481,14 +481,24 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
     // the lane's own.  (Branches per slot made this launch issue three times the instructions: it is bound by
     // instruction issue, SQ_ACTIVE_INST_ANY x waves per SIMD ~ 0.8.)
     const int dummy = nk * nv + (tid & 63);
+    // Every slot's value goes to fixed point FIRST and a run of one venue is merged as integers: exact, so a venue's sum
+    // does not depend on where the block boundaries and the padding put its runs relative to the 8-slot groups - the
+    // tile geometry (eb_target, sv_max, slices) cannot change a single bit of `cum`.  (Round 2 merged the runs in fp32
+    // and converted the run totals; the launch is bound by the memory system, the extra integer adds are free.)
     auto run_sums = [&](const int (&lv)[8], const float (&x)[8], int base_k) {
-      float s8 = x[0];
+      fx_t s8 = 0;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
+        const float xq = x[q];
+        const bool ok = fabsf(xq) <= fx_max<kFxVenue>();
+        const fx_t f = to_fx<kFxVenue>(ok ? xq : 0.0f);
+        const bool first = (q == 0) || (lv[q] != lv[q - (q > 0)]);
+        s8 = first ? f : s8 + f;
         const bool last = (q == 7) || (lv[q + (q < 7)] != lv[q]);
         const bool take = last && lv[q] != 0xFFFF;
-        fx_add<kFxVenue>(sums, vflags, take ? base_k + lv[q] : dummy, take ? s8 : 0.0f);
-        if (q < 7) s8 = last ? x[q + 1] : s8 + x[q + 1];
+        atomicAdd(&sums[take ? base_k + lv[q] : dummy], take ? s8 : (fx_t)0);
+        // a NaN / infinity / out-of-range term: the venue reads back NaN
+        if (__builtin_expect(!ok && lv[q] != 0xFFFF, 0)) atomicOr(&vflags[(base_k + lv[q]) >> 5], 1u << ((base_k + lv[q]) & 31));
       }
     };
     auto add_group = [&](const uint4 raw, const float4 xa, const float4 xb, const uint2 craw) {
@@ -791,6 +801,13 @@ __device__ __forceinline__ void direct_stage(const TileDArgs& D, const TDirect& 
 // region - its venue values on their way to LDS (DMA): a memory round trip costs 4-10 us while every CU streams, and
 // with one workgroup per CU nothing else would hide it.  `cur` holds the rows of the first item, issued before the
 // caller's own LDS phase.  LDS: two class-weight buffers (sets alternate), table region 0, table region 1.
+// The barrier that publishes a DMA-staged table to the other waves: global_load_lds completes under vmcnt, and a
+// workgroup barrier by itself does not wait for it (hipcc happens to place the wait; this does not rely on that).
+__device__ __forceinline__ void publish_staged() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
 __device__ __forceinline__ bool direct_next(const TileDArgs& D, int& t, int& v0, int& plane) {
   const TDirect& T = D.direct[t];
   if (plane + 1 < T.planes) {
@@ -821,7 +838,7 @@ __device__ __forceinline__ void direct_sets(const TileDArgs& D, float (&acc)[kQu
   while (more) {
     const TDirect& T = D.direct[t];
     const int nv = min(T.group_venues, T.V - v0);
-    if (plane == 0) __syncthreads();            // this group's values have landed (vmcnt(0) + barrier) - and its rows
+    if (plane == 0) publish_staged();           // this group's values have landed (vmcnt(0) + barrier) - and its rows
 #ifdef GJ_DIAG_STAMPS
     if (threadIdx.x == 0 && D.trans_susc && t < 4)
       D.trans_susc[(int64_t)blockIdx.x * D.slice_agents + 8 + 2 * t] = (float)(__builtin_amdgcn_s_memtime() - diag_t0);

@@ -424,20 +424,19 @@ __device__ __forceinline__ float dwell_sample(int kind, float loc, float scale, 
   return kind == 1 ? expf(v) : v;
 }
 
-__global__ __launch_bounds__(kThreads) void k_symptoms(const SymptomsArgs S) {
-  const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= S.n) return;
+// One agent's stage update (symptoms.py:204-247, 82-128).  Returns true when any of the three values changed.
+__device__ __forceinline__ bool symptoms_agent(const SymptomsArgs& S, int64_t a, float nw, int cls, float& cur,
+                                               float& nx, float& tt) {
   const int n_stages = S.P.n_stages;
   const float time = S.P.time;
-  const float nw = S.new_inf[a];
-  float cur = S.cur[a], nx = S.nxt[a], tt = S.ttn[a];
+  const float cur0 = cur, nx0 = nx, tt0 = tt;
   nx = nx + nw * (2.0f - nx);                       // newly infected: next stage = exposed, due now
   tt = tt + nw * (time - tt);
   const bool moving = (time >= tt) && (cur < (float)(n_stages - 1));
   cur = cur - (cur - nx) * (moving ? 1.0f : 0.0f);
   int s = (int)cur;
   s = min(max(s, 0), n_stages - 1);
-  const int age = S.cls[a] % 100;
+  const int age = cls % 100;
   if (moving && s >= 2 && s <= n_stages - 2 && cur == (float)s) {
     bool onward;
     float d;
@@ -459,6 +458,16 @@ __global__ __launch_bounds__(kThreads) void k_symptoms(const SymptomsArgs S) {
     }
     tt = tt + d;
   }
+  // (bit comparison: a NaN that stays a NaN has not changed)
+  return __float_as_uint(cur) != __float_as_uint(cur0) || __float_as_uint(nx) != __float_as_uint(nx0) ||
+         __float_as_uint(tt) != __float_as_uint(tt0);
+}
+
+__global__ __launch_bounds__(kThreads) void k_symptoms(const SymptomsArgs S) {
+  const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= S.n) return;
+  float cur = S.cur[a], nx = S.nxt[a], tt = S.ttn[a];
+  symptoms_agent(S, a, S.new_inf[a], (int)S.cls[a], cur, nx, tt);
   S.cur[a] = cur;
   S.nxt[a] = nx;
   S.ttn[a] = tt;
@@ -655,6 +664,81 @@ __global__ __launch_bounds__(kThreads) void k_step_stats(const StatsArgs S) {
     else if (k <= GJ_MAX_AGE_BINS) dst = (k - 1 < S.n_bins) ? k : -1;
     else dst = 1 + S.n_bins;
     if (dst >= 0 && v != 0.0) atomicAdd(&S.out[dst], v);
+  }
+}
+
+// f1 + f2 in one pass (gj_symptoms_step_stats): the stage update of four agents per lane, written back only where a
+// value changed (early in an epidemic almost nobody moves: the three arrays are then read, not rewritten), and the
+// Runner's reductions taken from the registers that hold the updated stages.
+__global__ __launch_bounds__(kThreads) void k_symptoms_stats(const SymptomsArgs S, const StatsArgs R) {
+  constexpr int kOut = GJ_MAX_AGE_BINS + 2;
+  __shared__ double part[kThreads / kWave][kOut];
+  double acc[kOut];
+#pragma unroll
+  for (int k = 0; k < kOut; ++k) acc[k] = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  auto take = [&](float inf, float stage, int cls) {
+    const int age = cls % 100;
+    acc[0] += inf;
+#pragma unroll
+    for (int b = 0; b < GJ_MAX_AGE_BINS; ++b)
+      if (b < R.n_bins && age > R.edges[b] && age < R.edges[b + 1]) acc[1 + b] += inf;
+    if (stage == (float)R.dead) acc[GJ_MAX_AGE_BINS + 1] += 1.0;
+  };
+  int64_t first_scalar = 0;
+  if (R.vec4) {
+    const int64_t n4 = S.n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+      // all six loads issued before the first use
+      const float4 nw = reinterpret_cast<const float4*>(S.new_inf)[i];
+      float4 c = reinterpret_cast<const float4*>(S.cur)[i];
+      float4 x = reinterpret_cast<const float4*>(S.nxt)[i];
+      float4 t = reinterpret_cast<const float4*>(S.ttn)[i];
+      const float4 f = reinterpret_cast<const float4*>(R.inf)[i];
+      const uint32_t cl = reinterpret_cast<const uint32_t*>(S.cls)[i];
+      bool ch = symptoms_agent(S, 4 * i, nw.x, (int)(cl & 0xFF), c.x, x.x, t.x);
+      ch |= symptoms_agent(S, 4 * i + 1, nw.y, (int)((cl >> 8) & 0xFF), c.y, x.y, t.y);
+      ch |= symptoms_agent(S, 4 * i + 2, nw.z, (int)((cl >> 16) & 0xFF), c.z, x.z, t.z);
+      ch |= symptoms_agent(S, 4 * i + 3, nw.w, (int)(cl >> 24), c.w, x.w, t.w);
+      if (ch) {
+        reinterpret_cast<float4*>(S.cur)[i] = c;
+        reinterpret_cast<float4*>(S.nxt)[i] = x;
+        reinterpret_cast<float4*>(S.ttn)[i] = t;
+      }
+      take(f.x, c.x, (int)(cl & 0xFF));
+      take(f.y, c.y, (int)((cl >> 8) & 0xFF));
+      take(f.z, c.z, (int)((cl >> 16) & 0xFF));
+      take(f.w, c.w, (int)(cl >> 24));
+    }
+    first_scalar = n4 << 2;
+  }
+  for (int64_t a = first_scalar + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; a < S.n; a += stride) {
+    float cur = S.cur[a], nx = S.nxt[a], tt = S.ttn[a];
+    const int cls = (int)S.cls[a];
+    if (symptoms_agent(S, a, S.new_inf[a], cls, cur, nx, tt)) {
+      S.cur[a] = cur;
+      S.nxt[a] = nx;
+      S.ttn[a] = tt;
+    }
+    take(R.inf[a], cur, cls);
+  }
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+#pragma unroll
+  for (int k = 0; k < kOut; ++k) {
+    double v = acc[k];
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    if (lane == 0) part[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kOut) {
+    double v = 0.0;
+    for (int w = 0; w < kThreads / kWave; ++w) v += part[w][threadIdx.x];
+    const int k = threadIdx.x;
+    int dst = -1;
+    if (k == 0) dst = 0;
+    else if (k <= GJ_MAX_AGE_BINS) dst = (k - 1 < R.n_bins) ? k : -1;
+    else dst = 1 + R.n_bins;
+    if (dst >= 0 && v != 0.0) atomicAdd(&R.out[dst], v);
   }
 }
 
@@ -1362,6 +1446,47 @@ int gj_step_stats(int64_t n, const uint8_t* agent_class, const float* is_infecte
   return gj::launch_status();
 }
 
+int gj_symptoms_step_stats(int64_t n, const uint8_t* agent_class, const float* new_infected, float* current_stage,
+                           float* next_stage, float* time_to_next_stage, const gj_symptoms_params* params,
+                           const float* progresses, const float* dwell, const float* is_infected, int32_t n_bins,
+                           const int32_t* bin_edges, int32_t dead_stage, double* out, void* stream) {
+  if (n < 0 || n_bins < 0 || n_bins > GJ_MAX_AGE_BINS) return GJ_E_RANGE;
+  if (!out || (n_bins > 0 && !bin_edges)) return GJ_E_NULL;
+  if (n == 0) return GJ_OK;
+  if (!agent_class || !new_infected || !current_stage || !next_stage || !time_to_next_stage || !params || !is_infected)
+    return GJ_E_NULL;
+  if (params->n_stages < 3 || params->n_stages > GJ_MAX_STAGES) return GJ_E_RANGE;
+  if ((progresses == nullptr) != (dwell == nullptr)) return GJ_E_NULL;   // inject both or neither
+  if (!progresses && !params->progress) return GJ_E_NULL;
+  gj::SymptomsArgs S;
+  S.P = *params;
+  S.n = n;
+  S.cls = agent_class;
+  S.new_inf = new_infected;
+  S.cur = current_stage;
+  S.nxt = next_stage;
+  S.ttn = time_to_next_stage;
+  S.progresses = progresses;
+  S.dwell = dwell;
+  gj::StatsArgs R;
+  R.n = n;
+  R.cls = agent_class;
+  R.inf = is_infected;
+  R.stage = current_stage;
+  R.n_bins = n_bins;
+  for (int b = 0; b <= GJ_MAX_AGE_BINS; ++b) R.edges[b] = (b <= n_bins) ? bin_edges[b] : 0;
+  R.dead = dead_stage;
+  R.out = out;
+  const uintptr_t bits = (uintptr_t)new_infected | (uintptr_t)current_stage | (uintptr_t)next_stage |
+                         (uintptr_t)time_to_next_stage | (uintptr_t)is_infected;
+  R.vec4 = (bits % 16 == 0 && (uintptr_t)agent_class % 4 == 0) ? 1 : 0;
+  int64_t blocks = ((R.vec4 ? (n >> 2) + 3 : n) + gj::kThreads - 1) / gj::kThreads;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(gj::k_symptoms_stats, dim3((unsigned)blocks), dim3(gj::kThreads), 0, (hipStream_t)stream, S, R);
+  return gj::launch_status();
+}
+
 int gj_step(const gj_plan* plan, const gj_agent_state* state, const gj_step_params* params, const gj_step_io* io,
             void* stream) {
   int rc = gj::check_plan(plan);
@@ -1417,13 +1542,14 @@ int gj_step_phase(const gj_plan* plan, const gj_agent_state* state, const gj_ste
 }
 
 namespace gj {
-__global__ void k_clock_advance(gj_clock* clock, float delta_now) {
-  clock->now += delta_now;
-  clock->step += 1;
+__global__ void k_clock_advance(gj_clock* clock, double delta_now) {
+  const uint64_t step = clock->step + 1;
+  clock->step = step;
+  clock->now = (float)(clock->now0 + (double)(int64_t)(step - clock->step0) * delta_now);
 }
 }  // namespace gj
 
-int gj_clock_advance(gj_clock* clock, float delta_now, void* stream) {
+int gj_clock_advance(gj_clock* clock, double delta_now, void* stream) {
   if (!clock) return GJ_E_NULL;
   hipLaunchKernelGGL(gj::k_clock_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, clock, delta_now);
   return gj::launch_status();

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 from typing import Optional
 
-GJ_ABI_VERSION = 3
+GJ_ABI_VERSION = 4
 GJ_MAX_SETS = 12
 GJ_MAX_NETS = 16
 GJ_MAX_NETS_PER_SET = 8
@@ -202,7 +202,12 @@ SYMBOLS = {
         C.c_int,
         [C.POINTER(Plan), C.POINTER(AgentState), C.POINTER(StepParams), C.POINTER(StepIO), C.c_int, _vp],
     ),
-    "gj_clock_advance": (C.c_int, [_vp, C.c_float, _vp]),
+    "gj_clock_advance": (C.c_int, [_vp, C.c_double, _vp]),
+    "gj_symptoms_step_stats": (
+        C.c_int,
+        [C.c_int64, _vp, _vp, _vp, _vp, _vp, C.POINTER(SymptomsParams), _vp, _vp, _vp, C.c_int32, C.POINTER(C.c_int32),
+         C.c_int32, _vp, _vp],
+    ),
     "gj_pack_f32": (C.c_int, [C.c_int64, _vp, _vp, _vp, _vp]),
     "gj_unpack_f32": (C.c_int, [C.c_int64, _vp, _vp, _vp, _vp]),
     "gj_event_create": (C.c_int, [C.POINTER(_vp)]),
@@ -240,7 +245,7 @@ SYMBOLS.update({
     "gj_compile_tiles": (C.c_int, [C.POINTER(CompileSet), _vp, C.POINTER(CompileOut), _vp, _vp, C.c_int64, _vp]),
     "gj_compile_wide_descriptors": (C.c_int, [C.POINTER(CompileSet), C.POINTER(CompileOut), C.c_int32, _vp, _vp, _vp]),
     "gj_compile_ell_degrees": (C.c_int, [C.POINTER(CompileSet), _vp, _vp, _vp]),
-    "gj_compile_ell": (C.c_int, [C.POINTER(CompileSet), C.c_int32, C.c_int64, _vp, _vp, _vp, C.c_int64, _vp]),
+    "gj_compile_ell": (C.c_int, [C.POINTER(CompileSet), C.c_int32, C.c_int64, _vp, _vp, _vp, C.c_int64, _vp, _vp]),
 })
 
 _lib: Optional[C.CDLL] = None

@@ -100,6 +100,7 @@ class SingleGpuHotPath:
         from .engine import StepClock
 
         self.clock = StepClock(self.device)
+        self._delta_now = float(delta_now)
         p = self._graph_params = self.params()
         p.clock = self.clock.ptr
         self.clock.set(p.now - delta_now, self.t - 1)              # the first replay advances to (now, t)
@@ -117,7 +118,7 @@ class SingleGpuHotPath:
             self.t += 1
             return
         if getattr(self, "graph", None) is not None:      # an eager step of a captured runner: keep the device clock in step
-            self.clock.advance(1.0)
+            self.clock.advance(self._delta_now)
         p = self.params()
         e = self.engine
         if not timed:
@@ -153,13 +154,12 @@ class SingleGpuHotPath:
         st = self.state
         p = self._sym_p
         p.time, p.seed, p.step, p.agent_offset = float(self.t), self.seed, self.t, 0
-        N.check(lib.gj_symptoms_update(self.new_infected.numel(), N.ptr(self.engine.plan.agent_class),
-                                       N.ptr(self.new_infected), N.ptr(st["current_stage"]), N.ptr(st["next_stage"]),
-                                       N.ptr(st["time_to_next_stage"]), C.byref(p), None, None, N.current_stream()),
-                "gj_symptoms_update")
-        N.check(lib.gj_step_stats(self.new_infected.numel(), N.ptr(self.engine.plan.agent_class), N.ptr(st["is_infected"]),
-                                  N.ptr(st["current_stage"]), 3, self._edges, 7, N.ptr(self._series[self._row % 4096]),
-                                  N.current_stream()), "gj_step_stats")
+        N.check(lib.gj_symptoms_step_stats(self.new_infected.numel(), N.ptr(self.engine.plan.agent_class),
+                                           N.ptr(self.new_infected), N.ptr(st["current_stage"]), N.ptr(st["next_stage"]),
+                                           N.ptr(st["time_to_next_stage"]), C.byref(p), None, None,
+                                           N.ptr(st["is_infected"]), 3, self._edges, 7,
+                                           N.ptr(self._series[self._row % 4096]), N.current_stream()),
+                "gj_symptoms_step_stats")
         self._row += 1
 
     def reset_timers(self):

@@ -541,7 +541,7 @@ class DistributedHotPath:
             self.t += 1
             return
         if self.graph is not None:           # an eager (event-bracketed) step of a captured runner: keep the device clock in step
-            self.clock.advance(1.0)
+            self.clock.advance(self._delta_now)
         self.run_step(self.bufs, self.io, self.params, timed=timed)
         self.t += 1
 
@@ -553,6 +553,7 @@ class DistributedHotPath:
         from .engine import StepClock
 
         self.clock = StepClock(self.device)
+        self._delta_now = float(delta_now)
         self._params_cache.clear()
         self._clock_ptr = self.clock.ptr
         p_all = self.params(None)
@@ -565,6 +566,12 @@ class DistributedHotPath:
             self.run_step(self.bufs, self.io, self.params, timed=False)
         self.graph = graph
         return graph
+
+    def drop_graph(self) -> None:
+        """Back to the eager production step (launch scalars from the arguments again)."""
+        self.graph = None
+        self._clock_ptr = None
+        self._params_cache.clear()
 
     def run_step(self, bufs, io, params_of, timed: bool = False):
         """The multi-rank launch sequence for one step.  ``params_of(None)`` gives the launch parameters of every

@@ -50,7 +50,8 @@ class StepClock:
 
     def __init__(self, device):
         self.lib = N.load()
-        self.buf = torch.zeros(2, dtype=torch.int64, device=device)      # {float now; float pad; uint64 step}
+        # {float now; float pad; uint64 step; double now0; uint64 step0}
+        self.buf = torch.zeros(4, dtype=torch.int64, device=device)
 
     @property
     def ptr(self) -> int:
@@ -59,9 +60,11 @@ class StepClock:
     def set(self, now: float, step: int) -> None:
         import numpy as np
 
-        host = np.zeros(2, dtype=np.int64)
+        host = np.zeros(4, dtype=np.int64)
         host.view(np.float32)[0] = now
         host[1] = step
+        host.view(np.float64)[2] = now          # the origin later advances are measured from
+        host[3] = step
         self.buf.copy_(torch.from_numpy(host))
 
     def read(self):
@@ -69,6 +72,7 @@ class StepClock:
         return float(host.view("float32")[0]), int(host[1])
 
     def advance(self, delta_now: float) -> None:
+        """step += 1; now = float32(now0 + (step - step0) * delta_now), evaluated in double on the device."""
         N.check(self.lib.gj_clock_advance(self.ptr, float(delta_now), N.current_stream()), "gj_clock_advance")
 
 

@@ -31,6 +31,7 @@ class GradJune(torch.nn.Module):
         self.device = device
         self.rng_seed = None        # Philox key; defaults to torch.initial_seed() at first use
         self.n_steps = 0            # Philox stream id: one stream per forward() call
+        self.step_stats = None      # see forward()
 
     @classmethod
     def from_file(cls, fpath=None):
@@ -116,5 +117,8 @@ class GradJune(torch.nn.Module):
         new_infected, _ = self.hot_path(data, timer, exp_noise=exp_noise)
         # in grad mode new_infected stays on the graph: the symptoms update is then an autograd node too
         # (autograd.SymptomsStep), which is what makes the deaths series differentiable (runner.py:198-215)
-        self.symptoms_updater(data=data, timer=timer, new_infected=new_infected)
+        # step_stats: set by the Runner for the duration of its time loop - the per-step result reductions
+        # (runner.py:167-171) then ride on the symptoms pass instead of re-reading the arrays it just wrote
+        self.symptoms_updater(data=data, timer=timer, new_infected=new_infected,
+                              stats=getattr(self, "step_stats", None))
         return data

@@ -143,27 +143,32 @@ class Runner(torch.nn.Module):
         self.model.symptoms_updater(data=self.data, timer=self.timer, new_infected=new_infected)
 
     # per-step result reductions: one fused pass (gj_step_stats) into a preallocated series ------------
-    def _record(self, data, row):
+    def _stats_args(self, data):
+        """(agent classes, age-bin edges as a C array, dead stage) of gj_step_stats / gj_symptoms_step_stats."""
         import ctypes as C
 
+        ag = data["agent"]
+        if getattr(self, "_cls", None) is None:
+            dev = require_hip(self.device)
+            sex = ag["sex"] if "sex" in ag else torch.zeros_like(ag.age)
+            self._cls = (sex.long() * 100 + ag.age.long()).to(device=dev, dtype=torch.uint8).contiguous()
+            self._edges = (C.c_int32 * (len(self.age_bins)))(*[int(b) for b in self.age_bins.cpu()])
+        return self._cls, self._edges, int(self.model.symptoms_updater.stages_ids[-1])
+
+    def _record(self, data, row):
         from . import _native as N
 
         ag = data["agent"]
         n = self.n_agents
-        dev = require_hip(self.device)
-        if getattr(self, "_cls", None) is None:
-            sex = ag["sex"] if "sex" in ag else torch.zeros_like(ag.age)
-            self._cls = (sex.long() * 100 + ag.age.long()).to(device=dev, dtype=torch.uint8).contiguous()
-            self._edges = (C.c_int32 * (len(self.age_bins)))(*[int(b) for b in self.age_bins.cpu()])
+        cls, edges, dead = self._stats_args(data)
         stage = ag.symptoms["current_stage"]
         if stage.dtype != torch.float32:
             stage = stage.to(torch.float32)
         inf = ag.is_infected
         if inf.dtype != torch.float32 or not inf.is_contiguous():
             inf = inf.to(torch.float32).contiguous()
-        dead = int(self.model.symptoms_updater.stages_ids[-1])
-        N.check(N.load().gj_step_stats(n, N.ptr(self._cls), N.ptr(inf), N.ptr(stage.contiguous()),
-                                       len(self.age_bins) - 1, self._edges, dead, N.ptr(self._series[row]),
+        N.check(N.load().gj_step_stats(n, N.ptr(cls), N.ptr(inf), N.ptr(stage.contiguous()),
+                                       len(self.age_bins) - 1, edges, dead, N.ptr(self._series[row]),
                                        N.current_stream()), "gj_step_stats")
 
     # time loop --------------------------------------------------------------------------------------
@@ -189,8 +194,9 @@ class Runner(torch.nn.Module):
             for n in model.infection_networks.networks.values())
         diff_rows = []
 
-        def record(row):
-            self._record(data, row)
+        def record(row, done=False):
+            if not done:
+                self._record(data, row)
             if differentiable:
                 ag = data["agent"]
                 stage = ag.symptoms["current_stage"]
@@ -204,9 +210,17 @@ class Runner(torch.nn.Module):
         row = 0
         while timer.date < timer.final_date:
             next(timer)
-            data = model(data, timer)
             row += 1
-            record(row)
+            sink = None
+            if not differentiable:      # rows f1 + f2 in one pass: the model's symptoms update fills this step's row
+                cls, edges, dead = self._stats_args(data)
+                sink = {"cls": cls, "edges": edges, "n_bins": n_bins, "dead": dead, "out": self._series[row]}
+            model.step_stats = sink
+            try:
+                data = model(data, timer)
+            finally:
+                model.step_stats = None
+            record(row, done=bool(sink and sink.get("done")))
             dates.append(timer.date)
         self._finalize_series(row + 1)
         series = self._series[: row + 1].to(torch.float32)

@@ -117,8 +117,11 @@ class SymptomsUpdater(torch.nn.Module):
     def stages_ids(self):
         return self.symptoms_sampler.stages_ids
 
-    def forward(self, data, timer, new_infected, progresses=None, dwell=None):
-        """HIP path (fused kernel).  ``progresses`` / ``dwell``: optional injected randomness [A]."""
+    def forward(self, data, timer, new_infected, progresses=None, dwell=None, stats=None):
+        """HIP path (fused kernel).  ``progresses`` / ``dwell``: optional injected randomness [A].
+        ``stats``: {"cls", "edges", "n_bins", "dead", "out"} - the Runner's per-step reductions (runner.py:167-171) of
+        the UPDATED state are taken in the same pass (``gj_symptoms_step_stats``) into the zeroed fp64 row ``out``;
+        ``stats["done"]`` is set when that happened (not in grad mode, where the update is an autograd node)."""
         from .world import require_hip
 
         ag = data["agent"]
@@ -170,6 +173,18 @@ class SymptomsUpdater(torch.nn.Module):
             self.used_kernel = True
             return symptoms
         nw = new_infected.detach().to(torch.float32).contiguous()
+        if stats is not None:
+            inf = ag.is_infected
+            if inf.dtype != torch.float32 or not inf.is_contiguous() or inf.device != device:
+                inf = inf.detach().to(device=device, dtype=torch.float32).contiguous()
+            N.check(N.load().gj_symptoms_step_stats(
+                n, N.ptr(cls), N.ptr(nw), N.ptr(symptoms["current_stage"]), N.ptr(symptoms["next_stage"]),
+                N.ptr(symptoms["time_to_next_stage"]), C.byref(p), N.ptr(progresses), N.ptr(dwell), N.ptr(inf),
+                int(stats["n_bins"]), stats["edges"], int(stats["dead"]), N.ptr(stats["out"]), N.current_stream()),
+                "gj_symptoms_step_stats")
+            stats["done"] = True
+            self.used_kernel = True
+            return symptoms
         N.check(N.load().gj_symptoms_update(n, N.ptr(cls), N.ptr(nw), N.ptr(symptoms["current_stage"]),
                                             N.ptr(symptoms["next_stage"]), N.ptr(symptoms["time_to_next_stage"]),
                                             C.byref(p), N.ptr(progresses), N.ptr(dwell), N.current_stream()),

@@ -154,8 +154,8 @@ def build_tiled(name: str, agent_index, venue_index, n_venues: int, v_pcontact: 
     agent = np.asarray(agent_index, dtype=np.int64).ravel()
     venue = np.asarray(venue_index, dtype=np.int64).ravel()
     E = len(agent)
-    if slice_agents > 65536 or sv_max > 65536:
-        raise ValueError("local indices are 16-bit")
+    if slice_agents > 65536 or sv_max > 65535:
+        raise ValueError("local indices are 16-bit (and local venue 0xFFFF marks a pad slot)")
     degree = np.bincount(venue, minlength=n_venues) if E else np.zeros(n_venues, dtype=np.int64)
     blk_v0 = venue_blocks(degree, sv_max, eb_target)
     J = len(blk_v0) - 1

@@ -23,7 +23,8 @@ from . import _native as N
 from . import tiling as TL
 
 _ERRORS = {1: "agent index out of range", 2: "venue index out of range", 3: "more venue blocks than expected",
-           4: "too many venue blocks for the wide descriptor's j0 field"}
+           4: "too many venue blocks for the wide descriptor's j0 field",
+           5: "an owned agent has more edges than the ELL table has columns"}
 
 
 def _i64(t: torch.Tensor, device) -> torch.Tensor:
@@ -71,7 +72,7 @@ class _Session:
 def build_tiled_native(name: str, agent_index, venue_index, n_venues: int, v_pcontact, n_slices: int, slice_agents: int,
                        agent_class=None, sv_max: int = TL.SV_MAX, eb_target: int = TL.EB_TARGET,
                        wide: Optional[bool] = None, device=None, n_ext_agents: Optional[int] = None) -> TL.TiledEdgeSet:
-    if slice_agents > 65536 or sv_max > 65536:
+    if slice_agents > 65536 or sv_max > 65535:
         raise ValueError("local indices are 16-bit")
     dev = torch.device(device if device is not None else agent_index.device)
     v_pc = (torch.as_tensor(np.asarray(v_pcontact, dtype=np.float32)) if not isinstance(v_pcontact, torch.Tensor)
@@ -163,7 +164,8 @@ class EllBuilder:
         with torch.cuda.device(se.dev):
             ws = se.workspace()
             N.check(se.lib.gj_compile_ell(C.byref(se.set), K, self.rows, N.ptr(self.degree), N.ptr(ell), N.ptr(ws),
-                                          ws.numel(), N.current_stream()), "gj_compile_ell")
-            torch.cuda.current_stream().synchronize()
+                                          ws.numel(), N.ptr(se.counts), N.current_stream()), "gj_compile_ell")
+            if int(se.counts[N.GJ_CC_ERROR].item()):          # (synchronises)
+                raise ValueError(f"ELL table of {K} columns does not hold every owned agent's edges")
         se.ws = None
         return ell, K

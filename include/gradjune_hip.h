@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GJ_ABI_VERSION 3
+#define GJ_ABI_VERSION 4
 
 #define GJ_MAX_SETS 12        /* distinct agent<->venue edge sets in a world (reference: 6)   */
 #define GJ_MAX_NETS 16        /* infection networks active in one step (reference: <= 11)      */
@@ -197,9 +197,12 @@ typedef struct gj_network {
  * hipGraph (kernels + the multi-GPU collectives) can be replayed for every following timestep of the same kind
  * (same networks, betas, duration) - gj_clock_advance is the graph's first node.                              */
 typedef struct gj_clock {
-  float now;      /* timer.now, days                                   */
+  float now;      /* timer.now, days: what the kernels read                                        */
   float _pad;
-  uint64_t step;  /* Philox stream id: timestep counter                */
+  uint64_t step;  /* Philox stream id: timestep counter                                            */
+  double now0;    /* (now0, step0): the origin the host set; gj_clock_advance derives               */
+  uint64_t step0; /* now = (float)(now0 + (step - step0) * delta) - no accumulated rounding, the    */
+                  /* same value an eager run computes on the host for that step (timer.py:92-95)    */
 } gj_clock;
 
 /* Scalars of one timestep.  `nets` MUST be in the reference's accumulation order
@@ -332,6 +335,18 @@ int gj_step_stats(int64_t n, const uint8_t* agent_class, const float* is_infecte
                   const float* current_stage, int32_t n_bins, const int32_t* bin_edges /* host [n_bins+1] */,
                   int32_t dead_stage, double* out, void* stream);
 
+/* ---- rows f1 + f2 in ONE pass: gj_symptoms_update followed by gj_step_stats of the updated state -----------------
+ * What the reference's time loop does after the hot path of every step (grad_june/model.py:141 then
+ * runner.py:167-171): the stage progression, then the result reductions over the post-update is_infected /
+ * current_stage.  One kernel, four agents per lane: the three symptom arrays are read once and written back only
+ * where an agent's values changed, the reductions are taken from the registers that hold the updated stages.
+ * Arguments as for the two calls it replaces; `out` (device double [2 + n_bins]) must be ZEROED by the caller.      */
+int gj_symptoms_step_stats(int64_t n, const uint8_t* agent_class, const float* new_infected,
+                           float* current_stage, float* next_stage, float* time_to_next_stage,
+                           const gj_symptoms_params* params, const float* progresses, const float* dwell,
+                           const float* is_infected, int32_t n_bins, const int32_t* bin_edges /* host [n_bins+1] */,
+                           int32_t dead_stage, double* out, void* stream);
+
 /* ---- row f3: adjoint (backward) of one hot-path step, forward-only kernels reused ---------------
  * The aggregation ts = susc * sum_n w_n * (M_n^T diag(beta_n p_contact) M_n)(m_n * transmission) is
  * self-adjoint up to the exchange of the masks m_n <-> w_n, so its backward is the same four tiled
@@ -385,8 +400,10 @@ int gj_step(const gj_plan* plan, const gj_agent_state* state, const gj_step_para
 int gj_step_phase(const gj_plan* plan, const gj_agent_state* state, const gj_step_params* params,
                   const gj_step_io* io, int phase, void* stream);
 
-/* clock->now += delta_now; clock->step += 1 - one tiny launch on `stream` (the first node of a captured step).   */
-int gj_clock_advance(gj_clock* clock, float delta_now, void* stream);
+/* clock->step += 1; clock->now = (float)(now0 + (step - step0) * delta_now), in double: a step length that is not a
+ * power of two (hours / 24) does not drift over the replays.  One tiny launch on `stream` (the first node of a
+ * captured step).                                                                                                 */
+int gj_clock_advance(gj_clock* clock, double delta_now, void* stream);
 
 /* Multi-GPU halo exchange helpers (one process per GPU; the all-to-all itself is issued by
  * the host through torch.distributed/RCCL between the two calls).
@@ -408,7 +425,8 @@ int gj_unpack_f32(int64_t n, const int32_t* index, const float* in, float* dst, 
  *   3. gj_compile_wide_descriptors   (optional) the 8-word descriptor format for sets with small tiles
  *   4. gj_compile_ell_degrees / gj_compile_ell    the ELL rows of the direct form of pass 2
  * counts[GJ_CC_ERROR] != 0 after a stage: 1 agent index out of range, 2 venue index out of range, 3 more venue
- * blocks than blk_cap, 4 wide descriptor field overflow.                                                           */
+ * blocks than blk_cap, 4 wide descriptor field overflow, 5 an owned agent has more edges than ell_k columns (the
+ * entry is skipped, nothing is written outside the table).                                                        */
 #define GJ_COMPILE_COUNTS 8
 #define GJ_CC_BLOCKS 0       /* J: venue blocks                                                        */
 #define GJ_CC_SLOTS 1        /* length of the block-major arrays (every block padded to 8 slots)       */
@@ -456,9 +474,10 @@ int gj_compile_wide_descriptors(const gj_compile_set* set, const gj_compile_out*
 /* degree[a] (int32 [n_agents + 1], caller-owned) = edges of owned agent a; counts[OWNED_EDGES], counts[MAX_DEGREE]. */
 int gj_compile_ell_degrees(const gj_compile_set* set, int32_t* degree, int32_t* counts, void* stream);
 /* ell: uint16 [ell_k / 2 planes][rows][2] (gj_tiled_set.ell), rows = owned slices * slice_agents; `degree` as
- * returned by gj_compile_ell_degrees.                                                                              */
+ * returned by gj_compile_ell_degrees; ell_k >= counts[GJ_CC_MAX_DEGREE] (checked per entry: counts[GJ_CC_ERROR] = 5
+ * when an agent does not fit; `counts` may be NULL).                                                               */
 int gj_compile_ell(const gj_compile_set* set, int32_t ell_k, int64_t rows, const int32_t* degree, uint16_t* ell,
-                   void* workspace, int64_t workspace_bytes, void* stream);
+                   void* workspace, int64_t workspace_bytes, int32_t* counts, void* stream);
 
 /* Average device time of the last-timed dominant kernel is measured by the caller with
  * hipEvents; these two helpers let a ctypes caller do that on the stream it launches on

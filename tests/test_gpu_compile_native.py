@@ -40,7 +40,7 @@ def assert_same_tiled(got, ref, what=""):
 
 CASES = [  # A, V, E, sa, svmax, eb, wide, dup
     (5000, 700, 20000, 512, 128, 3000, None, 0),
-    (300, 5, 4000, 64, 65536, 1 << 30, None, 50),
+    (300, 5, 4000, 64, 65535, 1 << 30, None, 50),
     (2000, 3000, 6000, 64, 16, 16, True, 0),
     (3000, 600, 30000, 128, 32, 600, None, 300),
     (64, 1, 10, 64, 16, 16, False, 0),

@@ -14,7 +14,7 @@ def random_set(rng, A, V, E, big=None):
     return agent, venue
 
 
-@pytest.mark.parametrize("A,V,E,sa,svmax,eb", [(5000, 700, 20000, 512, 128, 3000), (300, 5, 4000, 64, 65536, 1 << 30),
+@pytest.mark.parametrize("A,V,E,sa,svmax,eb", [(5000, 700, 20000, 512, 128, 3000), (300, 5, 4000, 64, 65535, 1 << 30),
                                                (10000, 9000, 15000, 1024, 4096, 2000), (64, 1, 10, 64, 16, 16),
                                                (2000, 3000, 6000, 64, 16, 16), (3000, 600, 30000, 128, 32, 600)])
 @pytest.mark.parametrize("wide", [False, True], ids=["narrow-desc", "wide-desc"])
@@ -170,3 +170,13 @@ def test_compile_plan_chooses_the_direct_form():
         back = load_plan(os.path.join(d, "p.npz"))
     for a, b in zip(host.sets, back.sets):
         assert a.tiled.ell_k == b.tiled.ell_k and np.array_equal(a.tiled.ell, b.tiled.ell)
+
+
+def test_local_venue_index_never_collides_with_the_pad_marker():
+    """e_lv is 16-bit and 0xFFFF marks a pad slot: a block of 65536 venues would give its last venue that index and
+    silently drop its edges - refused at compile time (tiling.py and the C ABI's gj_compile_* alike)."""
+    with pytest.raises(ValueError, match="16-bit"):
+        build_tiled("x", np.zeros(4, np.int64), np.arange(4), 70000, np.ones(70000, np.float32), 1, 64, sv_max=65536)
+    t = build_tiled("x", np.arange(64) % 8, np.arange(64) * 1000, 70000, np.ones(70000, np.float32), 1, 64,
+                       sv_max=65535, eb_target=1 << 30)
+    assert int(np.diff(t.blk_v0).max()) <= 65535 and int(t.e_lv[t.e_lv != 0xFFFF].max()) <= 65534
