@@ -607,6 +607,7 @@ def main():
         return time.perf_counter() - t_a, t_issue
 
     elapsed, issue = region()
+    infected_first = float(runner.state["is_infected"].double().sum())    # after warm-up + the first K steps
     repeats = [elapsed]
     for _ in range(max(0, args.repeats - 1)):         # the same region again, back to back: run-to-run spread
         repeats.append(region()[0])
@@ -630,9 +631,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, peak_rss_mb, issue = float(t[0].item()), float(t[1].item()), float(t[2].item())
         repeats = [float(x) for x in t[3:].tolist()]
-        t = torch.tensor([infected_local], dtype=torch.float64, device=red_dev)
+        t = torch.tensor([infected_local, infected_first], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        infected_local = float(t.item())
+        infected_local, infected_first = float(t[0].item()), float(t[1].item())
 
     if rank != 0:
         dist.destroy_process_group()
@@ -706,7 +707,9 @@ def main():
                 "includes": "hot path a1-a9 + symptoms and per-step result reductions in one kernel (f1 + f2)"}
 
     # what the timed steps computed: variants of one kernel must agree on these (tools/ab.py prints them)
-    checksum = {"infected": infected_local}      # summed over the ranks
+    # summed over the ranks; "after_first_region" = after warm-up + K steps: what tests/test_gpu_fullsize_properties.py
+    # ::test_the_arrangement_bench_times pins for the driver's --warmup 5 --steps 20
+    checksum = {"infected": infected_local, "infected_after_first_region": infected_first}
     if getattr(runner, "stamps", None) is not None:      # GJ_DIAG_STAMPS builds: cycles since workgroup start at marked points
         sa = runner.engine.plan.host.slice_agents
         st = runner.stamps[: (world["n_agents"] // sa) * sa].view(-1, sa)[:, :16].cpu().numpy()

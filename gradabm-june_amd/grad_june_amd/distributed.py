@@ -113,8 +113,24 @@ class RankPartitioner:
     wants every rank's part (``PartitionedHotPath``) sorts each set once instead of scanning it once per rank."""
 
     def __init__(self, n_agents: int, world_size: int, ranks: Optional[Sequence[int]] = None,
-                 modes: Optional[Dict[str, str]] = None):
+                 modes: Optional[Dict[str, str]] = None, networks: Optional[Sequence[str]] = None,
+                 n_sets: Optional[int] = None, log=None):
+        """``networks``: the infection networks that will run on the world (names; their edge sets by
+        ``synthetic.edge_set_of``) and ``n_sets``: how many edge sets will be added - what the split mode needs to
+        stay inside the library's limits (a split set becomes two sets and every network on it gets a twin)."""
+        from . import _native as N_
+        from .synthetic import edge_set_of
+
         self.n_agents, self.world_size = int(n_agents), int(world_size)
+        self._limits = (N_.GJ_MAX_SETS, N_.GJ_MAX_NETS, N_.GJ_MAX_NETS_PER_SET)
+        self._nets_on: Dict[str, int] = {}
+        for n in (networks or ()):
+            self._nets_on[edge_set_of(n)] = self._nets_on.get(edge_set_of(n), 0) + 1
+        self._n_nets = sum(self._nets_on.values())            # grows by a set's networks with every split
+        self._n_sets_expected = n_sets
+        self._n_sets_added = 0                                 # parts, i.e. a split set counts twice
+        self._n_sets_seen = 0
+        self._log = log
         self.ranks = list(range(world_size)) if ranks is None else [int(r) for r in ranks]
         self.bounds = partition_bounds(self.n_agents, self.world_size)
         self.mode_override = dict(modes or {})
@@ -132,6 +148,10 @@ class RankPartitioner:
         mode = self.mode_override.get(name) or mode_of(len(agent), len(people), self.world_size, people)
         self.total_edges += len(agent)
         self.sizes[name] = (len(agent), len(people))
+        self._n_sets_seen += 1
+        if mode == "split":
+            mode = self._split_or_fallback(name, len(people))
+        self._n_sets_added += 2 if mode == "split" else 1
         if mode == "split":
             # two edge sets with venue numberings of their own: the small venues exchange halo transmissions, the
             # large ones partial sums; every network on the set gets a twin on the second (expand_split_networks)
@@ -142,6 +162,25 @@ class RankPartitioner:
                 self._add_part(part, agent[sel_e], remap[venue[sel_e]], people[sel_v], m)
             return mode
         self._add_part(name, agent, venue, people, mode)
+        return mode
+
+    def _split_or_fallback(self, name: str, n_venues: int) -> str:
+        """A split set becomes two edge sets and every network on it gets a twin: only while GJ_MAX_SETS,
+        GJ_MAX_NETS and GJ_MAX_NETS_PER_SET hold (six sets split = 12 = GJ_MAX_SETS; the reference's eleven networks
+        split everywhere = 22 > 16).  Otherwise the set runs unsplit: partial sums when its cum buffer is no larger
+        than one float per agent of the world, else halo - a function of global sizes, so every rank agrees."""
+        max_sets, max_nets, max_per_set = self._limits
+        k = self._nets_on.get(name, 1)
+        still_to_come = (self._n_sets_expected - self._n_sets_seen) if self._n_sets_expected is not None else 0
+        fits = (self._n_sets_added + 2 + max(0, still_to_come) <= max_sets and self._n_nets + k <= max_nets
+                and k <= max_per_set)
+        if fits:
+            self._n_nets += k
+            return "split"
+        mode = "partial" if n_venues * max(1, k) <= self.n_agents else "halo"
+        if self._log:
+            self._log(f"edge set {name}: not split (the library holds {max_sets} edge sets / {max_nets} networks; "
+                      f"{self._n_sets_added} sets and {self._n_nets} networks so far) - runs in {mode} mode")
         return mode
 
     def _add_part(self, name: str, agent: np.ndarray, venue: np.ndarray, people: np.ndarray, mode: str) -> None:
@@ -216,7 +255,8 @@ def build_rank_worlds(world: dict, world_size: int, ranks: Optional[Sequence[int
                       modes: Optional[Dict[str, str]] = None, slice_agents: Optional[int] = None,
                       progress=None) -> Dict[int, RankWorld]:
     """The parts of ``ranks`` (default: all) of a world held in memory."""
-    part = RankPartitioner(world["n_agents"], world_size, ranks, modes)
+    part = RankPartitioner(world["n_agents"], world_size, ranks, modes, networks=world.get("networks"),
+                           n_sets=len(world["edge_sets"]), log=progress)
     for name, es in world["edge_sets"].items():
         mode = part.add_set(name, es["agent"], es["venue"], es["people"])
         if progress:
@@ -243,7 +283,8 @@ def stream_rank_share(pieces, rank: int, world_size: int, reorder: Optional[str]
     for piece in pieces:
         if piece[0] == "header":
             header = piece[1]
-            part = RankPartitioner(header["n_agents"], world_size, [rank], modes)
+            part = RankPartitioner(header["n_agents"], world_size, [rank], modes, networks=header.get("networks"),
+                                   n_sets=header.get("n_sets"), log=progress)
         elif piece[0] == "set":
             _, name, es = piece
             agent = es["agent"]

@@ -116,7 +116,8 @@ def iter_world(preset: str = "c3", n_agents: Optional[int] = None, seed: int = 1
     rng = np.random.default_rng(seed)
     A = int(n_agents)
     yield ("header", {"preset": preset, "n_agents": A, "age": rng.integers(0, 100, A, dtype=np.int64),
-                      "sex": rng.integers(0, 2, A, dtype=np.int64), "networks": list(NETWORKS[preset])})
+                      "sex": rng.integers(0, 2, A, dtype=np.int64), "networks": list(NETWORKS[preset]),
+                      "n_sets": len([s for s in spec if sets is None or s in sets])})
     for name, (per_agent, dist) in spec.items():
         if sets is not None and name not in sets:
             continue

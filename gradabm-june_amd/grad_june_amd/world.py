@@ -32,7 +32,10 @@ DEVICE_COMPILE = os.environ.get("GRAD_JUNE_AMD_DEVICE_COMPILE", "auto")
 #: candidate) and the world has 2e5 .. 4e7 set-edges, compile it under a few candidate geometries, time the two
 #: sparse passes on dummy data and keep the fastest - the size-based defaults of tiling.py are right for ~1.5
 #: memberships per agent and set, denser worlds (BASELINE's C2: 5) want larger tiles (0.156 -> 0.110 ms per step);
-#: "0" = always the defaults.  The geometry never changes a result: the passes sum in fixed point / in ELL order.
+#: "0" = always the defaults.  The geometry cannot change a bit of a result: every edge's term goes to fixed point
+#: BEFORE anything is added to it (phase B merges a venue's runs as integers - round 2 merged them in fp32, where the
+#: geometry reached the last bits - phase D adds fixed-point terms, the direct form sums in COO order), so the race
+#: between candidates decides the speed only (tests/test_gpu_api.py::test_tile_geometry_cannot_change_a_bit).
 TUNE = os.environ.get("GRAD_JUNE_AMD_TUNE", "auto")
 TUNE_CANDIDATES = ({}, {"eb_target": 131072, "sv_max": 16384}, {"eb_target": 65536, "sv_max": 16384})
 TUNE_MIN_EDGES, TUNE_MAX_EDGES = 200_000, 40_000_000

@@ -288,3 +288,41 @@ def test_twin_networks_of_split_sets():
     s3, n3, b3 = expand_split_networks(specs, names, betas, {"school": 0, "leisure": 0, "household": 0})
     assert n3 == names and len(s3) == len(specs) and b3 == betas
     assert with_twins(["a", "b"], {"a": "x", "b": "y"}.get, lambda n: None) == ["a", "b"]
+
+
+def test_split_mode_stays_inside_the_library_limits():
+    """A split set becomes two edge sets and every network on it a pair: six heavy-tailed sets carrying the reference's
+    eleven networks would need 12 sets / 22 networks (GJ_MAX_SETS 12, GJ_MAX_NETS 16).  The partitioner splits while the
+    limits hold and runs the remaining sets unsplit (partial sums or halo, from global sizes) - and says so - instead of
+    failing later in compile_plan."""
+    from grad_june_amd import _native as N
+    from grad_june_amd.distributed import RankPartitioner, expand_split_networks
+    from grad_june_amd.plan import NetworkSpec
+    from grad_june_amd.synthetic import edge_set_of
+
+    world = make_world("c5", n_agents=30_000, seed=3)
+    networks = ["school", "university", "company", "care_home", "pub", "gym", "grocery", "visit", "care_visit", "cinema",
+                "household"]
+    said = []
+    want = {s: "split" for s in world["edge_sets"]}      # (at 10^8 agents mode_of asks for this by itself)
+    part = RankPartitioner(world["n_agents"], 4, [1], modes=want, networks=networks, n_sets=len(world["edge_sets"]),
+                           log=said.append)
+    for name, es in world["edge_sets"].items():
+        part.add_set(name, es["agent"], es["venue"], es["people"])
+    modes = dict(part.modes)
+    rw = part.finish(world["age"], world["sex"])[1]
+    split = [s for s in modes if s.endswith("~big")]
+    assert len(split) == 5 and "leisure~big" not in modes and modes["leisure"] in ("partial", "halo")
+    assert len(said) == 1 and "leisure" in said[0] and "not split" in said[0]
+    specs = [NetworkSpec(n, edge_set_of(n), N.MASK_RAW if n == "household" else N.MASK_Q, None) for n in networks]
+    out_specs, names, _ = expand_split_networks(specs, networks, {n: 1.0 for n in networks}, rw.edge_sets)
+    assert len(rw.edge_sets) <= N.GJ_MAX_SETS and len(names) <= N.GJ_MAX_NETS
+    per_set = {}
+    for sp in out_specs:
+        per_set[sp.edge_set] = per_set.get(sp.edge_set, 0) + 1
+    assert max(per_set.values()) <= N.GJ_MAX_NETS_PER_SET
+    # the benchmark's own configuration (8 networks) still splits every set, as before
+    part = RankPartitioner(world["n_agents"], 4, [0], modes=want, networks=world["networks"],
+                           n_sets=len(world["edge_sets"]))
+    for name, es in world["edge_sets"].items():
+        assert part.add_set(name, es["agent"], es["venue"], es["people"]) == "split"

@@ -548,3 +548,43 @@ def test_api_geometry_tuning_changes_speed_not_results(G, device):
     assert torch.equal(new0, new1) and float(new0.sum()) > 0
     assert ms1 <= ms0 * 1.10            # the tuner keeps the defaults unless another geometry measured faster
     print(f"defaults {ms0:.3f} ms {geo0}; tuned {ms1:.3f} ms {geo1}")
+
+
+def test_tile_geometry_cannot_change_a_bit(G, device):
+    """Every candidate geometry of the tuner (world.TUNE_CANDIDATES, bench's GEOMETRY_CANDIDATES without its
+    direct=False variant) gives bitwise the same per-venue sums, per-agent trans_susc and probabilities: phase B merges
+    the runs of a venue as fixed-point integers (round 2 merged them in fp32, where a run's position relative to the
+    8-slot groups - i.e. the geometry - reached the last bits), phase D adds fixed-point terms, the direct form sums in
+    COO order.  So a wall-clock race between geometries cannot make two runs of one script differ."""
+    import bench as B
+    from grad_june_amd import world as W
+    from grad_june_amd.benchrun import GEOMETRY_CANDIDATES, SingleGpuHotPath
+    from grad_june_amd.synthetic import make_world
+
+    world = make_world("c3", n_agents=300_000, seed=11, infected_fraction=0.2)
+    specs, betas = B.network_specs(world), B.betas_of(world)
+    cands = [dict(c) for c in W.TUNE_CANDIDATES] + [dict(c) for c in GEOMETRY_CANDIDATES if "direct" not in c]
+    cands.append({"eb_target": 4096, "sv_max": 64, "slice_agents": 1024})       # tiny tiles, runs cut everywhere
+    ref = None
+    seen = set()
+    for cand in cands:
+        cand = dict(cand)
+        sa = cand.pop("slice_agents", None)
+        if sa is not None:
+            cand["slices"] = (-(-world["n_agents"] // sa), sa)
+        r = SingleGpuHotPath(world, specs, betas, device, seed=3, device_compile=True, **cand)
+        ts = torch.empty(world["n_agents"], device=device)
+        r.io = r.engine.io(not_infected_probs=r.probs, new_infected=r.new_infected, trans_susc=ts)
+        r.step()
+        torch.cuda.synchronize()
+        got = {"ts": ts.clone(), "probs": r.probs.clone(), "new": r.new_infected.clone()}
+        for hs in r.engine.plan.host.sets:
+            got["cum/" + hs.name] = r.engine.plan.cum_of(hs.name).clone()
+        seen.add(tuple(hs.tiled.n_blocks for hs in r.engine.plan.host.sets) + (r.engine.plan.host.n_slices,))
+        if ref is None:
+            ref = got
+            assert float(ts.max()) > 0 and float(got["new"].sum()) > 100
+        else:
+            for k in ref:
+                assert torch.equal(got[k], ref[k]), (cand, k)
+    assert len(seen) >= 4          # the candidates really are different geometries

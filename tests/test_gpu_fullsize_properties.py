@@ -347,3 +347,63 @@ def test_device_compiled_plan_is_identical(device):
     for k in ("is_infected", "susceptibility", "infection_time"):
         assert torch.equal(r0.state[k], r1.state[k]), k
     assert torch.equal(r0.probs, r1.probs)
+
+
+def test_the_arrangement_bench_times(device):
+    """The EXACT world and arrangement of the driver's bench line: C3, seed 1234, 1 % infected, agents renumbered
+    household-major (bench.py's default `--reorder`), graph compiled on the device, Philox noise keyed by seed 1234.
+      (a) 25 steps (the driver's --warmup 5 --steps 20) end with is_infected.sum() == 2 958 814 - the checksum the
+          builder's profiled run and the driver's BENCH_r02 run both printed: the kernels that are timed compute THIS;
+      (b) the CSR layout stepped from the same states with the same Philox stream takes the same decisions except
+          where a probability sits within float rounding of its threshold;
+      (c) every venue sum and every agent's probability of that arrangement against fp64 sums taken on the device from
+          the renumbered COO lists (diagonal household tiles, wide descriptors and all)."""
+    from grad_june_amd.synthetic import reorder_agents
+
+    world = reorder_agents(make_world("c3", seed=1234, infected_fraction=0.01), by="household")
+    A = world["n_agents"]
+    specs, betas = B.network_specs(world), B.betas_of(world)
+    tiled = SingleGpuHotPath(world, specs, betas, device, seed=1234, layout="tiled", device_compile=True)
+    assert any(hs.tiled.desc_wide for hs in tiled.engine.plan.host.sets)      # the arrangement has small-tile sets
+    # (c) first: stateless stages on the initial state
+    run_stages(tiled)
+    cum64, ts64 = fp64_device_reference(world, tiled, betas, device)
+    per_set = {}
+    for name in world["networks"]:
+        k = per_set.get(edge_set_of(name), 0)
+        per_set[edge_set_of(name)] = k + 1
+        got = tiled.engine.plan.cum_of(edge_set_of(name))[:, k].double()
+        err = (got - cum64[name]).abs() / (cum64[name].abs() + 1e-9)
+        assert float(err.max()) <= 3e-5, (name, float(err.max()))
+    p64 = torch.exp(-torch.clamp(ts64, 1e-6, 100.0)).clamp(0.0, 1.0)
+    assert float((tiled.probs.double() - p64).abs().max()) <= 2e-6
+    del cum64, ts64, p64
+    # (b) + (a): 25 production steps; the CSR runner is teacher-forced with the tiled runner's state before each of the
+    # first steps (a flipped tie would otherwise send the two epidemics apart)
+    csr = SingleGpuHotPath(world, specs, betas, device, seed=1234, layout="csr")
+    keys = ("is_infected", "susceptibility", "infection_time", "current_stage")
+    flips = 0
+    for step in range(25):
+        if step < 4:
+            for k in keys:
+                csr.state[k].copy_(tiled.state[k])
+            csr.t = tiled.t
+            csr.step()
+        tiled.step()
+        if step < 4:
+            torch.cuda.synchronize()
+            differ = tiled.new_infected != csr.new_infected
+            n = int(differ.sum())
+            flips += n
+            assert n <= 8, (step, n)
+            assert float((tiled.probs - csr.probs).abs().max()) <= 2e-6
+            if n:        # only where the probability is within rounding of the agent's threshold
+                from gj_philox_ref import infection_uniform
+
+                idx = torch.nonzero(differ).flatten().cpu().numpy()
+                theta = infection_uniform(1234, step, idx.astype(np.int64))
+                assert np.abs(tiled.probs.cpu().numpy()[idx] - theta).max() <= 2e-6
+            assert abs(float(tiled.new_infected.sum()) - float(csr.new_infected.sum())) <= 8
+    torch.cuda.synchronize()
+    assert float(tiled.state["is_infected"].double().sum()) == 2958814.0
+    print(f"decisions that differ between the layouts over 4 teacher-forced steps: {flips}")
