@@ -265,6 +265,96 @@ __global__ void k_ell_fill(const uint32_t* keys, const uint32_t* order, int64_t 
   }
 }
 
+// ---- run form (tiling.split_primary_runs / finish_run_form) ---------------------------------------------------------
+constexpr int32_t kNoVenue = 0x7FFFFFFF;
+
+__global__ void k_run_vmin(const int64_t* agent, const int64_t* venue, int64_t E, int64_t n_agents, int32_t* vmin) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t a = agent[e];
+    if (a >= 0 && a < n_agents) atomicMin(&vmin[a], (int32_t)venue[e]);
+  }
+}
+// the primary edge of an agent: the FIRST edge in COO order to its smallest venue
+__global__ void k_run_pick(const int64_t* agent, const int64_t* venue, int64_t E, int64_t n_agents, const int32_t* vmin,
+                           int32_t* pick) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t a = agent[e];
+    if (a >= 0 && a < n_agents && (int32_t)venue[e] == vmin[a]) atomicMin(&pick[a], (int32_t)e);
+  }
+}
+__global__ void k_run_keep(const int64_t* agent, int64_t E, int64_t n_agents, const int32_t* pick, uint8_t* keep,
+                           int32_t* counts) {
+  __shared__ int32_t part[2];
+  if (threadIdx.x < 2) part[threadIdx.x] = 0;
+  __syncthreads();
+  int32_t primary = 0, owned = 0;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t a = agent[e];
+    const bool own = a >= 0 && a < n_agents;
+    const bool prim = own && pick[a] == (int32_t)e;
+    keep[e] = prim ? 0 : 1;
+    primary += prim ? 1 : 0;
+    owned += own ? 1 : 0;
+  }
+  if (primary) atomicAdd(&part[0], primary);
+  if (owned) atomicAdd(&part[1], owned);
+  __syncthreads();
+  if (threadIdx.x == 0 && part[0]) atomicAdd(&counts[GJ_CC_RUN_PRIMARY], part[0]);
+  if (threadIdx.x == 0 && part[1]) atomicAdd(&counts[GJ_CC_OWNED_EDGES], part[1]);
+}
+// vmin must be non-decreasing over the owned agents (agents without an edge - kNoVenue - last)
+__global__ void k_run_sorted(const int32_t* vmin, int64_t n_agents, int32_t* counts) {
+  for (int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; a + 1 < n_agents; a += (int64_t)gridDim.x * blockDim.x)
+    if (vmin[a] > vmin[a + 1]) counts[GJ_CC_RUN_UNSORTED] = 1;
+}
+// the window of venues of every owned slice: [vmin of its first agent, vmin of its last agent with an edge]
+__global__ void k_run_windows(const int32_t* vmin, int64_t n_agents, int32_t slice_agents, int32_t n_own_slices,
+                              int32_t* win_lo, int32_t* win_n, int32_t* counts) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_own_slices) return;
+  const int64_t a0 = (int64_t)s * slice_agents, a1 = min(n_agents, a0 + slice_agents);
+  int32_t lo = 0, n = 0;
+  if (a0 < a1 && vmin[a0] != kNoVenue) {
+    int64_t last = a1 - 1;
+    while (last > a0 && vmin[last] == kNoVenue) --last;      // only the world's last agents have no edge (sorted)
+    lo = vmin[a0];
+    n = vmin[last] - lo + 1;
+  }
+  win_lo[s] = lo;
+  win_n[s] = n;
+  if (n > 0) atomicMax(&counts[GJ_CC_RUN_WINDOW], n);
+}
+__global__ void k_run_index(const int32_t* vmin, int64_t n_agents, int64_t rows, int32_t slice_agents, const int32_t* blk_v0,
+                            int32_t J, const int32_t* win_lo, uint16_t* pv_blk, uint16_t* pv_win) {
+  for (int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; a < rows; a += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t v = a < n_agents ? vmin[a] : kNoVenue;
+    uint16_t b = 0xFFFF, w = 0xFFFF;
+    if (v != kNoVenue) {
+      const int j = upper_bound(blk_v0, J + 1, v) - 1;
+      b = (uint16_t)(v - blk_v0[j]);
+      w = (uint16_t)(v - win_lo[a / slice_agents]);
+    }
+    pv_blk[a] = b;
+    pv_win[a] = w;
+  }
+}
+// blk_r0[j] = first owned agent whose smallest venue is >= blk_v0[j] (numpy searchsorted side="left" on the sorted vmin)
+__global__ void k_run_blk_r0(const int32_t* vmin, int64_t n_agents, const int32_t* blk_v0, int32_t J, int32_t* blk_r0) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j > J) return;
+  const int32_t x = blk_v0[j];
+  int64_t lo = 0, hi = n_agents;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (vmin[mid] < x) {
+      lo = mid + 1;
+    } else {
+      hi = mid;
+    }
+  }
+  blk_r0[j] = (int32_t)lo;
+}
+
 // ---- workspace ----------------------------------------------------------------------------------------------
 struct Geometry {
   int64_t E, V, S, J, n_agents;
@@ -301,6 +391,13 @@ static size_t sort32_temp(int64_t E, int end_bit) {
 static size_t scan_temp(int64_t n) {
   size_t b = 0;
   (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b, (const int32_t*)nullptr, (int32_t*)nullptr, (int)n, (hipStream_t)0);
+  return b;
+}
+
+static size_t select_temp(int64_t E) {
+  size_t b = 0;
+  (void)hipcub::DeviceSelect::Flagged(nullptr, b, (const int64_t*)nullptr, (const uint8_t*)nullptr, (int64_t*)nullptr,
+                                      (int32_t*)nullptr, (int)E, (hipStream_t)0);
   return b;
 }
 
@@ -418,7 +515,8 @@ int gj_compile_workspace_bytes(const gj_compile_set* set, int64_t* bytes) {
   const gjc::Geometry g = gjc::geometry_of(set);
   if (g.tiles() >= ((int64_t)1 << 31) - 1) return GJ_E_RANGE;
   *bytes = std::max({gjc::carve_blocks(g, nullptr, nullptr), gjc::carve_tiles(g, nullptr, nullptr),
-                     gjc::carve_ell(g, nullptr, nullptr)});
+                     gjc::carve_ell(g, nullptr, nullptr),
+                     gjc::align_up((int64_t)gjc::select_temp(std::max<int64_t>(g.E, 1))) + 256});
   return 0;
 }
 
@@ -538,6 +636,62 @@ int gj_compile_ell(const gj_compile_set* set, int32_t ell_k, int64_t rows, const
   if (const int rc = gjc::exclusive_scan(w.temp, w.temp_bytes, degree, w.rowptr, g.n_agents + 1, st)) return rc;
   gjc::k_ell_fill<<<gjc::grid_for(g.E), gjc::kThreads, 0, st>>>(w.keys_b, w.vals_b, g.E, g.n_agents, w.rowptr, set->venue,
                                                                rows, ell_k, ell, counts);
+  return (int)hipGetLastError();
+}
+
+// ---- run form ---------------------------------------------------------------------------------------------------------
+int gj_compile_runs_pick(const gj_compile_set* set, int32_t* vmin, int32_t* pick, uint8_t* keep, int32_t* win_lo,
+                         int32_t* win_n, int32_t* counts, void* stream) {
+  if (const int rc = gjc::check_set(set)) return rc;
+  if (!vmin || !pick || !counts || !win_lo || !win_n || (set->n_edges > 0 && !keep)) return GJ_E_NULL;
+  if (set->n_venues >= gjc::kNoVenue) return GJ_E_RANGE;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t A = set->n_agents, E = set->n_edges;
+  const int32_t n_own_slices = (int32_t)std::max<int64_t>(1, (A + set->slice_agents - 1) / set->slice_agents);
+  GJC_HIP(hipMemsetAsync(counts, 0, GJ_COMPILE_COUNTS * sizeof(int32_t), st));
+  if (A > 0) {
+    GJC_HIP(hipMemsetD32Async((hipDeviceptr_t)vmin, gjc::kNoVenue, (size_t)A, st));
+    GJC_HIP(hipMemsetD32Async((hipDeviceptr_t)pick, gjc::kNoVenue, (size_t)A, st));
+  }
+  if (E > 0 && A > 0) {
+    gjc::k_run_vmin<<<gjc::grid_for(E), gjc::kThreads, 0, st>>>(set->agent, set->venue, E, A, vmin);
+    gjc::k_run_pick<<<gjc::grid_for(E), gjc::kThreads, 0, st>>>(set->agent, set->venue, E, A, vmin, pick);
+  }
+  if (E > 0) gjc::k_run_keep<<<gjc::grid_for(E), gjc::kThreads, 0, st>>>(set->agent, E, A, pick, keep, counts);
+  if (A > 1) gjc::k_run_sorted<<<gjc::grid_for(A), gjc::kThreads, 0, st>>>(vmin, A, counts);
+  gjc::k_run_windows<<<(n_own_slices + gjc::kThreads - 1) / gjc::kThreads, gjc::kThreads, 0, st>>>(
+      vmin, A, set->slice_agents, n_own_slices, win_lo, win_n, counts);
+  return (int)hipGetLastError();
+}
+
+int gj_compile_runs_rest(const gj_compile_set* set, const uint8_t* keep, int64_t* agent_out, int64_t* venue_out,
+                         void* workspace, int64_t workspace_bytes, int32_t* counts, void* stream) {
+  if (const int rc = gjc::check_set(set)) return rc;
+  if (!counts || !workspace) return GJ_E_NULL;
+  if (set->n_edges == 0) return 0;
+  if (!keep || !agent_out || !venue_out) return GJ_E_NULL;
+  hipStream_t st = (hipStream_t)stream;
+  size_t tb = gjc::select_temp(set->n_edges);
+  if ((int64_t)gjc::align_up((int64_t)tb) + 256 > workspace_bytes) return GJ_E_RANGE;
+  int32_t* n_out = reinterpret_cast<int32_t*>(workspace);            // the selection's own counter, then its scratch
+  void* temp = reinterpret_cast<char*>(workspace) + 256;
+  GJC_HIP(hipcub::DeviceSelect::Flagged(temp, tb, set->agent, keep, agent_out, n_out, (int)set->n_edges, st));
+  GJC_HIP(hipcub::DeviceSelect::Flagged(temp, tb, set->venue, keep, venue_out, n_out, (int)set->n_edges, st));
+  return (int)hipGetLastError();
+}
+
+int gj_compile_runs_index(const gj_compile_set* set, const int32_t* vmin, const int32_t* blk_v0, int32_t n_blocks,
+                          int64_t rows, const int32_t* win_lo, uint16_t* pv_blk, uint16_t* pv_win, int32_t* blk_r0,
+                          void* stream) {
+  if (const int rc = gjc::check_set(set)) return rc;
+  if (!vmin || !blk_v0 || !win_lo || !pv_blk || !pv_win || !blk_r0) return GJ_E_NULL;
+  if (n_blocks < 1 || rows < set->n_agents) return GJ_E_RANGE;
+  hipStream_t st = (hipStream_t)stream;
+  if (rows > 0)
+    gjc::k_run_index<<<gjc::grid_for(rows), gjc::kThreads, 0, st>>>(vmin, set->n_agents, rows, set->slice_agents, blk_v0,
+                                                                    n_blocks, win_lo, pv_blk, pv_win);
+  gjc::k_run_blk_r0<<<(n_blocks + 1 + gjc::kThreads - 1) / gjc::kThreads, gjc::kThreads, 0, st>>>(vmin, set->n_agents, blk_v0,
+                                                                                                  n_blocks, blk_r0);
   return (int)hipGetLastError();
 }
 

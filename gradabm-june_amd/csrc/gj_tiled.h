@@ -402,6 +402,11 @@ struct TSetB {
   int32_t age75[GJ_MAX_NETS_PER_SET];      // susceptibility additionally * (age > 75)
   int32_t leisure;
   int32_t direct;                          // pass 2 runs in phase D's direct form: phase C has nothing to do
+  // run form (gj_tiled_set.run_*): the primary edge of the agents [blk_r0[j], blk_r0[j+1]) - value x[a], venue pv_blk[a]
+  const uint16_t* pv_blk;
+  const int32_t* blk_r0;
+  const float* x;                          // transmission or q * transmission [n_x], 16-byte aligned
+  int64_t n_x;
 };
 
 struct TileBArgs {
@@ -485,6 +490,18 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
     // does not depend on where the block boundaries and the padding put its runs relative to the 8-slot groups - the
     // tile geometry (eb_target, sv_max, slices) cannot change a single bit of `cum`.  (Round 2 merged the runs in fp32
     // and converted the run totals; the launch is bound by the memory system, the extra integer adds are free.)
+#ifdef GJ_DIAG_FLOAT_RUNS      // round 2's form, kept for A/B timing only (tools/ab.py): runs merged in fp32
+    auto run_sums = [&](const int (&lv)[8], const float (&x)[8], int base_k) {
+      float s8 = x[0];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const bool last = (q == 7) || (lv[q + (q < 7)] != lv[q]);
+        const bool take = last && lv[q] != 0xFFFF;
+        fx_add<kFxVenue>(sums, vflags, take ? base_k + lv[q] : dummy, take ? s8 : 0.0f);
+        if (q < 7) s8 = last ? x[q + 1] : s8 + x[q + 1];
+      }
+    };
+#else
     auto run_sums = [&](const int (&lv)[8], const float (&x)[8], int base_k) {
       fx_t s8 = 0;
 #pragma unroll
@@ -501,6 +518,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
         if (__builtin_expect(!ok && lv[q] != 0xFFFF, 0)) atomicOr(&vflags[(base_k + lv[q]) >> 5], 1u << ((base_k + lv[q]) & 31));
       }
     };
+#endif
     auto add_group = [&](const uint4 raw, const float4 xa, const float4 xb, const uint2 craw) {
       const Slots8 L{{raw.x, raw.y, raw.z, raw.w}};
       const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
@@ -535,6 +553,50 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
 #pragma unroll
       for (int u = 0; u < kVenueUnroll; ++u)
         if (g + u * kTileThreads < g1) add_group(raw[u], xa[u], xb[u], craw[u]);
+    }
+    if (T.pv_blk) {
+      // Run form: the agents [r0, r1) have their primary venue in this block; agent a is a slot with value x[a] and
+      // local venue pv_blk[a] - the same straight-line groups of 8 as above, read from the per-agent arrays themselves
+      // (consecutive agents of one venue are a run).  Agents of the neighbouring blocks in the first / last group are
+      // masked; the last group of the world may reach past x.
+      const int r0 = T.blk_r0[j], r1 = T.blk_r0[j + 1];
+      const uint4* pv8 = reinterpret_cast<const uint4*>(T.pv_blk);
+      const float4* x4 = reinterpret_cast<const float4*>(T.x);
+      const int ga = r0 >> 3, gb = (r1 + 7) >> 3;
+      const int g_in = (int)(T.n_x >> 3);            // groups wholly inside x
+      for (int g = ga + tid; g < gb; g += kVenueUnroll * kTileThreads) {
+        uint4 raw[kVenueUnroll];
+        float4 xa[kVenueUnroll], xb[kVenueUnroll];
+#pragma unroll
+        for (int u = 0; u < kVenueUnroll; ++u) {
+          const int gu = min(g + u * kTileThreads, gb - 1);
+          raw[u] = pv8[gu];
+          if (gu < g_in) {
+            xa[u] = x4[2 * gu];
+            xb[u] = x4[2 * gu + 1];
+          } else {
+            float t[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] = ((int64_t)gu * 8 + q < T.n_x) ? T.x[(int64_t)gu * 8 + q] : 0.0f;
+            xa[u] = make_float4(t[0], t[1], t[2], t[3]);
+            xb[u] = make_float4(t[4], t[5], t[6], t[7]);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kVenueUnroll; ++u) {
+          const int gu = g + u * kTileThreads;
+          if (gu >= gb) continue;
+          const Slots8 L{{raw[u].x, raw[u].y, raw[u].z, raw[u].w}};
+          const float x[8] = {xa[u].x, xa[u].y, xa[u].z, xa[u].w, xb[u].x, xb[u].y, xb[u].z, xb[u].w};
+          int lv[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int a = gu * 8 + q;
+            lv[q] = (a >= r0 && a < r1) ? L.lv(q) : 0xFFFF;
+          }
+          run_sums(lv, x, 0);
+        }
+      }
     }
     __syncthreads();
     for (int k = 0; k < nk; ++k) {
@@ -610,6 +672,10 @@ struct TDirect {          // a set whose pass 2 is taken straight from the venue
   int32_t raw, leisure;
   int32_t table[GJ_MAX_NETS_PER_SET];
   int32_t age75[GJ_MAX_NETS_PER_SET];
+  // run form (gj_tiled_set.run_*): `ell` holds ONE window-relative index per agent, the table is the slice's window
+  // [win_lo[s], win_lo[s] + win_n[s]) of cum - one group, one plane
+  const int32_t* win_lo;
+  const int32_t* win_n;
 };
 
 struct TileDArgs {
@@ -703,11 +769,19 @@ __device__ __forceinline__ void direct_load(const TileDArgs& D, const TDirect& T
     // invariants and pays for the ten registers with scratch spills - 144 bytes per lane, more than the XCD's L2 holds
     // for its 32 workgroups, i.e. HBM traffic)
     asm volatile("" : "+v"(q));
-    const uint4 r = *reinterpret_cast<const uint4*>(ell + 8u * q);
-    b.w[u][0] = r.x;
-    b.w[u][1] = r.y;
-    b.w[u][2] = r.z;
-    b.w[u][3] = r.w;
+    if (!T.win_lo) {
+      const uint4 r = *reinterpret_cast<const uint4*>(ell + 8u * q);
+      b.w[u][0] = r.x;
+      b.w[u][1] = r.y;
+      b.w[u][2] = r.z;
+      b.w[u][3] = r.w;
+    } else {          // one index per agent: the quad's four in 8 bytes; the second column is empty
+      const uint2 r = *reinterpret_cast<const uint2*>(T.ell + base + 4u * q);
+      b.w[u][0] = (r.x & 0xFFFFu) | 0xFFFF0000u;
+      b.w[u][1] = (r.x >> 16) | 0xFFFF0000u;
+      b.w[u][2] = (r.y & 0xFFFFu) | 0xFFFF0000u;
+      b.w[u][3] = (r.y >> 16) | 0xFFFF0000u;
+    }
     // the quad's four classes: one dword (agent_class is 4-byte aligned and padded to a multiple of 4 agents)
     b.cls[u] = T.leisure ? *reinterpret_cast<const uint32_t*>(cls + 4u * q) : 0u;
   }
@@ -815,7 +889,7 @@ __device__ __forceinline__ bool direct_next(const TileDArgs& D, int& t, int& v0,
     return true;
   }
   plane = 0;
-  if (v0 + T.group_venues < T.V) {
+  if (!T.win_lo && v0 + T.group_venues < T.V) {
     v0 += T.group_venues;
     return true;
   }
@@ -831,13 +905,17 @@ __device__ __forceinline__ void direct_sets(const TileDArgs& D, float (&acc)[kQu
   auto tab_of = [&](const TDirect& T) {
     return lds + 2 * kClassWeightFloats + (T.region ? D.table_floats + kWave : 0);
   };
+  // a group of venue values: [lo, lo + nv) of the set's cum; the rows index it relative to `v0` (run form: the slice's
+  // window, indexed from 0)
+  auto group_nv = [&](const TDirect& T, int v0) { return T.win_lo ? T.win_n[blockIdx.x] : min(T.group_venues, T.V - v0); };
+  auto group_lo = [&](const TDirect& T, int v0) { return T.win_lo ? T.win_lo[blockIdx.x] : v0; };
   int t = 0, v0 = 0, plane = 0;
   __syncthreads();                              // the LDS is free: every lane has its sums in registers
-  direct_stage(D, D.direct[0], wtab_of(0), tab_of(D.direct[0]), 0, min(D.direct[0].group_venues, D.direct[0].V), tid);
+  direct_stage(D, D.direct[0], wtab_of(0), tab_of(D.direct[0]), group_lo(D.direct[0], 0), group_nv(D.direct[0], 0), tid);
   bool more = true;
   while (more) {
     const TDirect& T = D.direct[t];
-    const int nv = min(T.group_venues, T.V - v0);
+    const int nv = group_nv(T, v0);
     if (plane == 0) publish_staged();           // this group's values have landed (vmcnt(0) + barrier) - and its rows
 #ifdef GJ_DIAG_STAMPS
     if (threadIdx.x == 0 && D.trans_susc && t < 4)
@@ -849,7 +927,7 @@ __device__ __forceinline__ void direct_sets(const TileDArgs& D, float (&acc)[kQu
     // the next group's values can be staged while this one is read if they go to the other region
     const bool overlap = new_group && D.direct[tn].region != T.region;
     if (overlap)
-      direct_stage(D, D.direct[tn], wtab_of(tn), tab_of(D.direct[tn]), vn, min(D.direct[tn].group_venues, D.direct[tn].V - vn), tid);
+      direct_stage(D, D.direct[tn], wtab_of(tn), tab_of(D.direct[tn]), group_lo(D.direct[tn], vn), group_nv(D.direct[tn], vn), tid);
     DirectBatch nxt;
     if (more) direct_load(D, D.direct[tn], base, n_local, tid, pn, nxt);     // in flight while this item is summed
 #ifndef GJ_DIAG_NO_DIRECT_ADD
@@ -863,7 +941,7 @@ __device__ __forceinline__ void direct_sets(const TileDArgs& D, float (&acc)[kQu
 #endif
     if (new_group && !overlap) {                // same region: only once every wave is done reading this group
       __syncthreads();
-      direct_stage(D, D.direct[tn], wtab_of(tn), tab_of(D.direct[tn]), vn, min(D.direct[tn].group_venues, D.direct[tn].V - vn), tid);
+      direct_stage(D, D.direct[tn], wtab_of(tn), tab_of(D.direct[tn]), group_lo(D.direct[tn], vn), group_nv(D.direct[tn], vn), tid);
     }
     if (more) cur = nxt;
     t = tn;

@@ -603,6 +603,60 @@ __global__ __launch_bounds__(kThreads) void k_adjoint_transmission(
   grad_time[a] = grad_time[a] - tb * dtdt;                   // d t / d infection_time = -1
 }
 
+// f3: d loss / d log_beta of the networks on one edge set (include/gradjune_hip.h, gj_adjoint_beta_*)
+struct AdjBetaArgs {
+  int64_t n_venues;
+  int32_t stride, nk;
+  const float* cum_fwd;
+  const float* cum_bwd;
+  const float* v_pc;
+  const double* weights;
+  float beta[GJ_MAX_NETS_PER_SET];
+  int32_t cols[GJ_MAX_NETS_PER_SET];
+  double* partial;
+};
+
+__global__ __launch_bounds__(kThreads) void k_adjoint_beta_partial(const AdjBetaArgs A) {
+  __shared__ double part[kThreads / kWave][GJ_MAX_NETS_PER_SET];
+  double acc[GJ_MAX_NETS_PER_SET];
+#pragma unroll
+  for (int k = 0; k < GJ_MAX_NETS_PER_SET; ++k) acc[k] = 0.0;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < A.n_venues; v += (int64_t)gridDim.x * blockDim.x) {
+    const double pc = (double)A.v_pc[v];
+    if (!(pc > 0.0)) continue;
+    const double w = A.weights ? A.weights[v] : 1.0;
+#pragma unroll
+    for (int k = 0; k < GJ_MAX_NETS_PER_SET; ++k) {
+      if (k >= A.nk) break;
+      const double beta = (double)A.beta[k];
+      if (beta == 0.0) continue;
+      const double prod = (double)A.cum_fwd[v * A.stride + k] * (double)A.cum_bwd[v * A.stride + k];
+      acc[k] += prod / (beta * pc) * w;
+    }
+  }
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+#pragma unroll
+  for (int k = 0; k < GJ_MAX_NETS_PER_SET; ++k) {
+    double x = acc[k];
+    for (int off = kWave / 2; off > 0; off >>= 1) x += __shfl_xor(x, off, kWave);
+    if (lane == 0) part[wave][k] = x;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < A.nk) {
+    double x = 0.0;
+    for (int w = 0; w < kThreads / kWave; ++w) x += part[w][threadIdx.x];
+    A.partial[(int64_t)blockIdx.x * GJ_MAX_NETS + A.cols[threadIdx.x]] += x;     // this (row, column) is this workgroup's alone
+  }
+}
+
+__global__ void k_adjoint_beta_finish(int32_t n_cols, const double* partial, const float* scale, double* out) {
+  const int c = threadIdx.x;
+  if (c >= n_cols) return;
+  double x = 0.0;
+  for (int b = 0; b < GJ_ADJ_BETA_BLOCKS; ++b) x += partial[(int64_t)b * GJ_MAX_NETS + c];
+  out[c] = x * (double)(*scale) * 2.302585092994046;      // ln(10)
+}
+
 // f2: per-step result reductions (reference grad_june/runner.py:167,198-224), one streaming pass
 struct StatsArgs {
   int64_t n;
@@ -984,7 +1038,15 @@ static int check_tiled(const gj_plan* plan) {
     if (S.n_blocks < 0) return GJ_E_PLAN;
     if (S.n_blocks == 0) continue;
     if (!S.blk_v0 || !S.blk_e0 || !S.tile_sptr || !S.tile_jpos || !S.chunk_ptr) return GJ_E_NULL;
-    if (plan->sets[s].n_edges > 0 && (!S.e_lv || !S.a_la || !S.val || !S.chunk_desc)) return GJ_E_NULL;
+    const bool run = S.run_pv_blk || S.run_pv_win || S.run_blk_r0 || S.run_win_lo || S.run_win_n;
+    if (run) {   // all or none; one window of cum per slice must fit phase D's table region
+      if (!S.run_pv_blk || !S.run_pv_win || !S.run_blk_r0 || !S.run_win_lo || !S.run_win_n) return GJ_E_NULL;
+      if (S.run_max_window < 0 || S.run_max_window > 32768 || S.run_tiled_edges < 0 ||
+          S.run_tiled_edges > plan->sets[s].n_edges || S.ell_k)
+        return GJ_E_PLAN;
+    }
+    const int64_t held = run ? (int64_t)S.run_tiled_edges : plan->sets[s].n_edges;
+    if (held > 0 && (!S.e_lv || !S.a_la || !S.val || !S.chunk_desc)) return GJ_E_NULL;
     if (S.max_block_venues < 1 || S.max_block_venues > 65536) return GJ_E_PLAN;
     // phases A and D address val / a_la / chunk_desc with 32-bit byte offsets: < 2^30 edges per set (a larger set
     // is split over several edge sets of the same venue type)
@@ -996,6 +1058,12 @@ static int check_tiled(const gj_plan* plan) {
     }
   }
   return GJ_OK;
+}
+
+// edges the tiled arrays of a set hold (a run form keeps one edge per owned agent out of them)
+static inline int64_t tiled_edges(const gj_plan* plan, int s) {
+  const gj_tiled_set& S = plan->tiled->sets[s];
+  return S.run_pv_blk ? (int64_t)S.run_tiled_edges : plan->sets[s].n_edges;
 }
 
 template <typename K>
@@ -1022,7 +1090,7 @@ static void fill_set_a(const gj_plan* plan, const gj_step_params* p, const Group
     sets[s].chunk_desc = reinterpret_cast<const int4*>(S.chunk_desc);
     sets[s].val = S.val;
     sets[s].J = S.n_blocks;
-    sets[s].active = (S.n_blocks > 0 && plan->sets[s].n_edges > 0) ? G.nk[g] : 0;
+    sets[s].active = (S.n_blocks > 0 && tiled_edges(plan, s) > 0) ? G.nk[g] : 0;
     sets[s].raw = p->nets[G.first[g]].mask_kind == GJ_MASK_RAW;
     sets[s].wide = S.desc_wide != 0;
     sets[s].direct = S.ell_k != 0;
@@ -1052,7 +1120,8 @@ static int tiled_scatter(const gj_plan* plan, const gj_agent_state* st, const gj
   return launch_status();
 }
 
-static int tiled_venues(const gj_plan* plan, const gj_step_params* p, const Groups& G, int mode, hipStream_t stream) {
+static int tiled_venues(const gj_plan* plan, const gj_agent_state* st, const gj_step_params* p, const Groups& G, int mode,
+                        hipStream_t stream) {
   const gj_tiled* T = plan->tiled;
   if (T->n_work == 0 || G.n == 0) return GJ_OK;
   TileBArgs B;
@@ -1087,6 +1156,20 @@ static int tiled_venues(const gj_plan* plan, const gj_step_params* p, const Grou
         if (X.table[k] < 0) return GJ_E_PLAN;
     } else if (G.nk[g] != 1) {
       return GJ_E_PLAN;   // several networks on one set need per-network tables
+    }
+    X.pv_blk = nullptr;
+    X.blk_r0 = nullptr;
+    X.x = nullptr;
+    X.n_x = 0;
+    if (S.run_pv_blk && mode != 2) {     // run form: phase B reads the primary edges' values from the per-agent array
+      if (X.leisure) return GJ_E_PLAN;
+      const bool raw = p->nets[G.first[g]].mask_kind == GJ_MASK_RAW;
+      X.x = (p->has_quarantine && !raw) ? st->q_transmission : st->transmission;
+      if (!X.x) return GJ_E_NULL;
+      if ((uintptr_t)X.x % 16 != 0 || (uintptr_t)S.run_pv_blk % 16 != 0) return GJ_E_PLAN;
+      X.pv_blk = S.run_pv_blk;
+      X.blk_r0 = S.run_blk_r0;
+      X.n_x = plan->n_ext_agents;
     }
     const size_t n_sums = (size_t)X.nk * S.max_block_venues + 64;               // + a scratch sum per lane of a wave
     const size_t need = n_sums * sizeof(fx_t) + (X.leisure ? 2 * 200 * (size_t)X.nk : 0) * sizeof(float) +
@@ -1143,15 +1226,19 @@ static int tiled_agents(const gj_plan* plan, const gj_agent_state* st, const gj_
     const int s = G.set[g];
     const gj_tiled_set& S = T->sets[s];
     const gj_edge_set& E = plan->sets[s];
-    if (!S.ell_k || S.n_blocks == 0 || E.n_edges == 0) continue;
+    const bool run = S.run_pv_win != nullptr;
+    if ((!S.ell_k && !run) || S.n_blocks == 0 || E.n_edges == 0) continue;
     if (D.n_direct == GJ_MAX_DIRECT) return GJ_E_PLAN;
     TDirect& X = D.direct[D.n_direct++];
-    X.ell = S.ell;
+    X.ell = run ? S.run_pv_win : S.ell;
     X.cum = E.cum;
     X.K = 2;
-    X.planes = S.ell_k / 2;
+    X.planes = run ? 1 : S.ell_k / 2;
     X.plane_stride = owned_slices * (int64_t)T->slice_agents * 2;
-    X.V = (int32_t)E.n_venues;
+    X.V = run ? S.run_max_window : (int32_t)E.n_venues;      // (run form: the table is one slice's window of cum)
+    X.win_lo = run ? S.run_win_lo : nullptr;
+    X.win_n = run ? S.run_win_n : nullptr;
+    if (run && (uintptr_t)S.run_pv_win % 8 != 0) return GJ_E_PLAN;
     X.stride = E.cum_stride;
     X.nk = G.nk[g];
     X.raw = p->nets[G.first[g]].mask_kind == GJ_MASK_RAW;
@@ -1197,7 +1284,7 @@ static int tiled_agents(const gj_plan* plan, const gj_agent_state* st, const gj_
       X.region = (prev_region == 0 && sz <= cap1) ? 1 : 0;
       const int64_t cap = X.region ? cap1 : cap0;
       X.group_venues = sz <= cap ? X.V : (int32_t)(cap / X.stride);
-      if (X.group_venues < 1) return GJ_E_PLAN;
+      if (X.group_venues < 1 || (X.win_lo && sz > cap)) return GJ_E_PLAN;   // a window is staged whole
       X._pad = 0;
       prev_region = X.region;
     }
@@ -1298,7 +1385,7 @@ int gj_venue_reduce(const gj_plan* plan, const gj_agent_state* state, const gj_s
   if (plan->tiled) {
     rc = gj::tiled_scatter(plan, state, params, G, (hipStream_t)stream);
     if (rc) return rc;
-    return gj::tiled_venues(plan, params, G, 1, (hipStream_t)stream);
+    return gj::tiled_venues(plan, state, params, G, 1, (hipStream_t)stream);
   }
   return gj::do_venue_reduce(plan, state, params, G, (hipStream_t)stream);
 }
@@ -1313,7 +1400,7 @@ int gj_agent_gather(const gj_plan* plan, const gj_agent_state* state, const gj_s
   rc = gj::check_state(plan, state, params, sample != 0);
   if (rc) return rc;
   if (plan->tiled) {
-    rc = gj::tiled_venues(plan, params, G, 2, (hipStream_t)stream);
+    rc = gj::tiled_venues(plan, state, params, G, 2, (hipStream_t)stream);
     if (rc) return rc;
     return gj::tiled_agents(plan, state, params, G, io, sample, (hipStream_t)stream);
   }
@@ -1360,6 +1447,39 @@ int gj_adjoint_transmission(int64_t n, const gj_agent_state* st, float now, cons
                      dim3(gj::kThreads), 0, (hipStream_t)stream, n, st->max_infectiousness, st->shape, st->rate,
                      st->shift, st->infection_time, st->is_infected, now, trans_bar, g_inf, grad_inf_out,
                      grad_time_inout);
+  return gj::launch_status();
+}
+
+int gj_adjoint_beta_partial(int64_t n_venues, int32_t stride, int32_t nk, const float* cum_fwd, const float* cum_bwd,
+                            const float* v_pcontact, const double* weights, const float* beta, const int32_t* cols,
+                            double* partial, void* stream) {
+  if (n_venues < 0 || stride < 1 || stride > GJ_MAX_NETS_PER_SET || nk < 0 || nk > stride) return GJ_E_RANGE;
+  if (!partial || (nk > 0 && (!beta || !cols))) return GJ_E_NULL;
+  if (n_venues == 0 || nk == 0) return GJ_OK;
+  if (!cum_fwd || !cum_bwd || !v_pcontact) return GJ_E_NULL;
+  gj::AdjBetaArgs A;
+  A.n_venues = n_venues;
+  A.stride = stride;
+  A.nk = nk;
+  A.cum_fwd = cum_fwd;
+  A.cum_bwd = cum_bwd;
+  A.v_pc = v_pcontact;
+  A.weights = weights;
+  for (int k = 0; k < GJ_MAX_NETS_PER_SET; ++k) {
+    A.beta[k] = k < nk ? beta[k] : 0.0f;
+    A.cols[k] = k < nk ? cols[k] : 0;
+    if (k < nk && (cols[k] < 0 || cols[k] >= GJ_MAX_NETS)) return GJ_E_RANGE;
+  }
+  A.partial = partial;
+  hipLaunchKernelGGL(gj::k_adjoint_beta_partial, dim3(GJ_ADJ_BETA_BLOCKS), dim3(gj::kThreads), 0, (hipStream_t)stream, A);
+  return gj::launch_status();
+}
+
+int gj_adjoint_beta_finish(int32_t n_cols, const double* partial, const float* scale, double* out, void* stream) {
+  if (n_cols < 0 || n_cols > GJ_MAX_NETS) return GJ_E_RANGE;
+  if (n_cols == 0) return GJ_OK;
+  if (!partial || !scale || !out) return GJ_E_NULL;
+  hipLaunchKernelGGL(gj::k_adjoint_beta_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, n_cols, partial, scale, out);
   return gj::launch_status();
 }
 
@@ -1501,7 +1621,7 @@ int gj_step(const gj_plan* plan, const gj_agent_state* state, const gj_step_para
   if (plan->tiled) {
     rc = gj::tiled_scatter(plan, state, params, G, (hipStream_t)stream);
     if (rc) return rc;
-    rc = gj::tiled_venues(plan, params, G, 0, (hipStream_t)stream);
+    rc = gj::tiled_venues(plan, state, params, G, 0, (hipStream_t)stream);
     if (rc) return rc;
     return gj::tiled_agents(plan, state, params, G, io, 1, (hipStream_t)stream);
   }
@@ -1524,19 +1644,19 @@ int gj_step_phase(const gj_plan* plan, const gj_agent_state* state, const gj_ste
     case 0: return gj::do_transmission(plan, state, params, st);
     case 1: return plan->tiled ? gj::tiled_scatter(plan, state, params, G, st)
                                : gj::do_venue_reduce(plan, state, params, G, st);
-    case 2: return plan->tiled ? gj::tiled_venues(plan, params, G, 0, st) : GJ_OK;
+    case 2: return plan->tiled ? gj::tiled_venues(plan, state, params, G, 0, st) : GJ_OK;
     case 3: return plan->tiled ? gj::tiled_agents(plan, state, params, G, io, 1, st)
                                : gj::do_agent_gather(plan, state, params, G, io, 1, st);
     case 4: return plan->tiled ? gj::tiled_agents(plan, state, params, G, io, 0, st)
                                : gj::do_agent_gather(plan, state, params, G, io, 0, st);
-    case 5: return plan->tiled ? gj::tiled_venues(plan, params, G, 1, st) : GJ_OK;
-    case 6: return plan->tiled ? gj::tiled_venues(plan, params, G, 2, st) : GJ_OK;
+    case 5: return plan->tiled ? gj::tiled_venues(plan, state, params, G, 1, st) : GJ_OK;
+    case 6: return plan->tiled ? gj::tiled_venues(plan, state, params, G, 2, st) : GJ_OK;
     case 7:   // 1 then 5 (A + B) in one call: the launch path of a partial-sum group
     case 8:   // 1 then 2 (A + B + C)
       if (!plan->tiled) return gj::do_venue_reduce(plan, state, params, G, st);
       rc = gj::tiled_scatter(plan, state, params, G, st);
       if (rc) return rc;
-      return gj::tiled_venues(plan, params, G, phase == 7 ? 1 : 0, st);
+      return gj::tiled_venues(plan, state, params, G, phase == 7 ? 1 : 0, st);
     default: return GJ_E_RANGE;
   }
 }

@@ -15,6 +15,7 @@ GJ_MAX_SETS = 12
 GJ_MAX_NETS = 16
 GJ_MAX_NETS_PER_SET = 8
 GJ_TABLE_SIZE = 400
+GJ_ADJ_BETA_BLOCKS = 256
 GJ_STREAM_EDGES = 2048
 
 MASK_RAW, MASK_Q, MASK_QL, MASK_QL_AGE75 = 0, 1, 2, 3
@@ -58,6 +59,13 @@ class TiledSet(C.Structure):
         ("chunk_desc", _vp),
         ("val", _vp),
         ("ell", _vp),
+        ("run_pv_blk", _vp),
+        ("run_pv_win", _vp),
+        ("run_blk_r0", _vp),
+        ("run_win_lo", _vp),
+        ("run_win_n", _vp),
+        ("run_max_window", C.c_int32),
+        ("run_tiled_edges", C.c_int32),
     ]
 
 
@@ -188,6 +196,11 @@ SYMBOLS = {
          _vp, _vp, _vp, _vp],
     ),
     "gj_adjoint_transmission": (C.c_int, [C.c_int64, C.POINTER(AgentState), C.c_float, _vp, _vp, _vp, _vp, _vp]),
+    "gj_adjoint_beta_partial": (
+        C.c_int,
+        [C.c_int64, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, C.POINTER(C.c_float), C.POINTER(C.c_int32), _vp, _vp],
+    ),
+    "gj_adjoint_beta_finish": (C.c_int, [C.c_int32, _vp, _vp, _vp, _vp]),
     "gj_symptoms_update": (
         C.c_int,
         [C.c_int64, _vp, _vp, _vp, _vp, _vp, C.POINTER(SymptomsParams), _vp, _vp, _vp],
@@ -217,8 +230,9 @@ SYMBOLS = {
 }
 
 # ---- graph compile on the device (include/gradjune_hip.h, "graph compile") ----
-GJ_COMPILE_COUNTS = 8
+GJ_COMPILE_COUNTS = 16
 GJ_CC_BLOCKS, GJ_CC_SLOTS, GJ_CC_CHUNKS, GJ_CC_MULTI, GJ_CC_OWNED_EDGES, GJ_CC_MAX_DEGREE, GJ_CC_ERROR = 0, 1, 2, 3, 4, 5, 7
+GJ_CC_RUN_PRIMARY, GJ_CC_RUN_UNSORTED, GJ_CC_RUN_WINDOW = 8, 9, 10
 
 
 class CompileSet(C.Structure):
@@ -245,6 +259,9 @@ SYMBOLS.update({
     "gj_compile_tiles": (C.c_int, [C.POINTER(CompileSet), _vp, C.POINTER(CompileOut), _vp, _vp, C.c_int64, _vp]),
     "gj_compile_wide_descriptors": (C.c_int, [C.POINTER(CompileSet), C.POINTER(CompileOut), C.c_int32, _vp, _vp, _vp]),
     "gj_compile_ell_degrees": (C.c_int, [C.POINTER(CompileSet), _vp, _vp, _vp]),
+    "gj_compile_runs_pick": (C.c_int, [C.POINTER(CompileSet), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gj_compile_runs_rest": (C.c_int, [C.POINTER(CompileSet), _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp]),
+    "gj_compile_runs_index": (C.c_int, [C.POINTER(CompileSet), _vp, _vp, C.c_int32, C.c_int64, _vp, _vp, _vp, _vp, _vp]),
     "gj_compile_ell": (C.c_int, [C.POINTER(CompileSet), C.c_int32, C.c_int64, _vp, _vp, _vp, C.c_int64, _vp, _vp]),
 })
 

@@ -86,27 +86,38 @@ def _names_with_twins(plan, nets):
 def _beta_gradients(plan, nets, betas, cum_fwd, scale, weights_of=None) -> List[torch.Tensor]:
     """ln(10) * sum_v cum_n[v] * cum'_n[v] / (beta_n * p_contact[v]) per network, from the forward's and the
     transposed pass's per-venue sums (``plan.cum_of`` holds the latter).  ``weights_of(edge set)``: this rank's
-    weight of every venue (multi-GPU: the ranks' values are summed by the caller)."""
-    grads: List[torch.Tensor] = []
-    per_set_k = {}
-    for net, names in _names_with_twins(plan, nets):
-        beta = float(betas[net.name])
-        total = None
+    weight of every venue (multi-GPU: the ranks' values are summed by the caller).  One launch per edge set + one to
+    finish (gj_adjoint_beta_*: fp64, summed in a fixed order) - as torch ops this was ~10 small launches per network
+    and what a backward step spent most of its host time on."""
+    lib, dev = N.load(), plan.device
+    partial = torch.zeros(N.GJ_ADJ_BETA_BLOCKS * N.GJ_MAX_NETS, dtype=torch.float64, device=dev)
+    out = torch.zeros(max(1, len(nets)), dtype=torch.float64, device=dev)
+    per_set, per_set_k = {}, {}
+    for col, (net, names) in enumerate(_names_with_twins(plan, nets)):
         for name in names:
             es = plan.networks[name].edge_set
             k = per_set_k.get(es, 0)
             per_set_k[es] = k + 1
-            i = plan.host.set_index[es]
-            pc = plan.keep[i]["v_pc"].double()
-            prod = cum_fwd[es][:, k].double() * plan.cum_of(es)[:, k].double()
-            w = weights_of(es) if weights_of is not None else None
-            if w is not None:
-                prod = prod * w
-            dot = (torch.where(pc > 0, prod / (beta * pc), torch.zeros_like(prod)).sum() if beta != 0.0
-                   else prod.sum() * 0)
-            total = dot if total is None else total + dot
-        grads.append(total * scale.double() * math.log(10.0))
-    return grads
+            per_set.setdefault(es, []).append((k, col, float(betas[net.name])))
+    scale32 = scale.to(device=dev, dtype=torch.float32).reshape(1)
+    keep = []
+    for es, items in per_set.items():
+        i = plan.host.set_index[es]
+        nk = len(items)
+        assert [k for k, _, _ in items] == list(range(nk))
+        beta = (C.c_float * nk)(*[b for _, _, b in items])
+        cols = (C.c_int32 * nk)(*[c for _, c, _ in items])
+        w = weights_of(es) if weights_of is not None else None
+        if w is not None:
+            w = w.to(device=dev, dtype=torch.float64).contiguous()
+        fwd, bwd = cum_fwd[es].contiguous(), plan.cum_of(es)
+        keep.append((w, fwd))
+        N.check(lib.gj_adjoint_beta_partial(plan.host.sets[i].n_venues, int(plan.c.sets[i].cum_stride), nk, N.ptr(fwd),
+                                            N.ptr(bwd), N.ptr(plan.keep[i]["v_pc"]), N.ptr(w), beta, cols, N.ptr(partial),
+                                            N.current_stream()), "gj_adjoint_beta_partial")
+    N.check(lib.gj_adjoint_beta_finish(len(nets), N.ptr(partial), N.ptr(scale32), N.ptr(out), N.current_stream()),
+            "gj_adjoint_beta_finish")
+    return [out[i] for i in range(len(nets))]
 
 
 def _power_of_two_scale(peak: torch.Tensor) -> torch.Tensor:

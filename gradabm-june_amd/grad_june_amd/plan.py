@@ -211,6 +211,11 @@ def save_plan(plan: HostPlan, path) -> None:
                 if getattr(t, k) is not None:
                     a = _host(getattr(t, k))
                     out[p + "tiled/" + k] = a.view(np.uint16) if (k in ("e_lv", "a_la", "ell") and a.dtype == np.int16) else a
+            if t.runs is not None:
+                for k in ("vmin", "pv_blk", "pv_win", "blk_r0", "win_lo", "win_n"):
+                    a = _host(getattr(t.runs, k))
+                    out[p + "tiled/runs/" + k] = a.view(np.uint16) if a.dtype == np.int16 else a
+                out[p + "tiled/runs/meta"] = np.array([t.runs.n_primary, t.runs.max_window], dtype=np.int64)
             out[p + "tiled/meta"] = np.array([t.n_slices, t.n_blocks, t.n_slots, int(t.desc_wide), int(t.ell_k)],
                                              dtype=np.int64)
     np.savez(path, **out)
@@ -237,6 +242,12 @@ def load_plan(path) -> HostPlan:
                                        v_pcontact=hs.v_pcontact, n_slots=n_slots, chunk_ptr=a[p + "tiled/chunk_ptr"],
                                        chunk_desc=a[p + "tiled/chunk_desc"], desc_wide=bool(wide),
                                        ell=a.get(p + "tiled/ell"), ell_k=ell_k)
+            if p + "tiled/runs/meta" in a:
+                r = p + "tiled/runs/"
+                hs.tiled.n_edges = int(len(a[p + "tiled/a_la"]))       # the tiled arrays hold the non-primary edges
+                hs.tiled.runs = TL.RunForm(n_primary=int(a[r + "meta"][0]), keep=None, vmin=a[r + "vmin"],
+                                           pv_blk=a[r + "pv_blk"], pv_win=a[r + "pv_win"], blk_r0=a[r + "blk_r0"],
+                                           win_lo=a[r + "win_lo"], win_n=a[r + "win_n"], max_window=int(a[r + "meta"][1]))
         sets.append(hs)
     return HostPlan(int(a["meta/n_agents"]), int(a["meta/n_ext_agents"]), sets, a["agent_class"], a["blocks"],
                     a["long_rows"], int(a["meta/n_partial_slots"]), {s.name: i for i, s in enumerate(sets)},
@@ -257,7 +268,7 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
                  layout: str = "csr", leisure_sets: Sequence[str] = ("leisure",),
                  sv_max: int = TL.SV_MAX, eb_target: Optional[int] = None, slices=None,
                  nets_per_set: Optional[Dict[str, int]] = None, progress=None,
-                 desc_wide: Optional[bool] = None, device=None, direct=None) -> HostPlan:
+                 desc_wide: Optional[bool] = None, device=None, direct=None, runs=None) -> HostPlan:
     """edge_sets: {name: {"agent": i64[E], "venue": i64[E], "people": [V]}} (insertion order = set ids).
 
     layout: "csr" (deterministic CSR kernels), "tiled" (LDS-tiled fast path) or "both".
@@ -270,6 +281,10 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
     direct: which sets take pass 2 in the "direct" form (tiling.build_ell: phase C skipped, phase D reads the
     venues' cum from an LDS table).  None = every set whose sizes allow it (tiling.direct_eligible), False =
     none, or a collection of set names (must be eligible).
+    runs: which sets keep one edge per owned agent in the "run form" (tiling.split_primary_runs: the set the agents
+    are ordered by - households under graph.locality_order - needs no index arrays for those edges).  None = every
+    single-network set whose agents are so ordered, that is not in the direct form and where it pays; False = none;
+    or a collection of set names (must be possible; takes precedence over the direct form).
     """
     if len(edge_sets) > N.GJ_MAX_SETS:
         raise ValueError(f"at most {N.GJ_MAX_SETS} edge sets")
@@ -295,21 +310,33 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
         if want_tiled:
             k = (nets_per_set or {}).get(name, 6 if name in leisure_sets else 1)
             use_cls = cls_all if (name in leisure_sets and cls_all is not None) else None
+            forced_run = runs is not None and runs is not False and name in runs
+            plan_direct = None
+            if not forced_run:
+                plan_direct = _direct_plan(name, es, hs.n_venues, n_agents, SA, k, direct, device)
+            rf, es_t = None, es
+            if runs is not False and (forced_run or (plan_direct is None and runs is None)) and k == 1 \
+                    and name not in leisure_sets:
+                rf, es_t = _split_runs(name, es, n_agents, hs.n_venues, SA, device, forced_run)
             if device is not None:
                 from .tiling_native import build_tiled_native
 
-                hs.tiled = build_tiled_native(name, es["agent"], es["venue"], hs.n_venues, hs.v_pcontact, S, SA,
+                hs.tiled = build_tiled_native(name, es_t["agent"], es_t["venue"], hs.n_venues, hs.v_pcontact, S, SA,
                                               agent_class=use_cls, sv_max=max(16, sv_max // max(1, k)),
                                               eb_target=eb_target, wide=desc_wide, device=device, n_ext_agents=n_ext)
             else:
-                hs.tiled = TL.build_tiled(name, es["agent"], es["venue"], hs.n_venues, hs.v_pcontact, S, SA,
+                hs.tiled = TL.build_tiled(name, es_t["agent"], es_t["venue"], hs.n_venues, hs.v_pcontact, S, SA,
                                           agent_class=use_cls, sv_max=max(16, sv_max // max(1, k)),
                                           eb_target=eb_target, wide=desc_wide)
             t = hs.tiled
-            _attach_ell(t, es, n_agents, SA, k, direct, device)
+            if rf is not None:
+                t.runs = _finish_runs(rf, t, n_agents, SA, device)
+            elif plan_direct is not None:
+                t.ell, t.ell_k = plan_direct()
             blk_e0, blk_v0 = _host(t.blk_e0).astype(np.int64), _host(t.blk_v0).astype(np.int64)
+            prim = np.diff(_host(t.runs.blk_r0).astype(np.int64)) if t.runs is not None else np.zeros(t.n_blocks, np.int64)
             for j in range(t.n_blocks):
-                work.append((int(blk_e0[j + 1] - blk_e0[j]) + int(blk_v0[j + 1] - blk_v0[j]), sid, j))
+                work.append((int(blk_e0[j + 1] - blk_e0[j]) + int(blk_v0[j + 1] - blk_v0[j]) + int(prim[j]), sid, j))
         if progress:
             progress(f"compiled edge set {name}")
         if not want_csr:
@@ -346,16 +373,18 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
                     work=work_arr if want_tiled else None)
 
 
-def _attach_ell(t: TL.TiledEdgeSet, es: dict, n_agents: int, slice_agents: int, nets: int, direct, device) -> None:
-    """Decide whether pass 2 of this set runs in the direct form and, if so, build its ELL table."""
-    if direct is False or t.n_edges == 0:
-        return
+def _direct_plan(name: str, es: dict, n_venues: int, n_agents: int, slice_agents: int, nets: int, direct, device):
+    """Decide whether pass 2 of this set runs in the direct form; returns None or a callable that builds its ELL
+    table -> (ell, K)."""
+    n_edges = int(es["agent"].numel() if hasattr(es["agent"], "numel") else np.asarray(es["agent"]).size)
+    if direct is False or n_edges == 0:
+        return None
     n_owned_slices = max(1, -(-n_agents // slice_agents))
     builder = None
     if device is not None:
         from .tiling_native import EllBuilder
 
-        builder = EllBuilder(es["agent"], es["venue"], t.n_venues, n_agents, slice_agents, device)
+        builder = EllBuilder(es["agent"], es["venue"], n_venues, n_agents, slice_agents, device)
         e_owned, dmax = builder.degrees()
     else:
         agent = np.asarray(_host(es["agent"]), dtype=np.int64).ravel()
@@ -363,16 +392,42 @@ def _attach_ell(t: TL.TiledEdgeSet, es: dict, n_agents: int, slice_agents: int, 
         own = agent[agent < n_agents]
         e_owned = int(len(own))
         dmax = int(np.bincount(own, minlength=max(1, n_agents)).max()) if e_owned else 0
-    ok = TL.direct_eligible(t.n_venues, e_owned, n_agents, dmax, nets, slice_agents)
-    forced = direct is not None and t.name in direct
+    ok = TL.direct_eligible(n_venues, e_owned, n_agents, dmax, nets, slice_agents)
+    forced = direct is not None and name in direct
     if forced and not ok:
-        raise ValueError(f"edge set {t.name}: not eligible for the direct form of pass 2")
+        raise ValueError(f"edge set {name}: not eligible for the direct form of pass 2")
     if not ok or (direct is not None and not forced):
-        return
+        return None
     if builder is not None:
-        t.ell, t.ell_k = builder.build(dmax)
+        return lambda: builder.build(dmax)
+    return lambda: TL.build_ell(agent, venue, n_agents, n_owned_slices, slice_agents)
+
+
+def _split_runs(name: str, es: dict, n_agents: int, n_venues: int, slice_agents: int, device, forced: bool):
+    """(RunForm or None, the edge lists that stay in the tiled arrays)."""
+    min_share = 0.0 if forced else TL.RUN_MIN_SHARE
+    if device is not None:
+        from .tiling_native import split_primary_runs_native
+
+        rf, rest = split_primary_runs_native(es["agent"], es["venue"], n_agents, n_venues, slice_agents, device, min_share)
     else:
-        t.ell, t.ell_k = TL.build_ell(agent, venue, n_agents, n_owned_slices, slice_agents)
+        agent, venue = _host(es["agent"]), _host(es["venue"])
+        rf = TL.split_primary_runs(agent, venue, n_agents, n_venues, slice_agents, min_share)
+        rest = None if rf is None else {"agent": np.asarray(agent).ravel()[rf.keep], "venue": np.asarray(venue).ravel()[rf.keep]}
+    if rf is None:
+        if forced:
+            raise ValueError(f"edge set {name}: the run form needs the owned agents ordered by their smallest venue of "
+                             f"the set (graph.locality_order), agents without an edge last")
+        return None, es
+    return rf, dict(es, **rest)
+
+
+def _finish_runs(rf, t, n_agents: int, slice_agents: int, device):
+    if device is not None:
+        from .tiling_native import finish_run_form_native
+
+        return finish_run_form_native(rf, t.blk_v0, n_agents, slice_agents, device)
+    return TL.finish_run_form(rf, _host(t.blk_v0), n_agents, slice_agents)
 
 
 class DevicePlan:
@@ -471,6 +526,16 @@ class DevicePlan:
                 c.tile_sptr, c.tile_jpos, c.val = t["tile_sptr"].data_ptr(), t["tile_jpos"].data_ptr(), t["val"].data_ptr()
                 c.chunk_ptr, c.chunk_desc = t["chunk_ptr"].data_ptr(), N.ptr(t["chunk_desc"])
                 c.ell_k, c.ell = int(ts.ell_k), N.ptr(t.get("ell"))
+                if ts.runs is not None:
+                    rf = ts.runs
+                    pad16 = lambda a: torch.cat([a, torch.full((8,), -1, dtype=a.dtype, device=a.device)])  # 16-byte groups
+                    t.update(run_pv_blk=pad16(u16(rf.pv_blk)), run_pv_win=pad16(u16(rf.pv_win)), run_blk_r0=up(rf.blk_r0),
+                             run_win_lo=up(rf.win_lo), run_win_n=up(rf.win_n))
+                    c.run_pv_blk, c.run_pv_win = t["run_pv_blk"].data_ptr(), t["run_pv_win"].data_ptr()
+                    c.run_blk_r0, c.run_win_lo, c.run_win_n = (t["run_blk_r0"].data_ptr(), t["run_win_lo"].data_ptr(),
+                                                               t["run_win_n"].data_ptr())
+                    c.run_max_window = int(rf.max_window)
+                    c.run_tiled_edges = int(ts.n_edges)
             self.keep.append(t)
             self.cum.append(cum)
         self.blocks = up(host.blocks.reshape(-1)) if len(host.blocks) else None

@@ -102,6 +102,7 @@ class TiledEdgeSet:
     desc_wide: bool = False                  # chunk_desc is int32 [n_chunks, 8], see wide_descriptors()
     ell: Optional[np.ndarray] = None         # uint16 [owned agents padded to slices, ell_k]: "direct" pass 2, see build_ell()
     ell_k: int = 0                           # 0: pass 2 runs through phases C + D like pass 1
+    runs: Optional["RunForm"] = None         # the set's primary edges in the run form (see split_primary_runs)
     # A chunk = 64 consecutive slice-major edges.  Its first `split` edges lie in one tile and map to
     # block-major slots slot0, slot0+1, ...; the rest lie in the next non-empty tile and map to slot1,
     # slot1+1, ...  `multi` flags the rare chunk that spans more than two tiles (tiny tiles): its
@@ -242,6 +243,98 @@ def build_tiled(name: str, agent_index, venue_index, n_venues: int, v_pcontact: 
 
 
 # ------------------------------------------------------------------------------------------------
+# "run form": the edge set that defines the agent order needs no index arrays for one edge per agent
+# ------------------------------------------------------------------------------------------------
+# Under the household-major agent order (graph.locality_order / synthetic.reorder_agents: agents sorted by their
+# first - smallest - venue of that set) the agents whose first venue is v are CONSECUTIVE.  One edge per agent, its
+# "primary" edge (a, vmin(a)), is then implied by the agent's position:
+#   pass 1: the block-major stream of these edges IS the transmission array itself - phase B reads x[a] (coalesced)
+#           next to a 2-byte block-local venue index per agent and adds it to the venue's sum like any other slot;
+#           phase A has nothing to scatter for them;
+#   pass 2: an agent's primary venue lies in a narrow window of consecutive venues per slice: phase D stages that
+#           window of `cum` through LDS (the direct form's machinery) and reads it through a 2-byte window-relative
+#           index per agent; phase C has nothing to write for them.
+# Per primary edge ~10 bytes per step instead of ~25.  The remaining edges of the set (an agent's other venues, edges
+# of halo agents) stay in the tiled arrays.  In a world of the reference's kind - every person lives in exactly one
+# household - the household set leaves the tiled path entirely.
+RUN_MIN_SHARE = 0.25        # primary edges / owned edges below which the run form is not worth its two extra arrays
+RUN_MAX_WINDOW = 32768      # venues a slice's window may span (LDS floats of phase D's table region; ids are 16-bit)
+
+
+@dataclass
+class RunForm:
+    n_primary: int
+    keep: Optional[np.ndarray]     # bool [E]: edges that stay in the tiled arrays (numpy build only)
+    vmin: np.ndarray               # int32 [owned agents] smallest venue of the agent, 0x7FFFFFFF = no edge
+    pv_blk: Optional[np.ndarray] = None   # uint16 [rows] primary venue, relative to its venue block's first venue
+    pv_win: Optional[np.ndarray] = None   # uint16 [rows] primary venue, relative to the slice's window; 0xFFFF = none
+    blk_r0: Optional[np.ndarray] = None   # int32 [J+1] agents [blk_r0[j], blk_r0[j+1]) have their primary venue in block j
+    win_lo: Optional[np.ndarray] = None   # int32 [owned slices] first venue of the slice's window
+    win_n: Optional[np.ndarray] = None    # int32 [owned slices] venues in the window
+    max_window: int = 0
+
+
+NO_VENUE = 0x7FFFFFFF
+
+
+def split_primary_runs(agent_index, venue_index, n_agents: int, n_venues: int, slice_agents: int,
+                       min_share: float = RUN_MIN_SHARE) -> Optional[RunForm]:
+    """Decide whether a set takes the run form and, if so, pick every owned agent's primary edge: the FIRST edge in
+    COO order to the agent's smallest venue.  None when the owned agents are not ordered by their smallest venue
+    (agents without an edge last), when a slice's window is too wide or when too few edges would leave."""
+    agent = np.asarray(agent_index, dtype=np.int64).ravel()
+    venue = np.asarray(venue_index, dtype=np.int64).ravel()
+    if n_agents <= 0 or len(agent) == 0:
+        return None
+    own = agent < n_agents
+    vmin = np.full(n_agents, NO_VENUE, dtype=np.int64)
+    np.minimum.at(vmin, agent[own], venue[own])
+    if (np.diff(vmin) < 0).any():
+        return None
+    e_idx = np.flatnonzero(own & (venue == vmin[np.minimum(agent, n_agents - 1)]))
+    pick = np.full(n_agents, np.iinfo(np.int64).max, dtype=np.int64)
+    np.minimum.at(pick, agent[e_idx], e_idx)
+    has = vmin != NO_VENUE
+    n_primary = int(has.sum())
+    if n_primary < min_share * int(own.sum()):
+        return None
+    n_own_slices = max(1, -(-n_agents // slice_agents))
+    win_lo = np.zeros(n_own_slices, dtype=np.int64)
+    win_n = np.zeros(n_own_slices, dtype=np.int64)
+    for s in range(n_own_slices):          # (vectorised below would need reduceat on ragged ends; slices are few)
+        seg = vmin[s * slice_agents:min(n_agents, (s + 1) * slice_agents)]
+        seg = seg[seg != NO_VENUE]
+        if len(seg):
+            win_lo[s] = seg[0]
+            win_n[s] = seg[-1] - seg[0] + 1
+    if int(win_n.max()) > RUN_MAX_WINDOW:
+        return None
+    keep = np.ones(len(agent), dtype=bool)
+    keep[pick[has]] = False
+    return RunForm(n_primary=n_primary, keep=keep, vmin=vmin.astype(np.int32), win_lo=win_lo.astype(np.int32),
+                   win_n=win_n.astype(np.int32), max_window=int(win_n.max()))
+
+
+def finish_run_form(rf: RunForm, blk_v0: np.ndarray, n_agents: int, slice_agents: int) -> RunForm:
+    """The per-agent indices once the venue blocks of the set's tiled part are known."""
+    vmin = rf.vmin.astype(np.int64)
+    blk_v0 = np.asarray(blk_v0, dtype=np.int64)
+    n_own_slices = len(rf.win_lo)
+    rows = n_own_slices * slice_agents
+    has = vmin != NO_VENUE
+    pv_blk = np.full(rows, 0xFFFF, dtype=np.uint16)
+    pv_win = np.full(rows, 0xFFFF, dtype=np.uint16)
+    j = np.searchsorted(blk_v0, vmin[has], side="right") - 1
+    pv_blk[:n_agents][has] = (vmin[has] - blk_v0[j]).astype(np.uint16)
+    sl = np.arange(n_agents)[has] // slice_agents
+    pv_win[:n_agents][has] = (vmin[has] - rf.win_lo.astype(np.int64)[sl]).astype(np.uint16)
+    # agents of block j: vmin in [blk_v0[j], blk_v0[j+1]) - vmin is sorted, agents without an edge (NO_VENUE) come last
+    rf.blk_r0 = np.searchsorted(vmin, blk_v0, side="left").astype(np.int32)
+    rf.pv_blk, rf.pv_win = pv_blk, pv_win
+    return rf
+
+
+# ------------------------------------------------------------------------------------------------
 # "direct" pass 2 for sets with few venues
 # ------------------------------------------------------------------------------------------------
 # When a set has so few venues that its whole cum vector fits in LDS (schools, universities, leisure venues:
@@ -368,6 +461,11 @@ def emulate_pass1(t: TiledEdgeSet, x: np.ndarray, slice_agents: int, beta: float
         if table is not None:
             xv = table[t.e_cls[e0:e1][real]].astype(np.float64) * xv
         sums = np.bincount(t.e_lv[e0:e1][real], weights=xv, minlength=v1 - v0)
+        if t.runs is not None:      # run form: the block's primary edges, value x[a], local venue pv_blk[a]
+            r0, r1 = int(t.runs.blk_r0[j]), int(t.runs.blk_r0[j + 1])
+            lv = t.runs.pv_blk[r0:r1].astype(np.int64)
+            assert (lv != 0xFFFF).all() and (lv < v1 - v0).all()
+            sums = sums + np.bincount(lv, weights=x[r0:r1].astype(np.float64), minlength=v1 - v0)
         cum[v0:v1] = (np.float32(beta) * t.v_pcontact[v0:v1]) * sums.astype(np.float32)
     return val, cum
 
@@ -391,4 +489,13 @@ def emulate_pass2(t: TiledEdgeSet, cum: np.ndarray, n_agents: int, slice_agents:
             a, b = t.tile_sptr[s * J + j], t.tile_sptr[s * J + j + 1]
             p = t.tile_jpos[s * J + j]
             np.add.at(acc, s * slice_agents + t.a_la[a:b].astype(np.int64), cval[p:p + (b - a)])
+    if t.runs is not None:          # run form: every owned agent reads its primary venue from its slice's window of cum
+        rf = t.runs
+        for s in range(len(rf.win_lo)):
+            lo, n = int(rf.win_lo[s]), int(rf.win_n[s])
+            window = cum[lo:lo + n]
+            pv = rf.pv_win[s * slice_agents:(s + 1) * slice_agents].astype(np.int64)
+            ok = pv != 0xFFFF
+            assert (pv[ok] < n).all()
+            acc[s * slice_agents:(s + 1) * slice_agents][ok] += window[pv[ok]]
     return acc[:n_agents].astype(np.float32)

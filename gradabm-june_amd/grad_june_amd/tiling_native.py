@@ -169,3 +169,64 @@ class EllBuilder:
                 raise ValueError(f"ELL table of {K} columns does not hold every owned agent's edges")
         se.ws = None
         return ell, K
+
+
+def split_primary_runs_native(agent_index, venue_index, n_agents: int, n_venues: int, slice_agents: int, device,
+                              min_share: float = TL.RUN_MIN_SHARE):
+    """``tiling.split_primary_runs`` on the device (gj_compile_runs_pick / _rest): returns (RunForm or None, {"agent",
+    "venue"}: the edges that stay in the tiled arrays, int64 tensors in COO order).  ``RunForm.vmin`` / windows are
+    device tensors; ``keep`` is not kept."""
+    n_own_slices = max(1, -(-int(n_agents) // int(slice_agents)))
+    if int(n_agents) <= 0:
+        return None, None
+    se = _Session(agent_index, venue_index, n_venues, n_agents, max(int(n_agents), 1), n_own_slices, slice_agents,
+                  TL.SV_MAX, TL.EB_TARGET, None, device)
+    # (n_ext of this session = the owned agents: halo agents' edges are never primary, the range check of their
+    # indices is gj_compile_blocks' on the remaining edges)
+    se.set.n_ext_agents = n_own_slices * int(slice_agents)
+    dev, E = se.dev, se.agent.numel()
+    if E == 0:
+        return None, None
+    i32 = lambda n: torch.empty(max(int(n), 1), dtype=torch.int32, device=dev)
+    vmin, pick, win_lo, win_n = i32(n_agents), i32(n_agents), i32(n_own_slices), i32(n_own_slices)
+    keep = torch.empty(E, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        st = N.current_stream()
+        N.check(se.lib.gj_compile_runs_pick(C.byref(se.set), N.ptr(vmin), N.ptr(pick), N.ptr(keep), N.ptr(win_lo),
+                                            N.ptr(win_n), N.ptr(se.counts), st), "gj_compile_runs_pick")
+        c = se.counts.cpu().numpy()
+        n_primary, owned = int(c[N.GJ_CC_RUN_PRIMARY]), int(c[N.GJ_CC_OWNED_EDGES])
+        if c[N.GJ_CC_RUN_UNSORTED] or n_primary == 0 or int(c[N.GJ_CC_RUN_WINDOW]) > TL.RUN_MAX_WINDOW \
+                or n_primary < min_share * owned:
+            return None, None
+        rest_a = torch.empty(max(E - n_primary, 1), dtype=torch.int64, device=dev)
+        rest_v = torch.empty(max(E - n_primary, 1), dtype=torch.int64, device=dev)
+        ws = se.workspace()
+        N.check(se.lib.gj_compile_runs_rest(C.byref(se.set), N.ptr(keep), N.ptr(rest_a), N.ptr(rest_v), N.ptr(ws),
+                                            ws.numel(), N.ptr(se.counts), st), "gj_compile_runs_rest")
+        torch.cuda.current_stream().synchronize()
+    rf = TL.RunForm(n_primary=n_primary, keep=None, vmin=vmin[:n_agents], win_lo=win_lo, win_n=win_n,
+                    max_window=int(c[N.GJ_CC_RUN_WINDOW]))
+    return rf, {"agent": rest_a[: E - n_primary], "venue": rest_v[: E - n_primary]}
+
+
+def finish_run_form_native(rf, blk_v0, n_agents: int, slice_agents: int, device):
+    """``tiling.finish_run_form`` on the device (gj_compile_runs_index)."""
+    dev = torch.device(device)
+    n_own_slices = max(1, -(-int(n_agents) // int(slice_agents)))
+    rows = n_own_slices * int(slice_agents)
+    blk_v0 = blk_v0.to(device=dev, dtype=torch.int32).contiguous()
+    J = blk_v0.numel() - 1
+    lib = N.load()
+    cset = N.CompileSet(None, None, None, 0, int(n_agents), rows, 0, n_own_slices, int(slice_agents), TL.SV_MAX,
+                        TL.EB_TARGET, 0)
+    pv_blk = torch.empty(rows, dtype=torch.int16, device=dev)
+    pv_win = torch.empty(rows, dtype=torch.int16, device=dev)
+    blk_r0 = torch.empty(J + 1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        N.check(lib.gj_compile_runs_index(C.byref(cset), N.ptr(rf.vmin), N.ptr(blk_v0), J, rows, N.ptr(rf.win_lo),
+                                          N.ptr(pv_blk), N.ptr(pv_win), N.ptr(blk_r0), N.current_stream()),
+                "gj_compile_runs_index")
+        torch.cuda.current_stream().synchronize()
+    rf.pv_blk, rf.pv_win, rf.blk_r0 = pv_blk, pv_win, blk_r0
+    return rf

@@ -143,6 +143,21 @@ typedef struct gj_tiled_set {
                                 ids (whole-set numbering) of each OWNED agent's edges in COO order, columns in pairs (plane p holds an agent's edges 2p and
                                 2p + 1), 0xFFFF = none.  Replaces a_la / val / chunk_desc reads of phase D and
                                 all of phase C for this set: 2 * ell_k bytes per agent                    */
+  /* "Run form" of ONE edge per owned agent (NULL pointers: none).  When the owned agents are ordered by their smallest
+   * venue of this set (the household-major order of graph.locality_order; agents without an edge last), the agents
+   * whose smallest venue is v are consecutive, and that "primary" edge (a, vmin(a)) needs no entry in the arrays
+   * above: phase B reads the transmissions of block j's agents [run_blk_r0[j], run_blk_r0[j+1]) straight from the
+   * per-agent array next to run_pv_blk (phase A has nothing to scatter for them); phase D stages the window
+   * [run_win_lo[s], run_win_lo[s] + run_win_n[s]) of the venues' cum through LDS and reads it through run_pv_win
+   * (phase C has nothing to write for them).  The set's other edges stay in the tiled arrays.                     */
+  const uint16_t* run_pv_blk; /* device [owned slices * slice_agents] vmin(a) - blk_v0[block of vmin(a)], 0xFFFF = none */
+  const uint16_t* run_pv_win; /* device [owned slices * slice_agents] vmin(a) - run_win_lo[slice of a], 0xFFFF = none    */
+  const int32_t* run_blk_r0;  /* device [J+1]  first agent whose primary venue lies in block j (non-decreasing)        */
+  const int32_t* run_win_lo;  /* device [owned slices] first venue of the slice's window                              */
+  const int32_t* run_win_n;   /* device [owned slices] venues in the window (0: no primary edge in the slice)         */
+  int32_t run_max_window;     /* max run_win_n (sizes the LDS table of phase D), <= 32768                             */
+  int32_t run_tiled_edges;    /* with a run form: the edges the tiled arrays above hold (the set's n_edges minus the
+                                 primary ones; may be 0 - every person lives in exactly one household)               */
 } gj_tiled_set;
 
 typedef struct gj_tiled {
@@ -369,6 +384,20 @@ int gj_adjoint_sample(int64_t n, const float* susceptibility0, const float* infe
 int gj_adjoint_transmission(int64_t n, const gj_agent_state* state0, float now, const float* trans_bar,
                             const float* g_inf, float* grad_inf_out, float* grad_time_inout, void* stream);
 
+/* d loss / d log_beta of the networks on ONE edge set, from the forward's and the transposed passes' per-venue sums:
+ *   col0 + k :  ln(10) * scale * sum_v [p_contact[v] > 0]  cum_fwd[v][k] * cum_bwd[v][k] / (beta[k] * p_contact[v]) * weight[v]
+ * (reference: autograd through base.py:36-42,78-83; `weights` - fp64 [n_venues] or NULL = 1 - is a rank's share of
+ * each venue in a multi-GPU run).  Two launches, deterministic: gj_adjoint_beta_partial ADDS every workgroup's fp64
+ * partial sums into partial[GJ_ADJ_BETA_BLOCKS][GJ_MAX_NETS] (zeroed by the caller before a step's first set; a twin
+ * network on the second half of a split set adds into its network's column), gj_adjoint_beta_finish sums the rows in
+ * order into out[0 .. n_cols) and applies ln(10) * *scale (a device float: the power of two the cotangent was
+ * normalised by).  beta[k] == 0 contributes 0.                                                                   */
+#define GJ_ADJ_BETA_BLOCKS 256
+int gj_adjoint_beta_partial(int64_t n_venues, int32_t stride, int32_t nk, const float* cum_fwd, const float* cum_bwd,
+                            const float* v_pcontact, const double* weights, const float* beta /* host [nk] */,
+                            const int32_t* cols /* host [nk] */, double* partial, void* stream);
+int gj_adjoint_beta_finish(int32_t n_cols, const double* partial, const float* scale, double* out, void* stream);
+
 /* gj_adjoint_symptoms: adjoint of gj_symptoms_update - what makes a loss on the symptom stages (the
  * deaths series, grad_june/runner.py:198-215; test/unit/test_runner.py:82-90 and
  * test_symptoms.py:208-231 assert the gradient exists) differentiable w.r.t. log_beta.  Inputs: the
@@ -427,7 +456,7 @@ int gj_unpack_f32(int64_t n, const int32_t* index, const float* in, float* dst, 
  * counts[GJ_CC_ERROR] != 0 after a stage: 1 agent index out of range, 2 venue index out of range, 3 more venue
  * blocks than blk_cap, 4 wide descriptor field overflow, 5 an owned agent has more edges than ell_k columns (the
  * entry is skipped, nothing is written outside the table).                                                        */
-#define GJ_COMPILE_COUNTS 8
+#define GJ_COMPILE_COUNTS 16
 #define GJ_CC_BLOCKS 0       /* J: venue blocks                                                        */
 #define GJ_CC_SLOTS 1        /* length of the block-major arrays (every block padded to 8 slots)       */
 #define GJ_CC_CHUNKS 2       /* 64-edge chunks of the slice-major order                                */
@@ -435,6 +464,9 @@ int gj_unpack_f32(int64_t n, const int32_t* index, const float* in, float* dst, 
 #define GJ_CC_OWNED_EDGES 4  /* edges whose agent is owned (< n_agents)                                */
 #define GJ_CC_MAX_DEGREE 5   /* largest number of edges of one owned agent                             */
 #define GJ_CC_ERROR 7
+#define GJ_CC_RUN_PRIMARY 8   /* gj_compile_runs_pick: owned agents with an edge = primary edges               */
+#define GJ_CC_RUN_UNSORTED 9  /* != 0: the owned agents are NOT ordered by their smallest venue - no run form  */
+#define GJ_CC_RUN_WINDOW 10   /* venues in the widest slice window                                            */
 
 typedef struct gj_compile_set {
   const int64_t* agent;        /* [n_edges] edge_index[0]: agent ids, owned then halo, < n_ext_agents            */
@@ -478,6 +510,23 @@ int gj_compile_ell_degrees(const gj_compile_set* set, int32_t* degree, int32_t* 
  * when an agent does not fit; `counts` may be NULL).                                                               */
 int gj_compile_ell(const gj_compile_set* set, int32_t ell_k, int64_t rows, const int32_t* degree, uint16_t* ell,
                    void* workspace, int64_t workspace_bytes, int32_t* counts, void* stream);
+
+/* ---- run form of the set that orders the agents (gj_tiled_set.run_*; specification: tiling.split_primary_runs /
+ * finish_run_form).  Three steps around the compile of the set's remaining edges:
+ *   gj_compile_runs_pick   vmin[a] (int32 [n_agents], 0x7FFFFFFF = no edge), pick[a] (COO position of the agent's
+ *                          primary edge: the first edge to its smallest venue), keep[e] (uint8 [E]: 1 = the edge stays
+ *                          in the tiled arrays), the slices' windows (int32 [owned slices] each) and
+ *                          counts[RUN_PRIMARY / RUN_UNSORTED / RUN_WINDOW / OWNED_EDGES] - the caller decides;
+ *   gj_compile_runs_rest   the kept edges, compacted in COO order (int64 [E - primary] each) - the input of
+ *                          gj_compile_blocks / _tiles for this set;
+ *   gj_compile_runs_index  once the venue blocks are known: run_pv_blk, run_pv_win (uint16 [rows]), run_blk_r0.     */
+int gj_compile_runs_pick(const gj_compile_set* set, int32_t* vmin, int32_t* pick, uint8_t* keep, int32_t* win_lo,
+                         int32_t* win_n, int32_t* counts, void* stream);
+int gj_compile_runs_rest(const gj_compile_set* set, const uint8_t* keep, int64_t* agent_out, int64_t* venue_out,
+                         void* workspace, int64_t workspace_bytes, int32_t* counts, void* stream);
+int gj_compile_runs_index(const gj_compile_set* set, const int32_t* vmin, const int32_t* blk_v0, int32_t n_blocks,
+                          int64_t rows, const int32_t* win_lo, uint16_t* pv_blk, uint16_t* pv_win, int32_t* blk_r0,
+                          void* stream);
 
 /* Average device time of the last-timed dominant kernel is measured by the caller with
  * hipEvents; these two helpers let a ctypes caller do that on the stream it launches on

@@ -180,3 +180,89 @@ def test_local_venue_index_never_collides_with_the_pad_marker():
     t = build_tiled("x", np.arange(64) % 8, np.arange(64) * 1000, 70000, np.ones(70000, np.float32), 1, 64,
                        sv_max=65535, eb_target=1 << 30)
     assert int(np.diff(t.blk_v0).max()) <= 65535 and int(t.e_lv[t.e_lv != 0xFFFF].max()) <= 65534
+
+
+def _household_major(A, V, mem, rng):
+    """A set in the household-major order: every agent gets `mem` memberships (mem = 1: the reference's worlds, one
+    household per person), agents renumbered by their smallest venue; unsorted COO."""
+    agent = np.repeat(np.arange(A), mem) if isinstance(mem, int) else np.repeat(np.arange(A), mem)
+    venue = rng.integers(0, V, len(agent))
+    first = np.full(A, np.iinfo(np.int64).max)
+    np.minimum.at(first, agent, venue)
+    order = np.argsort(first, kind="stable")
+    new_of = np.empty(A, dtype=np.int64)
+    new_of[order] = np.arange(A)
+    perm = rng.permutation(len(agent))
+    return new_of[agent][perm], venue[perm]
+
+
+@pytest.mark.parametrize("A,V,mem,sa,halo", [(5000, 1800, 2, 512, 0), (5000, 2500, 1, 512, 0), (3000, 900, 3, 256, 700),
+                                             (700, 5000, 1, 64, 0)])
+def test_run_form_of_the_set_that_orders_the_agents(A, V, mem, sa, halo):
+    """tiling.split_primary_runs + finish_run_form: one edge per owned agent leaves the tiled arrays and both passes
+    (emulated) still give the sums of the whole set - also when EVERY edge is primary (mem = 1: the tiled arrays are
+    empty) and with halo agents, whose edges all stay tiled."""
+    from grad_june_amd import tiling as TL
+
+    rng = np.random.default_rng(A + V + mem)
+    agent, venue = _household_major(A, V, mem, rng)
+    n_own_slices = -(-A // sa)
+    if halo:        # halo agents sit behind the owned slices and attend random venues
+        ha = n_own_slices * sa + rng.integers(0, halo, 2 * halo)
+        agent, venue = np.concatenate([agent, ha]), np.concatenate([venue, rng.integers(0, V, 2 * halo)])
+        perm = rng.permutation(len(agent))
+        agent, venue = agent[perm], venue[perm]
+    n_ext = n_own_slices * sa + halo if halo else A
+    S = -(-n_ext // sa)
+    rf = TL.split_primary_runs(agent, venue, A, V, sa)
+    assert rf is not None and rf.n_primary == A and int((~rf.keep).sum()) == A
+    # the primary edge of an agent: the first COO edge to its smallest venue
+    for a in rng.integers(0, A, 50):
+        e = np.flatnonzero(agent == a)
+        assert venue[e].min() == rf.vmin[a]
+        assert not rf.keep[e[venue[e] == rf.vmin[a]][0]] and rf.keep[e].sum() == len(e) - 1
+    pc = rng.random(V).astype(np.float32)
+    t = build_tiled("hh", agent[rf.keep], venue[rf.keep], V, pc, S, sa, sv_max=300, eb_target=2000)
+    t.runs = TL.finish_run_form(rf, t.blk_v0, A, sa)
+    assert t.n_edges == len(agent) - A and (t.n_edges == 0) == (mem == 1 and not halo)
+    assert t.runs.blk_r0[0] == 0 and t.runs.blk_r0[-1] == A and (np.diff(t.runs.blk_r0) >= 0).all()
+    x = rng.random(S * sa).astype(np.float32)
+    x[A:n_own_slices * sa] = 0
+    _, cum = emulate_pass1(t, x, sa, 0.7)
+    ref = np.float32(0.7) * pc * np.bincount(venue, weights=x[agent].astype(np.float64), minlength=V).astype(np.float32)
+    assert np.allclose(cum, ref, rtol=1e-5, atol=1e-7)
+    acc = emulate_pass2(t, cum, A, sa)
+    own = agent < A
+    ref2 = np.bincount(agent[own], weights=cum[venue[own]].astype(np.float64), minlength=A)
+    assert np.allclose(acc, ref2, rtol=1e-5, atol=1e-7)
+    # a world that is NOT in that order has no run form; neither has one whose windows would not fit
+    shuffled = rng.permutation(A)[agent[agent < A]]
+    assert TL.split_primary_runs(shuffled, venue[agent < A], A, V, sa) is None
+    if V >= 5000:
+        assert t.runs.max_window <= TL.RUN_MAX_WINDOW
+        assert TL.split_primary_runs(agent, venue * 100, A, V * 100, sa) is None
+
+
+def test_compile_plan_run_form_choice_and_roundtrip(tmp_path):
+    from grad_june_amd.plan import compile_plan, load_plan, save_plan
+    from grad_june_amd.synthetic import make_world, reorder_agents
+
+    w = reorder_agents(make_world("c3", n_agents=30_000, seed=4), by="household")
+    # at this size every set is small enough for the direct form: the run form must be asked for
+    host = compile_plan(w["n_agents"], w["edge_sets"], age=w["age"], sex=w["sex"], layout="tiled", runs=("household",))
+    by = {s.name: s.tiled for s in host.sets}
+    assert by["household"].runs is not None and by["household"].ell_k == 0
+    assert by["household"].runs.n_primary == w["n_agents"]
+    assert by["household"].n_edges == len(w["edge_sets"]["household"]["agent"]) - w["n_agents"]
+    assert all(by[s].runs is None for s in by if s != "household")
+    with pytest.raises(ValueError, match="ordered by their smallest venue"):
+        compile_plan(w["n_agents"], w["edge_sets"], age=w["age"], sex=w["sex"], layout="tiled", runs=("company",))
+    none = compile_plan(w["n_agents"], w["edge_sets"], age=w["age"], sex=w["sex"], layout="tiled", runs=False)
+    assert all(s.tiled.runs is None for s in none.sets)
+    path = tmp_path / "plan.npz"
+    save_plan(host, path)
+    back = load_plan(path)
+    rb = {s.name: s.tiled for s in back.sets}["household"]
+    for k in ("pv_blk", "pv_win", "blk_r0", "win_lo", "win_n"):
+        assert np.array_equal(np.asarray(getattr(rb.runs, k)), np.asarray(getattr(by["household"].runs, k))), k
+    assert rb.n_edges == by["household"].n_edges and rb.runs.max_window == by["household"].runs.max_window
