@@ -419,6 +419,24 @@ struct TileBArgs {
   int32_t _pad;
 };
 
+// Phase B, a group of 8 slots that holds a value which cannot be summed (rare; kept out of line so that its registers
+// do not count against the launch's two workgroups per CU).
+__device__ __noinline__ void venue_group_slow(fx_t* sums, uint32_t* vflags, int base_k, int l0, int l1, int l2, int l3,
+                                              int l4, int l5, int l6, int l7, float x0, float x1, float x2, float x3,
+                                              float x4, float x5, float x6, float x7) {
+  const int lv[8] = {l0, l1, l2, l3, l4, l5, l6, l7};
+  const float x[8] = {x0, x1, x2, x3, x4, x5, x6, x7};
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    if (lv[q] == 0xFFFF) continue;
+    if ((__float_as_uint(x[q]) & 0x7FFFFFFFu) <= 0x46800000u) {      // |x| <= 16384 = fx_max<kFxVenue>()
+      atomicAdd(&sums[base_k + lv[q]], to_fx<kFxVenue>(x[q]));
+    } else {
+      atomicOr(&vflags[(base_k + lv[q]) >> 5], 1u << ((base_k + lv[q]) & 31));
+    }
+  }
+}
+
 struct Slots8 {           // 8 consecutive block-major slots: 16 bytes of local venue indices
   uint32_t w[4];
   __device__ __forceinline__ int lv(int q) const { return (w[q >> 1] >> ((q & 1) * 16)) & 0xFFFF; }
@@ -446,7 +464,12 @@ struct VenueStamp {
 // workgroup's slot idles for a few us until its successor's 16 waves are up.  Persistent workgroups that work through
 // several items each closed those gaps and took as long: with every slot busy the items stretch, the launch is bound
 // by the memory system at ~4.8 TB/s of measured traffic, not by the slots.)
-__global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B) {   // 8 waves per SIMD: two workgroups per CU (<= 64 VGPRs)
+#ifndef GJ_VENUE_WAVES_PER_SIMD
+#define GJ_VENUE_WAVES_PER_SIMD 4      // 72 VGPRs, no scratch.  (8 = two workgroups per CU needs <= 64 VGPRs and spills 12 dwords
+                                       // with the exact run merging: measured 207 vs 204 us - the second workgroup, worth 25 % in
+                                       // round 1, no longer pays now that the direct form took half of phase C away)
+#endif
+__global__ __launch_bounds__(kTileThreads, GJ_VENUE_WAVES_PER_SIMD) void k_tile_venues(const TileBArgs B) {
   extern __shared__ __align__(16) float lds_s[];
 #ifdef GJ_DIAG_STAMPS
   VenueStamp gj_stamp;
@@ -490,7 +513,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
     // does not depend on where the block boundaries and the padding put its runs relative to the 8-slot groups - the
     // tile geometry (eb_target, sv_max, slices) cannot change a single bit of `cum`.  (Round 2 merged the runs in fp32
     // and converted the run totals; the launch is bound by the memory system, the extra integer adds are free.)
-#ifdef GJ_DIAG_FLOAT_RUNS      // round 2's form, kept for A/B timing only (tools/ab.py): runs merged in fp32
+#if defined(GJ_DIAG_FLOAT_RUNS)      // round 2's form, kept for A/B timing only (tools/ab.py): runs merged in fp32
     auto run_sums = [&](const int (&lv)[8], const float (&x)[8], int base_k) {
       float s8 = x[0];
 #pragma unroll
@@ -501,21 +524,46 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_venues(const TileBArgs B)
         if (q < 7) s8 = last ? x[q + 1] : s8 + x[q + 1];
       }
     };
-#else
+#elif defined(GJ_DIAG_SLOT_ADDS)     // A/B: no run merging at all - every slot adds its own value to its venue
     auto run_sums = [&](const int (&lv)[8], const float (&x)[8], int base_k) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const bool valid = lv[q] != 0xFFFF;
+        const bool ok = fabsf(x[q]) <= fx_max<kFxVenue>();
+        atomicAdd(&sums[valid ? base_k + lv[q] : dummy], to_fx<kFxVenue>((ok && valid) ? x[q] : 0.0f));
+        if (__builtin_expect(!ok && valid, 0)) atomicOr(&vflags[(base_k + lv[q]) >> 5], 1u << ((base_k + lv[q]) & 31));
+      }
+    };
+#else
+    // Every slot's value goes to fixed point FIRST and a run of one venue is merged as integers: exact, so a venue's sum
+    // does not depend on where the block boundaries and the padding put its runs relative to the 8-slot groups - the
+    // tile geometry (eb_target, sv_max, slices) and the partition cannot change a single bit of `cum`.  (Round 2 merged
+    // the runs in fp32 and converted the run totals: GJ_DIAG_FLOAT_RUNS, 8-18 us faster on C3 from box to box and not
+    // exact.  Measured and ruled out as the cause of that gap, tools/ab.py: instruction count - this form has 12 per slot
+    // against 19 -, zero / non-zero scratch adds, LDS operations in flight, registers reused behind an LDS operation.)
+    // The range check is made ONCE per group on the bit patterns - as unsigned integers |x| <= 16384, NaN and the
+    // infinities order like their patterns - and a slot that is not the end of a run adds whatever the running sum is
+    // to the lane's scratch sum instead of selecting a zero.
+    auto run_sums = [&](const int (&lv)[8], const float (&x)[8], int base_k) {
+      constexpr uint32_t kLimit = 0x46800000u;          // bit pattern of fx_max<kFxVenue>() = 16384.0f
+      static_assert(kFxVenue == 36, "kLimit is the pattern of 2^(50 - kFxVenue)");
+      uint32_t m = 0u;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) m = max(m, __float_as_uint(x[q]) & 0x7FFFFFFFu);
+      if (__builtin_expect(m > kLimit, 0)) {            // a NaN / infinity / out-of-range term: its venue reads back NaN
+        venue_group_slow(sums, vflags, base_k, lv[0], lv[1], lv[2], lv[3], lv[4], lv[5], lv[6], lv[7], x[0], x[1], x[2], x[3],
+                         x[4], x[5], x[6], x[7]);
+        return;
+      }
       fx_t s8 = 0;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const float xq = x[q];
-        const bool ok = fabsf(xq) <= fx_max<kFxVenue>();
-        const fx_t f = to_fx<kFxVenue>(ok ? xq : 0.0f);
+        const fx_t f = to_fx<kFxVenue>(x[q]);
         const bool first = (q == 0) || (lv[q] != lv[q - (q > 0)]);
         s8 = first ? f : s8 + f;
         const bool last = (q == 7) || (lv[q + (q < 7)] != lv[q]);
         const bool take = last && lv[q] != 0xFFFF;
-        atomicAdd(&sums[take ? base_k + lv[q] : dummy], take ? s8 : (fx_t)0);
-        // a NaN / infinity / out-of-range term: the venue reads back NaN
-        if (__builtin_expect(!ok && lv[q] != 0xFFFF, 0)) atomicOr(&vflags[(base_k + lv[q]) >> 5], 1u << ((base_k + lv[q]) & 31));
+        atomicAdd(&sums[take ? base_k + lv[q] : dummy], s8);
       }
     };
 #endif
