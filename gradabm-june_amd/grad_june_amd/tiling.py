@@ -28,8 +28,10 @@ from typing import Optional
 import numpy as np
 
 SA_MAX = 20160        # agents per slice: 64-bit fixed-point sums + one flag bit per agent in 160 KiB of LDS (phase D)
-SV_MAX = 8192         # venues per block: 64 KiB of 64-bit sums in phase B, so two blocks share a CU's LDS
-                      # (measured: phases B+C 0.27 -> 0.21 ms on C3 against 16384; local venue index is 16-bit)
+SV_MAX = 16384        # venues per block: 128 KiB of 64-bit sums in phase B, one block per CU.  (Rounds 1-2: 8192, so that
+                      # two blocks shared a CU's LDS - worth 25 % then; with the direct form of pass 2 and the exact run
+                      # merging the launch runs one workgroup per CU and larger blocks win: round 3, tools/ab.py on C3,
+                      # 8192 / 65536 edges per block 538 us per step, 16384 / 131072 528.  Local venue index is 16-bit.)
 EB_TARGET = 131072    # edges per block aimed for (work per workgroup of phases B/C)
 N_CU = 256
 PAD = 8               # block-major arrays: every block starts on a multiple of PAD slots
@@ -58,8 +60,8 @@ def choose_block_edges(n_slices: int, eb_max: int = EB_TARGET) -> int:
     slow down (chunks spanning several tiles), while small blocks give phases B/C more workgroups -
     what a small world (one rank's share of a strong-scaled run) needs to fill 256 CUs.  Measured on
     MI355X (gpurun_out sweeps, c3 preset): 1.25M agents 0.190 -> 0.131 ms/step with 32768 instead of
-    131072; 10M agents flat between 49152 and 131072."""
-    return int(min(eb_max, max(32768, 128 * n_slices)))
+    131072; 10M agents: 131072 (with blocks of up to 16384 venues) 2 % faster than 65536 in round 3."""
+    return int(min(eb_max, max(32768, 256 * n_slices)))
 
 
 def venue_blocks(degree: np.ndarray, sv_max: int = SV_MAX, eb_target: int = EB_TARGET) -> np.ndarray:
