@@ -67,6 +67,9 @@ def parse():
                     help="run form of the edge set that orders the agents (households under --reorder household): one "
                          "edge per agent read from the per-agent arrays instead of the tiled index arrays (auto) or "
                          "every edge in the tiled arrays (off)")
+    ap.add_argument("--presum", default="auto", choices=["auto", "off"],
+                    help="pass 1 of the sets in the direct form from their ELL rows and per-workgroup LDS tables (auto) or "
+                         "through phases A + B like the other sets (off)")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"], nargs="?", const="on",
                     help="N > 1: capture the production step (kernels + RCCL collectives) in a hipGraph after the warm-up "
                          "and replay it per timed step (13.5 us of host time per step instead of ~100).  auto (default): "
@@ -546,6 +549,8 @@ def main():
                 kw["direct"] = False
             if args.runs == "off":
                 kw["runs"] = False
+            if args.presum == "off":
+                kw["presum"] = False
             if args.sv_max:
                 kw["sv_max"] = args.sv_max
             if args.eb_target:
@@ -562,7 +567,7 @@ def main():
             extra = {"partitions_on_one_gpu": parts}
         else:
             set_edges = sum(len(v["agent"]) for v in world["edge_sets"].values())
-            tune = args.tune == "on" or (args.tune == "auto" and args.layout == "tiled" and not (set(kw) - {"device_compile", "direct", "runs"})
+            tune = args.tune == "on" or (args.tune == "auto" and args.layout == "tiled" and not (set(kw) - {"device_compile", "direct", "runs", "presum"})
                                          and set_edges <= 40_000_000)
             if tune:      # small worlds compile in seconds: measure the candidate tile geometries, keep the best
                 from grad_june_amd.benchrun import GEOMETRY_CANDIDATES, tune_geometry

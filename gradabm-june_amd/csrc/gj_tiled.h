@@ -96,7 +96,7 @@ struct TSetA {            // what phases A and D need of one set
   int32_t raw;            // 1: reads raw transmission / susceptibility weight (household)
   int32_t wide;           // chunk_desc holds two int4 per chunk (up to 6 tiles per chunk), see tiling.py
   int32_t direct;         // pass 2 of the set is taken by phase D's direct form (TDirect): no val / a_la reads there
-  int32_t _pad;
+  int32_t presum;         // pass 1 of the set is taken by k_tile_presum: phase A has nothing to scatter
 };
 
 struct TileAArgs {
@@ -369,14 +369,14 @@ __global__ __launch_bounds__(kTileThreads, GJ_SCATTER_WAVES_PER_SIMD) void k_til
     if (pass == 1 && !two_sources) break;
     bool any = false;
     for (int t = 0; t < A.n_sets; ++t)
-      if (A.sets[t].active && (!two_sources || A.sets[t].raw == pass)) any = true;
+      if (A.sets[t].active && !A.sets[t].presum && (!two_sources || A.sets[t].raw == pass)) any = true;
     if (!any) continue;
     if (pass == 1) __syncthreads();
     load_slice(lds_x, pass == 0 ? A.qtrans : A.trans, base, n_local, tid);
     __syncthreads();
     for (int t = 0; t < A.n_sets; ++t) {
       const TSetA& T = A.sets[t];
-      if (!T.active || (two_sources && T.raw != pass)) continue;
+      if (!T.active || T.presum || (two_sources && T.raw != pass)) continue;
       if (T.wide) {
         scatter_set<true>(T, lds_x, s, wave, lane);
       } else {
@@ -702,6 +702,157 @@ __global__ __launch_bounds__(kTileThreads, GJ_VENUE_WAVES_PER_SIMD) void k_tile_
       val4[2 * gu + 1] = make_float4(r[4], r[5], r[6], r[7]);
     }
   }
+}
+
+// ---- pass 1 in the "direct" form (sets with few venues whose edges all belong to owned agents) ----------------------
+// A set whose pass 2 is direct has, per owned agent, the venue ids of its edges (ELL rows) - which serve pass 1 as
+// well: a workgroup takes a contiguous range of agents, reads their transmissions (coalesced), rows and classes, and
+// adds every edge's term into an LDS table of 64-bit fixed-point sums, one per (venue, network) - exact, so the order
+// and the split over workgroups cannot change a bit - and writes its table to partial[workgroup][venue][network].
+// k_presum_reduce then adds the tables up and applies beta * p_contact.  Per edge: ~3 bytes of rows instead of the
+// ~12.3 of phases A + B (a_la + val write + descriptors, e_lv + val read), and the LDS atomics leave the venue launch.
+constexpr int GJ_MAX_PRESUM = 6;              // (= GJ_MAX_DIRECT: a set in this form is in the direct form of pass 2)
+constexpr int64_t kPresumBad = (int64_t)0x8000000000000000ll;      // a sum that holds a value which cannot be summed
+struct TPSet {
+  const uint16_t* ell;    // [planes][rows][2]
+  int64_t plane_stride;
+  fx_t* partial;          // [workgroups][V * stride]
+  int32_t planes, V, stride, nk;
+  int32_t group_venues;   // venues per LDS table
+  int32_t raw, leisure, _pad;
+  int32_t table[GJ_MAX_NETS_PER_SET];
+  int32_t age75[GJ_MAX_NETS_PER_SET];
+};
+struct TilePArgs {
+  TPSet sets[GJ_MAX_PRESUM];
+  int32_t n_sets;
+  int32_t agents_per_wg;  // multiple of 4
+  int64_t n_agents;
+  const float* trans;
+  const float* qtrans;
+  const uint8_t* cls;
+  const float* tables;
+  int32_t day_type, transpose;
+};
+
+constexpr int kPresumQuads = 4;     // quads of agents a lane keeps in flight
+
+__global__ __launch_bounds__(kTileThreads) void k_tile_presum(const TilePArgs P) {
+  extern __shared__ __align__(16) fx_t lds_p[];
+  const int tid = threadIdx.x;
+  const int64_t a_begin = (int64_t)blockIdx.x * P.agents_per_wg;
+  const int64_t a_end = min(P.n_agents, a_begin + P.agents_per_wg);
+  const int n_quads = (int)((max(a_end - a_begin, (int64_t)0) + 3) >> 2);
+  for (int t = 0; t < P.n_sets; ++t) {
+    const TPSet& T = P.sets[t];
+    const int nk = T.nk;
+    const float* x = T.raw ? P.trans : P.qtrans;
+    for (int v0 = 0; v0 < T.V; v0 += T.group_venues) {
+      const int nv = min(T.group_venues, T.V - v0);
+      const int n_sums = nv * nk;
+      const int dummy = n_sums + (tid & 63);             // a scratch sum per lane of a wave: what does not count adds 0 there
+      float* wtab = reinterpret_cast<float*>(lds_p + n_sums + 64);                  // [nk][200] weights of the transmitting side
+      uint32_t* flags = reinterpret_cast<uint32_t*>(wtab + (T.leisure ? nk * 200 : 0));
+      __syncthreads();                                   // the previous table has been written out
+      for (int i = tid; i < n_sums + 64; i += kTileThreads) lds_p[i] = 0;
+      for (int i = tid; i < (n_sums + 64 + 31) / 32; i += kTileThreads) flags[i] = 0u;
+      if (T.leisure) {
+        for (int i = tid; i < nk * 200; i += kTileThreads) {
+          const int k = i / 200, c = i % 200;
+          const float l = P.tables[(int64_t)T.table[k] * GJ_TABLE_SIZE + P.day_type * 200 + c];
+          const float lw = T.age75[k] ? l * (((c % 100) > 75) ? 1.0f : 0.0f) : l;
+          wtab[i] = P.transpose ? lw : l;
+        }
+      }
+      __syncthreads();
+      for (int plane = 0; plane < T.planes; ++plane) {
+        const uint16_t* ell = T.ell + plane * T.plane_stride + a_begin * 2;
+        for (int q0 = tid; q0 < n_quads; q0 += kPresumQuads * kTileThreads) {
+          uint4 rows[kPresumQuads];
+          float4 xs[kPresumQuads];
+          uint32_t cl[kPresumQuads];
+#pragma unroll
+          for (int u = 0; u < kPresumQuads; ++u) {       // clamped, unconditional: every load in flight together
+            const int q = min(q0 + u * kTileThreads, n_quads - 1);
+            const int64_t a0 = a_begin + 4 * (int64_t)q;
+            rows[u] = *reinterpret_cast<const uint4*>(ell + 8 * (int64_t)q);       // rows are padded to whole slices
+            if (a0 + 4 <= P.n_agents) {
+              xs[u] = *reinterpret_cast<const float4*>(x + a0);
+            } else {
+              xs[u] = make_float4(a0 < P.n_agents ? x[a0] : 0.0f, a0 + 1 < P.n_agents ? x[a0 + 1] : 0.0f,
+                                  a0 + 2 < P.n_agents ? x[a0 + 2] : 0.0f, 0.0f);
+            }
+            cl[u] = T.leisure ? *reinterpret_cast<const uint32_t*>(P.cls + a0) : 0u;
+          }
+#pragma unroll
+          for (int u = 0; u < kPresumQuads; ++u) {
+            const int q = q0 + u * kTileThreads;
+            if (q >= n_quads) continue;
+            const uint32_t w[4] = {rows[u].x, rows[u].y, rows[u].z, rows[u].w};
+            const float xv[4] = {xs[u].x, xs[u].y, xs[u].z, xs[u].w};
+            const int n_ok = (int)min((int64_t)4, a_end - (a_begin + 4 * (int64_t)q));   // agents of the quad in this range
+            // straight-line: every entry adds - what is empty, another group's or past the range adds 0 to the scratch sum
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+              for (int c = 0; c < 2; ++c) {
+                const int lv = (int)((w[j] >> (16 * c)) & 0xFFFF) - v0;
+                const bool in = ((unsigned)lv < (unsigned)nv) && (j < n_ok);
+                if (!T.leisure) {
+                  fx_add<kFxVenue>(lds_p, flags, in ? lv : dummy, in ? xv[j] : 0.0f);
+                } else {
+                  const int cj = (cl[u] >> (8 * j)) & 0xFF;
+                  for (int k = 0; k < nk; ++k)
+                    fx_add<kFxVenue>(lds_p, flags, in ? lv * nk + k : dummy, in ? wtab[k * 200 + cj] * xv[j] : 0.0f);
+                }
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+      fx_t* out = T.partial + (int64_t)blockIdx.x * T.V * T.stride;
+      for (int i = tid; i < n_sums; i += kTileThreads) {
+        const int lv = i / nk, k = i % nk;
+        const bool bad = (flags[i >> 5] >> (i & 31)) & 1u;
+        out[(int64_t)(v0 + lv) * T.stride + k] = bad ? (fx_t)kPresumBad : lds_p[i];
+      }
+    }
+  }
+}
+
+struct PReduceSet {
+  const fx_t* partial;
+  const float* v_pc;
+  float* cum;
+  int32_t V, stride, nk, first;      // first: index of the set's first (venue, network) entry in the launch
+  float beta[GJ_MAX_NETS_PER_SET];
+};
+struct PReduceArgs {
+  PReduceSet sets[GJ_MAX_PRESUM];
+  int32_t n_sets, n_wgs;
+  int32_t total;                     // entries of all sets
+  int32_t _pad;
+};
+
+// cum[v][k] = (beta_k * p_contact[v]) * sum over the workgroups' tables - the same expression as phase B's
+__global__ __launch_bounds__(kThreads) void k_presum_reduce(const PReduceArgs R) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R.total) return;
+  int t = 0;
+  while (t + 1 < R.n_sets && i >= R.sets[t + 1].first) ++t;
+  const PReduceSet& T = R.sets[t];
+  const int e = i - T.first;
+  const int v = e / T.nk, k = e % T.nk;
+  const int64_t idx = (int64_t)v * T.stride + k, table = (int64_t)T.V * T.stride;
+  fx_t s = 0;
+  bool bad = false;
+  for (int w = 0; w < R.n_wgs; ++w) {
+    const fx_t p = T.partial[w * table + idx];
+    bad |= p == (fx_t)kPresumBad;
+    s += p;
+  }
+  T.cum[idx] = (T.beta[k] * T.v_pc[v]) * (bad ? __builtin_nanf("") : from_fx<kFxVenue>(s));
 }
 
 // ---- phase D: per slice, accumulate the edges' values per agent in LDS; epilogue a7-a9 -----------

@@ -1045,6 +1045,7 @@ static int check_tiled(const gj_plan* plan) {
           S.run_tiled_edges > plan->sets[s].n_edges || S.ell_k)
         return GJ_E_PLAN;
     }
+    if (S.presum && (!S.ell_k || T->presum_wgs < 1 || T->presum_wgs > 4096)) return GJ_E_PLAN;
     const int64_t held = run ? (int64_t)S.run_tiled_edges : plan->sets[s].n_edges;
     if (held > 0 && (!S.e_lv || !S.a_la || !S.val || !S.chunk_desc)) return GJ_E_NULL;
     if (S.max_block_venues < 1 || S.max_block_venues > 65536) return GJ_E_PLAN;
@@ -1064,6 +1065,13 @@ static int check_tiled(const gj_plan* plan) {
 static inline int64_t tiled_edges(const gj_plan* plan, int s) {
   const gj_tiled_set& S = plan->tiled->sets[s];
   return S.run_pv_blk ? (int64_t)S.run_tiled_edges : plan->sets[s].n_edges;
+}
+
+// pass 1 of this set runs in the direct form (k_tile_presum + k_presum_reduce) instead of phases A + B
+static inline bool uses_presum(const gj_plan* plan, int s) {
+  const gj_tiled* T = plan->tiled;
+  return T->presum_wgs > 0 && T->sets[s].presum != nullptr && T->sets[s].ell_k != 0 && T->sets[s].n_blocks > 0 &&
+         plan->sets[s].n_edges > 0;
 }
 
 template <typename K>
@@ -1091,6 +1099,7 @@ static void fill_set_a(const gj_plan* plan, const gj_step_params* p, const Group
     sets[s].val = S.val;
     sets[s].J = S.n_blocks;
     sets[s].active = (S.n_blocks > 0 && tiled_edges(plan, s) > 0) ? G.nk[g] : 0;
+    sets[s].presum = uses_presum(plan, s);
     sets[s].raw = p->nets[G.first[g]].mask_kind == GJ_MASK_RAW;
     sets[s].wide = S.desc_wide != 0;
     sets[s].direct = S.ell_k != 0;
@@ -1101,6 +1110,114 @@ static void fill_set_a(const gj_plan* plan, const gj_step_params* p, const Group
 static size_t slice_lds(const gj_tiled* T, size_t elem) { return (size_t)T->slice_agents * elem; }
 // phase D: 64-bit sums + one "not summable" bit per agent
 static size_t agents_lds(const gj_tiled* T) { return (size_t)T->slice_agents * sizeof(fx_t) + (size_t)T->slice_agents / 8; }
+
+// pass 1 of the sets in its direct form: LDS tables of fixed-point sums per workgroup (k_tile_presum)
+static int presum_fill(const gj_plan* plan, const gj_step_params* p, const Groups& G, int g, TPSet* X) {
+  const gj_tiled* T = plan->tiled;
+  const int s = G.set[g];
+  const gj_tiled_set& S = T->sets[s];
+  const gj_edge_set& E = plan->sets[s];
+  const int64_t owned_slices = (plan->n_agents + T->slice_agents - 1) / T->slice_agents;
+  X->ell = S.ell;
+  X->plane_stride = owned_slices * (int64_t)T->slice_agents * 2;
+  X->partial = reinterpret_cast<fx_t*>(S.presum);
+  X->planes = S.ell_k / 2;
+  X->V = (int32_t)E.n_venues;
+  X->stride = E.cum_stride;
+  X->nk = G.nk[g];
+  X->raw = p->nets[G.first[g]].mask_kind == GJ_MASK_RAW;
+  X->leisure = 0;
+  X->_pad = 0;
+  for (int k = 0; k < GJ_MAX_NETS_PER_SET; ++k) X->table[k] = X->age75[k] = 0;
+  for (int k = 0; k < G.nk[g]; ++k) {
+    const gj_network& N = p->nets[G.first[g] + k];
+    X->table[k] = N.mask_kind >= GJ_MASK_QL ? N.table : -1;
+    X->age75[k] = N.mask_kind == GJ_MASK_QL_AGE75;
+    if (N.mask_kind >= GJ_MASK_QL) X->leisure = 1;
+  }
+  if (X->leisure) {
+    if (!plan->agent_class || (uintptr_t)plan->agent_class % 4 != 0) return GJ_E_PLAN;
+    for (int k = 0; k < G.nk[g]; ++k)
+      if (X->table[k] < 0) return GJ_E_PLAN;
+  } else if (G.nk[g] != 1) {
+    return GJ_E_PLAN;
+  }
+  return GJ_OK;
+}
+
+static int tiled_presum(const gj_plan* plan, const gj_agent_state* st, const gj_step_params* p, const Groups& G,
+                        hipStream_t stream) {
+  const gj_tiled* T = plan->tiled;
+  TilePArgs P;
+  P.n_sets = 0;
+  for (int g = 0; g < G.n; ++g) {
+    if (!uses_presum(plan, G.set[g])) continue;
+    if (P.n_sets == GJ_MAX_PRESUM) return GJ_E_PLAN;
+    const int rc = presum_fill(plan, p, G, g, &P.sets[P.n_sets++]);
+    if (rc) return rc;
+  }
+  if (P.n_sets == 0 || plan->n_agents == 0) return GJ_OK;
+  // the LDS table of a set: (venues of a group x networks + 64 scratch) 8-byte sums, leisure weights, one flag bit per sum
+  const int64_t budget = 160 * 1024;
+  size_t lds = 0;
+  for (int t = 0; t < P.n_sets; ++t) {
+    TPSet& X = P.sets[t];
+    const int64_t fixed = 64 * 8 + (X.leisure ? (int64_t)X.nk * 200 * 4 : 0) + 64;
+    int64_t per_venue = (int64_t)X.nk * 8;                  // + its flag bits: 1/8 byte per sum, counted below
+    int64_t gv = (budget - fixed) * 8 / (per_venue * 8 + X.nk);
+    if (T->direct_table_floats > 0 && gv > T->direct_table_floats / X.nk) gv = T->direct_table_floats / X.nk;   // tests: several groups
+    if (gv > X.V) gv = X.V;
+    if (gv < 1) gv = 1;
+    X.group_venues = (int32_t)gv;
+    const size_t need = (size_t)(gv * X.nk + 64) * 8 + (X.leisure ? (size_t)X.nk * 200 * 4 : 0) + ((size_t)(gv * X.nk + 64 + 31) / 32) * 4;
+    if (need > lds) lds = need;
+  }
+  int64_t apw = (plan->n_agents + T->presum_wgs - 1) / T->presum_wgs;
+  apw = (apw + 63) / 64 * 64;
+  P.agents_per_wg = (int32_t)apw;
+  P.n_agents = plan->n_agents;
+  P.trans = st->transmission;
+  P.qtrans = p->has_quarantine ? st->q_transmission : st->transmission;
+  if ((uintptr_t)P.trans % 16 != 0 || (uintptr_t)P.qtrans % 16 != 0) return GJ_E_PLAN;
+  P.cls = plan->agent_class;
+  P.tables = plan->tables;
+  P.day_type = p->day_type;
+  P.transpose = p->transpose;
+  int rc = allow_lds(k_tile_presum, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_tile_presum, dim3((unsigned)T->presum_wgs), dim3(kTileThreads), lds, stream, P);
+  return launch_status();
+}
+
+static int tiled_presum_reduce(const gj_plan* plan, const gj_step_params* p, const Groups& G, hipStream_t stream) {
+  const gj_tiled* T = plan->tiled;
+  PReduceArgs R;
+  R.n_sets = 0;
+  R.n_wgs = T->presum_wgs;
+  R._pad = 0;
+  int64_t total = 0;
+  for (int g = 0; g < G.n; ++g) {
+    const int s = G.set[g];
+    if (!uses_presum(plan, s)) continue;
+    if (R.n_sets == GJ_MAX_PRESUM) return GJ_E_PLAN;
+    PReduceSet& X = R.sets[R.n_sets++];
+    const gj_edge_set& E = plan->sets[s];
+    X.partial = reinterpret_cast<const fx_t*>(T->sets[s].presum);
+    X.v_pc = E.v_pcontact;
+    X.cum = E.cum;
+    X.V = (int32_t)E.n_venues;
+    X.stride = E.cum_stride;
+    X.nk = G.nk[g];
+    X.first = (int32_t)total;
+    for (int k = 0; k < GJ_MAX_NETS_PER_SET; ++k) X.beta[k] = k < G.nk[g] ? p->nets[G.first[g] + k].beta : 0.0f;
+    total += (int64_t)X.V * X.nk;
+  }
+  if (R.n_sets == 0 || total == 0) return GJ_OK;
+  if (total > INT32_MAX) return GJ_E_RANGE;
+  R.total = (int32_t)total;
+  hipLaunchKernelGGL(k_presum_reduce, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, R);
+  return launch_status();
+}
 
 static int tiled_scatter(const gj_plan* plan, const gj_agent_state* st, const gj_step_params* p, const Groups& G,
                          hipStream_t stream) {
@@ -1117,13 +1234,16 @@ static int tiled_scatter(const gj_plan* plan, const gj_agent_state* st, const gj
   int rc = allow_lds(k_tile_scatter, lds);
   if (rc) return rc;
   hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)T->n_slices), dim3(kTileThreads), lds, stream, A);
-  return launch_status();
+  rc = launch_status();
+  if (rc) return rc;
+  return tiled_presum(plan, st, p, G, stream);
 }
 
 static int tiled_venues(const gj_plan* plan, const gj_agent_state* st, const gj_step_params* p, const Groups& G, int mode,
                         hipStream_t stream) {
   const gj_tiled* T = plan->tiled;
-  if (T->n_work == 0 || G.n == 0) return GJ_OK;
+  if (G.n == 0) return GJ_OK;
+  if (T->n_work == 0) return mode == 2 ? GJ_OK : tiled_presum_reduce(plan, p, G, stream);
   TileBArgs B;
   for (int s = 0; s < GJ_MAX_SETS; ++s) B.sets[s] = TSetB{};
   size_t lds = 16;
@@ -1141,6 +1261,7 @@ static int tiled_venues(const gj_plan* plan, const gj_agent_state* st, const gj_
     X.cum = E.cum;
     X.stride = E.cum_stride;
     X.nk = S.n_blocks > 0 ? G.nk[g] : 0;
+    if (uses_presum(plan, s)) X.nk = 0;          // pass 1 of the set is k_tile_presum's, pass 2 phase D's: nothing here
     X.direct = S.ell_k != 0;
     X.leisure = 0;
     for (int k = 0; k < G.nk[g]; ++k) {
@@ -1184,7 +1305,9 @@ static int tiled_venues(const gj_plan* plan, const gj_agent_state* st, const gj_
   int rc = allow_lds(k_tile_venues, lds);
   if (rc) return rc;
   hipLaunchKernelGGL(k_tile_venues, dim3((unsigned)T->n_work), dim3(kTileThreads), lds, stream, B);
-  return launch_status();
+  rc = launch_status();
+  if (rc || mode == 2) return rc;
+  return tiled_presum_reduce(plan, p, G, stream);
 }
 
 static int tiled_agents(const gj_plan* plan, const gj_agent_state* st, const gj_step_params* p, const Groups& G,

@@ -66,6 +66,7 @@ class TiledSet(C.Structure):
         ("run_win_n", _vp),
         ("run_max_window", C.c_int32),
         ("run_tiled_edges", C.c_int32),
+        ("presum", _vp),
     ]
 
 
@@ -77,6 +78,8 @@ class Tiled(C.Structure):
         ("n_work", C.c_int32),
         ("work", _vp),
         ("agent_scratch", _vp),
+        ("presum_wgs", C.c_int32),
+        ("_pad_presum", C.c_int32),
         ("sets", TiledSet * GJ_MAX_SETS),
     ]
 

@@ -216,8 +216,8 @@ def save_plan(plan: HostPlan, path) -> None:
                     a = _host(getattr(t.runs, k))
                     out[p + "tiled/runs/" + k] = a.view(np.uint16) if a.dtype == np.int16 else a
                 out[p + "tiled/runs/meta"] = np.array([t.runs.n_primary, t.runs.max_window], dtype=np.int64)
-            out[p + "tiled/meta"] = np.array([t.n_slices, t.n_blocks, t.n_slots, int(t.desc_wide), int(t.ell_k)],
-                                             dtype=np.int64)
+            out[p + "tiled/meta"] = np.array([t.n_slices, t.n_blocks, t.n_slots, int(t.desc_wide), int(t.ell_k),
+                                              int(t.presum)], dtype=np.int64)
     np.savez(path, **out)
 
 
@@ -241,7 +241,8 @@ def load_plan(path) -> HostPlan:
                                        tile_sptr=a[p + "tiled/tile_sptr"], tile_jpos=a[p + "tiled/tile_jpos"],
                                        v_pcontact=hs.v_pcontact, n_slots=n_slots, chunk_ptr=a[p + "tiled/chunk_ptr"],
                                        chunk_desc=a[p + "tiled/chunk_desc"], desc_wide=bool(wide),
-                                       ell=a.get(p + "tiled/ell"), ell_k=ell_k)
+                                       ell=a.get(p + "tiled/ell"), ell_k=ell_k,
+                                       presum=bool(meta[5]) if len(meta) > 5 else False)
             if p + "tiled/runs/meta" in a:
                 r = p + "tiled/runs/"
                 hs.tiled.n_edges = int(len(a[p + "tiled/a_la"]))       # the tiled arrays hold the non-primary edges
@@ -268,7 +269,7 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
                  layout: str = "csr", leisure_sets: Sequence[str] = ("leisure",),
                  sv_max: int = TL.SV_MAX, eb_target: Optional[int] = None, slices=None,
                  nets_per_set: Optional[Dict[str, int]] = None, progress=None,
-                 desc_wide: Optional[bool] = None, device=None, direct=None, runs=None) -> HostPlan:
+                 desc_wide: Optional[bool] = None, device=None, direct=None, runs=None, presum=None) -> HostPlan:
     """edge_sets: {name: {"agent": i64[E], "venue": i64[E], "people": [V]}} (insertion order = set ids).
 
     layout: "csr" (deterministic CSR kernels), "tiled" (LDS-tiled fast path) or "both".
@@ -285,6 +286,8 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
     are ordered by - households under graph.locality_order - needs no index arrays for those edges).  None = every
     single-network set whose agents are so ordered, that is not in the direct form and where it pays; False = none;
     or a collection of set names (must be possible; takes precedence over the direct form).
+    presum: False = pass 1 of every set through phases A + B; None = a set in the direct form whose edges all belong
+    to owned agents takes pass 1 in the direct form too (its ELL rows + per-workgroup LDS tables of fixed-point sums).
     """
     if len(edge_sets) > N.GJ_MAX_SETS:
         raise ValueError(f"at most {N.GJ_MAX_SETS} edge sets")
@@ -333,6 +336,7 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
                 t.runs = _finish_runs(rf, t, n_agents, SA, device)
             elif plan_direct is not None:
                 t.ell, t.ell_k = plan_direct()
+                t.presum = presum is not False and plan_direct.all_owned
             blk_e0, blk_v0 = _host(t.blk_e0).astype(np.int64), _host(t.blk_v0).astype(np.int64)
             prim = np.diff(_host(t.runs.blk_r0).astype(np.int64)) if t.runs is not None else np.zeros(t.n_blocks, np.int64)
             for j in range(t.n_blocks):
@@ -398,9 +402,10 @@ def _direct_plan(name: str, es: dict, n_venues: int, n_agents: int, slice_agents
         raise ValueError(f"edge set {name}: not eligible for the direct form of pass 2")
     if not ok or (direct is not None and not forced):
         return None
-    if builder is not None:
-        return lambda: builder.build(dmax)
-    return lambda: TL.build_ell(agent, venue, n_agents, n_owned_slices, slice_agents)
+    build = (lambda: builder.build(dmax)) if builder is not None else (
+        lambda: TL.build_ell(agent, venue, n_agents, n_owned_slices, slice_agents))
+    build.all_owned = e_owned == n_edges          # no halo agent attends: the rows hold every edge of the set
+    return build
 
 
 def _split_runs(name: str, es: dict, n_agents: int, n_venues: int, slice_agents: int, device, forced: bool):
@@ -560,6 +565,15 @@ class DevicePlan:
             self.tiled_c.work = N.ptr(self.work)
             self.agent_scratch = (torch.zeros(max(1, host.n_agents), dtype=torch.float32, device=dev)
                                   if split_epilogue else None)
+            # pass 1 in the direct form: one table of fixed-point sums per workgroup and set
+            wgs = int(min(256, max(1, -(-host.n_agents // 4096))))
+            for i, s_ in enumerate(host.sets):
+                if s_.tiled is not None and s_.tiled.presum and s_.tiled.ell_k:
+                    stride = int(self.c.sets[i].cum_stride) if hasattr(self, "c") else int(plan.sets[i].cum_stride)
+                    buf = torch.zeros(wgs * max(1, s_.n_venues) * stride, dtype=torch.int64, device=dev)
+                    self.keep[i]["presum"] = buf
+                    self.tiled_c.sets[i].presum = buf.data_ptr()
+                    self.tiled_c.presum_wgs = wgs
             self.tiled_c.agent_scratch = N.ptr(self.agent_scratch)
             plan.tiled = C.pointer(self.tiled_c)
         self.c = plan

@@ -105,6 +105,8 @@ class TiledEdgeSet:
     ell: Optional[np.ndarray] = None         # uint16 [owned agents padded to slices, ell_k]: "direct" pass 2, see build_ell()
     ell_k: int = 0                           # 0: pass 2 runs through phases C + D like pass 1
     runs: Optional["RunForm"] = None         # the set's primary edges in the run form (see split_primary_runs)
+    presum: bool = False                     # pass 1 in the direct form too (ELL rows + per-workgroup LDS tables): a set
+                                             # in the direct form whose edges all belong to owned agents
     # A chunk = 64 consecutive slice-major edges.  Its first `split` edges lie in one tile and map to
     # block-major slots slot0, slot0+1, ...; the rest lie in the next non-empty tile and map to slot1,
     # slot1+1, ...  `multi` flags the rare chunk that spans more than two tiles (tiny tiles): its

@@ -158,6 +158,12 @@ typedef struct gj_tiled_set {
   int32_t run_max_window;     /* max run_win_n (sizes the LDS table of phase D), <= 32768                             */
   int32_t run_tiled_edges;    /* with a run form: the edges the tiled arrays above hold (the set's n_edges minus the
                                  primary ones; may be 0 - every person lives in exactly one household)               */
+  /* Pass 1 in the "direct" form (NULL: through phases A + B).  For a set in the direct form of pass 2 (ell_k != 0)
+   * whose edges ALL belong to owned agents, the ELL rows serve pass 1 too: gj_tiled.presum_wgs workgroups each take a
+   * contiguous range of owned agents, add every edge's term into an LDS table of 64-bit fixed-point sums per (venue,
+   * network) and write it to presum[workgroup][venue][network]; a second launch adds the tables up and applies
+   * beta * p_contact.  Exact (integer sums), so cum is the same bit for bit as through phases A + B.              */
+  int64_t* presum;            /* device [presum_wgs][n_venues * cum_stride] workspace or NULL                         */
 } gj_tiled_set;
 
 typedef struct gj_tiled {
@@ -169,6 +175,9 @@ typedef struct gj_tiled {
   const int32_t* work;       /* device [2*n_work] (set, block) pairs, heaviest first         */
   float* agent_scratch;      /* device [n_agents] workspace or NULL.  Non-NULL: phase D hands its
                                 per-agent sums to a separate full-occupancy epilogue launch  */
+  int32_t presum_wgs;        /* workgroups (= partial tables) of the direct form of pass 1, see gj_tiled_set.presum;
+                                0: no set uses it                                                 */
+  int32_t _pad_presum;
   gj_tiled_set sets[GJ_MAX_SETS];
 } gj_tiled;
 
