@@ -67,9 +67,9 @@ def parse():
                     help="run form of the edge set that orders the agents (households under --reorder household): one "
                          "edge per agent read from the per-agent arrays instead of the tiled index arrays (auto) or "
                          "every edge in the tiled arrays (off)")
-    ap.add_argument("--presum", default="auto", choices=["auto", "off"],
-                    help="pass 1 of the sets in the direct form from their ELL rows and per-workgroup LDS tables (auto) or "
-                         "through phases A + B like the other sets (off)")
+    ap.add_argument("--presum", default="off", choices=["on", "off"],
+                    help="experiment: pass 1 of the sets in the direct form from their ELL rows and per-workgroup LDS "
+                         "tables (on) instead of through phases A + B like the other sets (off, the default: faster)")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"], nargs="?", const="on",
                     help="N > 1: capture the production step (kernels + RCCL collectives) in a hipGraph after the warm-up "
                          "and replay it per timed step (13.5 us of host time per step instead of ~100).  auto (default): "
@@ -549,8 +549,8 @@ def main():
                 kw["direct"] = False
             if args.runs == "off":
                 kw["runs"] = False
-            if args.presum == "off":
-                kw["presum"] = False
+            if args.presum == "on":
+                kw["presum"] = True
             if args.sv_max:
                 kw["sv_max"] = args.sv_max
             if args.eb_target:

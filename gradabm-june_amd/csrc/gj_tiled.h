@@ -305,22 +305,33 @@ __device__ __forceinline__ void gather_set(const TSetA& T, fx_t* lds_acc, uint32
     }
   };
   auto add = [&](int c, const int (&la)[kU], const float (&v)[kU]) {
-    // straight-line: every lane adds (0 where there is no edge; la is a valid local index either way), what cannot
-    // be summed is flagged after the batch
-    uint32_t bad = 0u;
+    // straight-line: every lane adds (0 where there is no edge; la is a valid local index either way).  Whether a value
+    // can be summed at all - |x| <= 262144, not a NaN - is checked once per batch on the bit patterns (as unsigned
+    // integers they order like the magnitudes, NaN and the infinities above every finite value); the batch that holds
+    // such a value takes the per-element form and flags the agent
+    constexpr uint32_t kLimit = 0x48800000u;            // bit pattern of fx_max<kFxAgent>() = 262144.0f
+    static_assert(kFxAgent == 32, "kLimit is the pattern of 2^(50 - kFxAgent)");
+    float x[kU];
+    uint32_t m = 0u;
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
       const int i = seg0 + (c + u) * kWave + lane;
       const bool edge = (c + u < n_chunks) && (i < seg1);
-      const float x = edge ? v[u] : 0.0f;
-      const bool ok = fabsf(x) <= fx_max<kFxAgent>();
-      atomicAdd(&lds_acc[la[u]], to_fx<kFxAgent>(ok ? x : 0.0f));
-      bad |= ok ? 0u : (1u << u);
+      x[u] = edge ? v[u] : 0.0f;
+      m = max(m, __float_as_uint(x[u]) & 0x7FFFFFFFu);
     }
-    if (__builtin_expect(bad != 0u, 0)) {
+    if (__builtin_expect(m <= kLimit, 1)) {
 #pragma unroll
-      for (int u = 0; u < kU; ++u)
-        if ((bad >> u) & 1u) atomicOr(&lds_flags[la[u] >> 5], 1u << (la[u] & 31));
+      for (int u = 0; u < kU; ++u) atomicAdd(&lds_acc[la[u]], to_fx<kFxAgent>(x[u]));
+    } else {
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        if ((__float_as_uint(x[u]) & 0x7FFFFFFFu) <= kLimit) {
+          atomicAdd(&lds_acc[la[u]], to_fx<kFxAgent>(x[u]));
+        } else {
+          atomicOr(&lds_flags[la[u] >> 5], 1u << (la[u] & 31));
+        }
+      }
     }
   };
   int c0 = wave * kU;

@@ -286,8 +286,11 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
     are ordered by - households under graph.locality_order - needs no index arrays for those edges).  None = every
     single-network set whose agents are so ordered, that is not in the direct form and where it pays; False = none;
     or a collection of set names (must be possible; takes precedence over the direct form).
-    presum: False = pass 1 of every set through phases A + B; None = a set in the direct form whose edges all belong
-    to owned agents takes pass 1 in the direct form too (its ELL rows + per-workgroup LDS tables of fixed-point sums).
+    presum: True = a set in the direct form whose edges all belong to owned agents takes pass 1 in the direct form too
+    (its ELL rows + per-workgroup LDS tables of fixed-point sums, k_tile_presum; bit-identical results).  Off by
+    default: measured on C3 (round 3, tools/ab.py) it moves 0.2 GB less per step and is 15 % SLOWER - the 64-bit LDS
+    atomics it takes out of the venue launch (115 M per step) cost the same there, and its own launch pays a memory
+    round trip per batch (one workgroup per CU: the tables fill the LDS).
     """
     if len(edge_sets) > N.GJ_MAX_SETS:
         raise ValueError(f"at most {N.GJ_MAX_SETS} edge sets")
@@ -336,7 +339,7 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
                 t.runs = _finish_runs(rf, t, n_agents, SA, device)
             elif plan_direct is not None:
                 t.ell, t.ell_k = plan_direct()
-                t.presum = presum is not False and plan_direct.all_owned
+                t.presum = presum is True and plan_direct.all_owned
             blk_e0, blk_v0 = _host(t.blk_e0).astype(np.int64), _host(t.blk_v0).astype(np.int64)
             prim = np.diff(_host(t.runs.blk_r0).astype(np.int64)) if t.runs is not None else np.zeros(t.n_blocks, np.int64)
             for j in range(t.n_blocks):
