@@ -93,68 +93,59 @@ __device__ __forceinline__ float transmission_value(float mx, float shp, float r
   return mx * sign * aux * aux2 * inf;
 }
 
-// The profile costs ~690 instructions (lgammaf ~420, powf ~200, two expf) and a wave evaluates it for all 64 lanes
-// whenever one lane needs it; early in an epidemic a few agents in a hundred are infected.  So a workgroup first walks
-// a chunk of 8192 agents with coalesced 16-byte loads of is_infected - writing the zeros of the uninfected and listing
-// the infected in LDS - and then evaluates the listed agents DENSELY, one per lane (scattered 4-byte loads of their
-// five parameters: few).  Waves that evaluate: infected / 64 instead of one or two per 256 agents (round 2: each lane
-// took its own infected agents in turn) - at 3 % prevalence a tenth of the arithmetic, and the launch is back at its
-// memory bound.
-constexpr int kTransQuads = 8;                                  // quads of agents per lane and chunk
-constexpr int kTransChunkAgents = kThreads * 4 * kTransQuads;   // 8192
+// (Round 3, measured and not adopted: listing a chunk's infected agents in LDS and evaluating them densely, one per
+// lane, from scattered parameter loads - a tenth of the arithmetic at 3 % prevalence, but the list can only be worked
+// off behind a barrier and a second, uncoalesced round trip: 110 us against 70 on C3, whose timed steps run at 5-25 %
+// prevalence.)
 __global__ __launch_bounds__(kThreads) void k_transmission(
     int64_t n, const float* __restrict__ mx, const float* __restrict__ shp, const float* __restrict__ rt,
     const float* __restrict__ sh, const float* __restrict__ t_inf, const float* __restrict__ inf,
     const float* __restrict__ stage, float* __restrict__ trans, float* __restrict__ qtrans, float now_arg,
     int has_q, float q_thr, const gj_clock* __restrict__ clock) {
-  __shared__ int32_t list[kTransChunkAgents];
-  __shared__ int32_t n_list;
   const float now = clock ? clock->now : now_arg;      // device clock: a captured step replayed for later timesteps
-  const int tid = threadIdx.x;
   const int64_t n4 = n >> 2;
-  const int64_t chunk_quads = (int64_t)kThreads * kTransQuads;
-  for (int64_t q0 = (int64_t)blockIdx.x * chunk_quads; q0 < n4; q0 += (int64_t)gridDim.x * chunk_quads) {
-    if (tid == 0) n_list = 0;
-    __syncthreads();
-    float4 f[kTransQuads];
-#pragma unroll
-    for (int u = 0; u < kTransQuads; ++u) {              // clamped, unconditional: all loads in flight together
-      const int64_t q = min(q0 + u * kThreads + tid, n4 - 1);
-      f[u] = reinterpret_cast<const float4*>(inf)[q];
-    }
-#pragma unroll
-    for (int u = 0; u < kTransQuads; ++u) {
-      const int64_t q = q0 + u * kThreads + tid;
-      if (q >= n4) continue;
-      const unsigned m = (f[u].x != 0.0f ? 1u : 0u) | (f[u].y != 0.0f ? 2u : 0u) | (f[u].z != 0.0f ? 4u : 0u) |
-                         (f[u].w != 0.0f ? 8u : 0u);
-      if (m == 0u) {
-        reinterpret_cast<float4*>(trans)[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (has_q) reinterpret_cast<float4*>(qtrans)[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      } else {
-        // is_infected == 0 makes the product 0 whatever the profile: the quad's uninfected agents get their zeros here,
-        // its infected ones are listed (their values are written by the lanes that evaluate them)
-        int slot = atomicAdd(&n_list, __builtin_popcount(m));
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if ((m >> k) & 1u) {
-            list[slot++] = (int32_t)((q - q0) * 4 + k);
-          } else {
-            trans[q * 4 + k] = 0.0f;
-            if (has_q) qtrans[q * 4 + k] = 0.0f;
-          }
-        }
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 f = reinterpret_cast<const float4*>(inf)[i];
+    float4 r = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    // is_infected == 0 makes the product 0 whatever the profile (finite for every agent the reference gives a
+    // finite value for), so the five parameter streams are only read where someone is infected: early in an
+    // epidemic most 128-byte lines of them are never touched
+    unsigned m = (f.x != 0.0f ? 1u : 0u) | (f.y != 0.0f ? 2u : 0u) | (f.z != 0.0f ? 4u : 0u) | (f.w != 0.0f ? 8u : 0u);
+    if (m) {
+      const float4 a = reinterpret_cast<const float4*>(mx)[i];
+      const float4 b = reinterpret_cast<const float4*>(shp)[i];
+      const float4 c = reinterpret_cast<const float4*>(rt)[i];
+      const float4 d = reinterpret_cast<const float4*>(sh)[i];
+      const float4 e = reinterpret_cast<const float4*>(t_inf)[i];
+      // The profile (lgammaf ~420, powf ~200, two expf: ~690 instructions) is evaluated by a wave for all 64 lanes
+      // whenever one of them needs it.  Each lane therefore takes ITS infected agents one after the other: a wave makes
+      // as many evaluations as its busiest lane has infected agents (at 1 % prevalence ~1 instead of ~2 with one
+      // evaluation per component, at 30 % 3.4 of 4): 67 -> 62 us on C3.  (Measured, not adopted: exp(-lgamma(shape)),
+      // 60 % of those instructions and a per-agent constant, cached in a sixth parameter array - 6 us SLOWER: with
+      // the evaluations compacted the launch is bound by its reads again, and the cache adds 4 bytes per agent.)
+      while (m) {
+        const int k = __builtin_ctz(m);
+        m &= m - 1u;
+#define GJ_PICK(v) (k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w)
+        const float val = transmission_value(GJ_PICK(a), GJ_PICK(b), GJ_PICK(c), GJ_PICK(d), GJ_PICK(e), GJ_PICK(f), now);
+#undef GJ_PICK
+        r.x = k == 0 ? val : r.x;
+        r.y = k == 1 ? val : r.y;
+        r.z = k == 2 ? val : r.z;
+        r.w = k == 3 ? val : r.w;
       }
     }
-    __syncthreads();
-    const int cnt = n_list;
-    for (int i = tid; i < cnt; i += kThreads) {
-      const int64_t a = q0 * 4 + list[i];
-      const float r = transmission_value(mx[a], shp[a], rt[a], sh[a], t_inf[a], inf[a], now);
-      trans[a] = r;
-      if (has_q) qtrans[a] = (stage[a] < q_thr ? 1.0f : 0.0f) * r;
+    reinterpret_cast<float4*>(trans)[i] = r;
+    if (has_q) {
+      const float4 s = reinterpret_cast<const float4*>(stage)[i];
+      float4 q;
+      q.x = (s.x < q_thr ? 1.0f : 0.0f) * r.x;
+      q.y = (s.y < q_thr ? 1.0f : 0.0f) * r.y;
+      q.z = (s.z < q_thr ? 1.0f : 0.0f) * r.z;
+      q.w = (s.w < q_thr ? 1.0f : 0.0f) * r.w;
+      reinterpret_cast<float4*>(qtrans)[i] = q;
     }
-    __syncthreads();                                     // the list is free for the next chunk
   }
   // tail (n % 4 agents): first threads of block 0
   if (blockIdx.x == 0) {
@@ -916,8 +907,8 @@ static int do_transmission(const gj_plan* plan, const gj_agent_state* st, const 
   const int64_t n = plan->n_agents;
   if (n == 0) return GJ_OK;
   const int64_t n4 = (n + 3) / 4;
-  int64_t blocks = (n4 + (int64_t)kThreads * kTransQuads - 1) / ((int64_t)kThreads * kTransQuads);   // one chunk each
-  if (blocks > 256 * 8) blocks = 256 * 8;
+  int64_t blocks = (n4 + kThreads - 1) / kThreads;
+  if (blocks > 256 * 16) blocks = 256 * 16;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(k_transmission, dim3((unsigned)blocks), dim3(kThreads), 0, stream, n, st->max_infectiousness,
                      st->shape, st->rate, st->shift, st->infection_time, st->is_infected, st->current_stage,
