@@ -63,6 +63,10 @@ def parse():
     ap.add_argument("--direct", default="auto", choices=["auto", "off"],
                     help="pass 2 of sets with few venues straight from an LDS table of venue values (auto) or, like the "
                          "other sets, through the per-edge workspace (off)")
+    ap.add_argument("--generator", default="numpy", choices=["numpy", "torch"],
+                    help="numpy: the seeded generator of synthetic.make_world (what every committed figure uses); torch: the "
+                         "same distributions drawn on the device in seconds (synthetic.make_world_torch - another random "
+                         "world; for 1e8-agent runs, where numpy needs half an hour)")
     ap.add_argument("--runs", default="auto", choices=["auto", "off"],
                     help="run form of the edge set that orders the agents (households under --reorder household): one "
                          "edge per agent read from the per-agent arrays instead of the tiled index arrays (auto) or "
@@ -249,13 +253,25 @@ def csrc_hash() -> str:
 
 def cached_world(args, progress, make_world):
     def gen():
+        if args.generator == "torch":
+            from grad_june_amd.synthetic import make_world_torch
+
+            n = args.agents or {"c2": 1_000_000, "c3": 10_000_000, "c5": 100_000_000}[args.preset]
+            w = make_world_torch(args.preset, n, args.seed, torch.device("cuda", torch.cuda.current_device()),
+                                 infected_fraction=args.infected)
+            for es in w["edge_sets"].values():      # the partitioner and the locality order work on host arrays
+                es["agent"], es["venue"] = es["agent"].cpu().numpy(), es["venue"].cpu().numpy()
+            torch.cuda.empty_cache()
+            progress("world drawn on the device")
+            return w
         return make_world(args.preset, n_agents=args.agents, seed=args.seed, infected_fraction=args.infected,
                           edge_mult=args.edge_mult, progress=progress)
 
     if not args.world_cache:
         return gen()
     os.makedirs(args.world_cache, exist_ok=True)
-    path = os.path.join(args.world_cache, f"{args.preset}_{args.agents}_{args.seed}_{args.infected}_{args.edge_mult}.npz")
+    path = os.path.join(args.world_cache,
+                        f"{args.preset}_{args.agents}_{args.seed}_{args.infected}_{args.edge_mult}_{args.generator}.npz")
     if not os.path.exists(path):
         w = gen()
         flat = {"n_agents": w["n_agents"], "age": w["age"], "sex": w["sex"], "networks": ",".join(w["networks"])}

@@ -270,7 +270,7 @@ def build_rank_world(world: dict, rank: int, world_size: int, modes: Optional[Di
 
 
 def stream_rank_share(pieces, rank: int, world_size: int, reorder: Optional[str] = None,
-                      modes: Optional[Dict[str, str]] = None, progress=None):
+                      modes: Optional[Dict[str, str]] = None, progress=None, slice_agents: Optional[int] = None):
     """One rank's share of a world that arrives piece by piece (``synthetic.iter_world``): every edge set is
     relabelled (``reorder``: the locality order of ``synthetic.reorder_agents``, defined by the FIRST set streamed),
     cut down to this rank's part and dropped before the next one is generated.  Returns (RankWorld, share) where
@@ -305,7 +305,7 @@ def stream_rank_share(pieces, rank: int, world_size: int, reorder: Optional[str]
     age = header["age"] if order is None else header["age"][order]
     sex = header["sex"] if order is None else header["sex"][order]
     total_edges, sizes = part.total_edges, dict(part.sizes)
-    rw = part.finish(age, sex)[rank]
+    rw = part.finish(age, sex, slice_agents)[rank]
     share = {"networks": header["networks"], "state": {k: np.ascontiguousarray(pick(v)) for k, v in state.items()},
              "n_agents": header["n_agents"], "total_edges": total_edges, "sizes": sizes,
              "original_id": (np.arange(a0, a1) if order is None else order[a0:a1])}

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--eb-target", type=int, default=None)
     ap.add_argument("--sv-max", type=int, default=None)
+    ap.add_argument("--slice-agents", type=int, default=None, help="agents per slice (default: sized for the owned agents)")
     a = ap.parse_args()
     import torch
 
@@ -48,7 +49,7 @@ def main():
 
     rw, share = stream_rank_share(iter_world(a.preset, n_agents=a.agents, seed=a.seed, infected_fraction=0.01,
                                              progress=progress),
-                                  a.rank, a.of, reorder="household", progress=progress)
+                                  a.rank, a.of, reorder="household", progress=progress, slice_agents=a.slice_agents)
     t_part = time.time() - t0
     world = {"n_agents": share["n_agents"], "networks": share["networks"], "state": share["state"],
              "edge_sets": {k: {"n_edges": e, "n_venues": v} for k, (e, v) in share["sizes"].items()}}
