@@ -55,8 +55,8 @@ def parse():
                          "auto = household-major: the members of a household become neighbours, which halves the halo of "
                          "a partitioned run and makes the household tiles of a single GPU diagonal (-1.5 %% per step)")
     ap.add_argument("--parts", type=int, default=0,
-                    help="one GPU: step the world as this many agent partitions in turn (0 = auto: partitions of "
-                         "~16 M agents once the world exceeds 48 M, where single-partition tiles get too small)")
+                    help="one GPU: step the world as this many agent partitions in turn (0 = one partition: the fastest at "
+                         "every size measured, see auto_parts)")
     ap.add_argument("--quarantine", type=float, default=None,
                     help="second configuration of SURVEY 8d: an active quarantine policy with this stage threshold")
     ap.add_argument("--edge-mult", type=float, default=1.0, help="experiments: memberships per agent x this")
@@ -102,6 +102,10 @@ def parse():
     ap.add_argument("--work-order", default=None, choices=["heavy", "light", "mixed", "set"],
                     help="experiments: order of the venue launch's (set, block) work list (default: heaviest first)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--only-headline", action="store_true",
+                    help="profiling runs: only the warm-up and the timed region(s) of the headline configuration (no "
+                         "quarantine / high-prevalence / full-step regions, no CPU baseline), so that a profile's last "
+                         "dispatches are the timed steps")
     ap.add_argument("--cpu-seconds", type=float, default=150.0,
                     help="wall-clock bound of the CPU baseline (SURVEY 8d protocol: 3 warm-up + 10 timed steps, no_grad "
                          "and autograd on; a leg that would exceed the bound stops early and says so in `sample`)")
@@ -368,9 +372,12 @@ def backward_bench(args, world, specs, networks, dev, progress):
 
 
 def auto_parts(n_agents: int) -> int:
-    """One GPU: agent partitions stepped in turn (distributed.PartitionedHotPath) once a single partition's tiles get
-    too small.  Threshold and partition size from the sweep in profiles/ ("size scaling")."""
-    return 1 if n_agents <= 48_000_000 else -(-n_agents // 16_000_000)
+    """One GPU: agent partitions stepped in turn (distributed.PartitionedHotPath).  Round 2 switched to partitions of
+    16 M agents above 48 M, unmeasured; the round-3 sweeps (profiles/r03_c3_40m_parts*.json, r03_c5_100m_parts*.json)
+    say a single partition is the fastest at every size tried - C3 at 40 M agents 2.62 / 2.78 / 2.96 / 3.00 ms for
+    1 / 2 / 3 / 4 partitions, C5 at 100 M agents 12.6 ms against 18.4 ms for 7 - so partitions are only what --parts
+    asks for (they remain the one-GPU rehearsal of the multi-GPU partitioning)."""
+    return 1
 
 
 def self_launch(args) -> int:
@@ -458,6 +465,8 @@ def capture_validated(runner, dev, backend, dist):
 
 def main():
     args = parse()
+    if args.only_headline:
+        args.no_cpu_baseline, args.high_prevalence = True, 0.0
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
     # stdout carries exactly ONE line, the JSON result: libraries that print to fd 1 (RCCL's version banner
@@ -691,7 +700,7 @@ def main():
     if single:
         kept = {k: v.clone() for k, v in runner.state.items()}
         kept_t = runner.t
-    if single and args.quarantine is None:
+    if single and args.quarantine is None and not args.only_headline:
         # second configuration of SURVEY 8d: a quarantine policy (quarantine_policies.py:13-33: agents at or beyond the
         # stage threshold neither transmit nor receive outside their household) and social distancing
         # (interaction_policies.py:25-31: beta factors) both active, same world, same state
@@ -718,7 +727,7 @@ def main():
         del kept
 
     full = None
-    if not distributed and hasattr(runner, "enable_full_step"):
+    if not distributed and hasattr(runner, "enable_full_step") and not args.only_headline:
         # second timed region: the "full step" of SURVEY section 8d (hot path + symptoms + result reductions)
         runner.enable_full_step()
         for _ in range(3):

@@ -211,6 +211,7 @@ __global__ void k_wide_descriptors(const int32_t* chunk_ptr, const int32_t* sptr
       ++k;
     }
     const uint32_t multi = (p < g.chunk_end) ? 1u : 0u;
+    if (multi) atomicAdd(&counts[GJ_CC_WIDE_MULTI], 1);      // chunks whose lanes walk the tile tables (> 6 tiles)
     const uint32_t j0 = (uint32_t)(g.t0 - g.s * J);
     if (j0 >= (1u << 22)) counts[GJ_CC_ERROR] = 4;
     int32_t* d = desc + (int64_t)c * 8;
@@ -262,6 +263,23 @@ __global__ void k_ell_fill(const uint32_t* keys, const uint32_t* order, int64_t 
       continue;
     }
     ell[((int64_t)(col >> 1) * rows + a) * 2 + (col & 1)] = (uint16_t)venue[order[i]];
+  }
+}
+
+// explicit slots (tiling.build_tiled, slot_idx): the block-major slot of every slice-major edge position
+__global__ void k_explicit_slots(const int32_t* sptr, const int32_t* tile_jpos, int64_t n_tiles, int64_t E, int32_t* slots) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t lo = 0, hi = n_tiles + 1;                 // last tile t with sptr[t] <= i (empty tiles share a start: the last wins)
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((int64_t)sptr[mid] > i) {
+        hi = mid;
+      } else {
+        lo = mid + 1;
+      }
+    }
+    const int64_t t = lo - 1;
+    slots[i] = tile_jpos[t] + (int32_t)(i - sptr[t]);
   }
 }
 
@@ -636,6 +654,18 @@ int gj_compile_ell(const gj_compile_set* set, int32_t ell_k, int64_t rows, const
   if (const int rc = gjc::exclusive_scan(w.temp, w.temp_bytes, degree, w.rowptr, g.n_agents + 1, st)) return rc;
   gjc::k_ell_fill<<<gjc::grid_for(g.E), gjc::kThreads, 0, st>>>(w.keys_b, w.vals_b, g.E, g.n_agents, w.rowptr, set->venue,
                                                                rows, ell_k, ell, counts);
+  return (int)hipGetLastError();
+}
+
+int gj_compile_explicit_slots(const gj_compile_set* set, const gj_compile_out* out, int32_t* slots, void* stream) {
+  if (const int rc = gjc::check_set(set)) return rc;
+  if (!out || !out->tile_sptr || !out->tile_jpos) return GJ_E_NULL;
+  if (set->n_blocks < 1) return GJ_E_RANGE;
+  if (set->n_edges == 0) return 0;
+  if (!slots) return GJ_E_NULL;
+  const int64_t n_tiles = (int64_t)set->n_slices * set->n_blocks;
+  gjc::k_explicit_slots<<<gjc::grid_for(set->n_edges), gjc::kThreads, 0, (hipStream_t)stream>>>(
+      out->tile_sptr, out->tile_jpos, n_tiles, set->n_edges, slots);
   return (int)hipGetLastError();
 }
 

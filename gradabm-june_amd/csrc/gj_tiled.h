@@ -94,7 +94,8 @@ struct TSetA {            // what phases A and D need of one set
   int32_t J;
   int32_t active;         // networks active on the set in this step (0: skip)
   int32_t raw;            // 1: reads raw transmission / susceptibility weight (household)
-  int32_t wide;           // chunk_desc holds two int4 per chunk (up to 6 tiles per chunk), see tiling.py
+  int32_t wide;           // 1: chunk_desc holds two int4 per chunk (up to 6 tiles per chunk), see tiling.py;
+                          // 2: no descriptors - chunk_desc is int32 [E], the block-major slot of every slice-major edge
   int32_t direct;         // pass 2 of the set is taken by phase D's direct form (TDirect): no val / a_la reads there
   int32_t presum;         // pass 1 of the set is taken by k_tile_presum: phase A has nothing to scatter
 };
@@ -363,6 +364,74 @@ __device__ __forceinline__ void gather_set(const TSetA& T, fx_t* lds_acc, uint32
 #endif
 }
 
+// Sets whose tiles hold a handful of edges (a rank's halo half of a heavy-tailed set, a 1e8-agent world in one
+// partition): a 64-edge chunk then spans more tiles than a descriptor can express and every lane would walk the tile
+// tables (dependent loads, the launch falls off a cliff - round 2 measured 1.48 ms for such a phase A next to 0.25 ms
+// for its phase B).  Such a set carries the slot of every edge explicitly instead: 4 more bytes per edge and pass,
+// coalesced, straight-line.
+template <int kU>
+__device__ __forceinline__ void scatter_explicit(const TSetA& T, const float* lds_x, int s, int wave, int lane) {
+  const int row = s * T.J;
+  const int seg0 = T.tile_sptr[row], seg1 = T.tile_sptr[row + T.J];
+  const int n_chunks = T.chunk_ptr[s + 1] - T.chunk_ptr[s];
+  const int32_t* slots = reinterpret_cast<const int32_t*>(T.chunk_desc);
+  for (int c0 = wave * kU; c0 < n_chunks; c0 += kTileWaves * kU) {
+    int la[kU], sl[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int i = min(seg0 + (c0 + u) * kWave + lane, seg1 - 1);
+      la[u] = at32(T.a_la, i);
+      sl[u] = at32(slots, i);
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int i = seg0 + (c0 + u) * kWave + lane;
+      if ((c0 + u < n_chunks) && (i < seg1)) put32(T.val, sl[u], lds_x[la[u]]);
+    }
+  }
+}
+
+template <int kU>
+__device__ __forceinline__ void gather_explicit(const TSetA& T, fx_t* lds_acc, uint32_t* lds_flags, int s, int wave, int lane) {
+  const int row = s * T.J;
+  const int seg0 = T.tile_sptr[row], seg1 = T.tile_sptr[row + T.J];
+  const int n_chunks = T.chunk_ptr[s + 1] - T.chunk_ptr[s];
+  const int32_t* slots = reinterpret_cast<const int32_t*>(T.chunk_desc);
+  constexpr uint32_t kLimit = 0x48800000u;              // fx_max<kFxAgent>() = 262144.0f (see gather_set)
+  for (int c0 = wave * kU; c0 < n_chunks; c0 += kTileWaves * kU) {
+    int la[kU], sl[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int i = min(seg0 + (c0 + u) * kWave + lane, seg1 - 1);
+      la[u] = at32(T.a_la, i);
+      sl[u] = at32(slots, i);
+    }
+    float x[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) x[u] = at32(T.val, sl[u]);
+    uint32_t m = 0u;
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int i = seg0 + (c0 + u) * kWave + lane;
+      x[u] = ((c0 + u < n_chunks) && (i < seg1)) ? x[u] : 0.0f;
+      m = max(m, __float_as_uint(x[u]) & 0x7FFFFFFFu);
+    }
+    if (__builtin_expect(m <= kLimit, 1)) {
+#pragma unroll
+      for (int u = 0; u < kU; ++u) atomicAdd(&lds_acc[la[u]], to_fx<kFxAgent>(x[u]));
+    } else {
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        if ((__float_as_uint(x[u]) & 0x7FFFFFFFu) <= kLimit) {
+          atomicAdd(&lds_acc[la[u]], to_fx<kFxAgent>(x[u]));
+        } else {
+          atomicOr(&lds_flags[la[u] >> 5], 1u << (la[u] & 31));
+        }
+      }
+    }
+  }
+}
+
 // ---- phase A: scatter the slice's transmissions to every edge, in block-major tile order -------
 #ifndef GJ_SCATTER_WAVES_PER_SIMD
 #define GJ_SCATTER_WAVES_PER_SIMD 4      // 8: two workgroups per CU (<= 64 VGPRs; the slice's 80 KB of LDS allow it)
@@ -388,7 +457,9 @@ __global__ __launch_bounds__(kTileThreads, GJ_SCATTER_WAVES_PER_SIMD) void k_til
     for (int t = 0; t < A.n_sets; ++t) {
       const TSetA& T = A.sets[t];
       if (!T.active || T.presum || (two_sources && T.raw != pass)) continue;
-      if (T.wide) {
+      if (T.wide == 2) {
+        scatter_explicit<kUnroll>(T, lds_x, s, wave, lane);
+      } else if (T.wide) {
         scatter_set<true>(T, lds_x, s, wave, lane);
       } else {
         scatter_set<false>(T, lds_x, s, wave, lane);
@@ -1216,7 +1287,9 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
     for (int t = 0; t < D.n_sets; ++t) {
       const TSetA& T = D.sets[t];
       if (!T.active || T.direct || T.raw != pass) continue;
-      if (T.wide) {
+      if (T.wide == 2) {
+        gather_explicit<kUnroll>(T, lds_acc, lds_flags, s, wave, lane);
+      } else if (T.wide) {
         gather_set<true>(T, lds_acc, lds_flags, s, wave, lane);
       } else {
         gather_set<false>(T, lds_acc, lds_flags, s, wave, lane);

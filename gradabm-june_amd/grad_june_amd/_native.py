@@ -235,7 +235,7 @@ SYMBOLS = {
 # ---- graph compile on the device (include/gradjune_hip.h, "graph compile") ----
 GJ_COMPILE_COUNTS = 16
 GJ_CC_BLOCKS, GJ_CC_SLOTS, GJ_CC_CHUNKS, GJ_CC_MULTI, GJ_CC_OWNED_EDGES, GJ_CC_MAX_DEGREE, GJ_CC_ERROR = 0, 1, 2, 3, 4, 5, 7
-GJ_CC_RUN_PRIMARY, GJ_CC_RUN_UNSORTED, GJ_CC_RUN_WINDOW = 8, 9, 10
+GJ_CC_RUN_PRIMARY, GJ_CC_RUN_UNSORTED, GJ_CC_RUN_WINDOW, GJ_CC_WIDE_MULTI = 8, 9, 10, 11
 
 
 class CompileSet(C.Structure):
@@ -262,6 +262,7 @@ SYMBOLS.update({
     "gj_compile_tiles": (C.c_int, [C.POINTER(CompileSet), _vp, C.POINTER(CompileOut), _vp, _vp, C.c_int64, _vp]),
     "gj_compile_wide_descriptors": (C.c_int, [C.POINTER(CompileSet), C.POINTER(CompileOut), C.c_int32, _vp, _vp, _vp]),
     "gj_compile_ell_degrees": (C.c_int, [C.POINTER(CompileSet), _vp, _vp, _vp]),
+    "gj_compile_explicit_slots": (C.c_int, [C.POINTER(CompileSet), C.POINTER(CompileOut), _vp, _vp]),
     "gj_compile_runs_pick": (C.c_int, [C.POINTER(CompileSet), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gj_compile_runs_rest": (C.c_int, [C.POINTER(CompileSet), _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp]),
     "gj_compile_runs_index": (C.c_int, [C.POINTER(CompileSet), _vp, _vp, C.c_int32, C.c_int64, _vp, _vp, _vp, _vp, _vp]),

@@ -803,9 +803,14 @@ class PartitionedHotPath:
             rk.engine.step_phase(rk.bufs, p, rk.io, 5)
         mark("tile_venues_B")
         if ranks[0].flat_cum is not None and ranks[0].flat_cum.numel():
-            total = ranks[0].flat_cum.clone()
-            for rk in ranks[1:]:
-                total += rk.flat_cum
+            # the stand-in of the partial-sum all-reduce: fp32 adds in `reduce_order` (default: rank order).  RCCL sums
+            # in an order of its own (ring / tree, per chunk), so a venue's cum - and what follows from it - agrees
+            # across rank counts to fp32 rounding of R terms, not bit for bit (tests: the order reversed)
+            order = getattr(self, "reduce_order", None) or range(len(ranks))
+            order = list(order)
+            total = ranks[order[0]].flat_cum.clone()
+            for r in order[1:]:
+                total += ranks[r].flat_cum
             for rk in ranks:
                 rk.flat_cum.copy_(total)
         mark("partial_sum")

@@ -207,7 +207,8 @@ def save_plan(plan: HostPlan, path) -> None:
                 out[p + k] = getattr(s, k)
         if s.tiled is not None:
             t = s.tiled
-            for k in ("blk_v0", "blk_e0", "e_lv", "e_cls", "a_la", "tile_sptr", "tile_jpos", "chunk_ptr", "chunk_desc", "ell"):
+            for k in ("blk_v0", "blk_e0", "e_lv", "e_cls", "a_la", "tile_sptr", "tile_jpos", "chunk_ptr", "chunk_desc", "ell",
+                      "slot_idx"):
                 if getattr(t, k) is not None:
                     a = _host(getattr(t, k))
                     out[p + "tiled/" + k] = a.view(np.uint16) if (k in ("e_lv", "a_la", "ell") and a.dtype == np.int16) else a
@@ -241,7 +242,7 @@ def load_plan(path) -> HostPlan:
                                        tile_sptr=a[p + "tiled/tile_sptr"], tile_jpos=a[p + "tiled/tile_jpos"],
                                        v_pcontact=hs.v_pcontact, n_slots=n_slots, chunk_ptr=a[p + "tiled/chunk_ptr"],
                                        chunk_desc=a[p + "tiled/chunk_desc"], desc_wide=bool(wide),
-                                       ell=a.get(p + "tiled/ell"), ell_k=ell_k,
+                                       ell=a.get(p + "tiled/ell"), ell_k=ell_k, slot_idx=a.get(p + "tiled/slot_idx"),
                                        presum=bool(meta[5]) if len(meta) > 5 else False)
             if p + "tiled/runs/meta" in a:
                 r = p + "tiled/runs/"
@@ -269,7 +270,8 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
                  layout: str = "csr", leisure_sets: Sequence[str] = ("leisure",),
                  sv_max: int = TL.SV_MAX, eb_target: Optional[int] = None, slices=None,
                  nets_per_set: Optional[Dict[str, int]] = None, progress=None,
-                 desc_wide: Optional[bool] = None, device=None, direct=None, runs=None, presum=None) -> HostPlan:
+                 desc_wide: Optional[bool] = None, device=None, direct=None, runs=None, presum=None,
+                 desc_explicit: Optional[bool] = None) -> HostPlan:
     """edge_sets: {name: {"agent": i64[E], "venue": i64[E], "people": [V]}} (insertion order = set ids).
 
     layout: "csr" (deterministic CSR kernels), "tiled" (LDS-tiled fast path) or "both".
@@ -329,11 +331,12 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
 
                 hs.tiled = build_tiled_native(name, es_t["agent"], es_t["venue"], hs.n_venues, hs.v_pcontact, S, SA,
                                               agent_class=use_cls, sv_max=max(16, sv_max // max(1, k)),
-                                              eb_target=eb_target, wide=desc_wide, device=device, n_ext_agents=n_ext)
+                                              eb_target=eb_target, wide=desc_wide, device=device, n_ext_agents=n_ext,
+                                              explicit=desc_explicit)
             else:
                 hs.tiled = TL.build_tiled(name, es_t["agent"], es_t["venue"], hs.n_venues, hs.v_pcontact, S, SA,
                                           agent_class=use_cls, sv_max=max(16, sv_max // max(1, k)),
-                                          eb_target=eb_target, wide=desc_wide)
+                                          eb_target=eb_target, wide=desc_wide, explicit=desc_explicit)
             t = hs.tiled
             if rf is not None:
                 t.runs = _finish_runs(rf, t, n_agents, SA, device)
@@ -528,6 +531,9 @@ class DevicePlan:
                 c.n_blocks = ts.n_blocks
                 c.max_block_venues = int(np.diff(_host(ts.blk_v0)).max()) if ts.n_blocks else 0
                 c.desc_wide = 1 if ts.desc_wide else 0
+                if ts.slot_idx is not None and ts.n_edges > 0:      # tiles of a few edges: explicit slots, no descriptors
+                    t["chunk_desc"] = up(ts.slot_idx)
+                    c.desc_wide = 2
                 c.blk_v0, c.blk_e0 = t["blk_v0"].data_ptr(), t["blk_e0"].data_ptr()
                 c.e_lv, c.a_la = t["e_lv"].data_ptr(), t["a_la"].data_ptr()
                 c.e_cls = N.ptr(t.get("e_cls"))

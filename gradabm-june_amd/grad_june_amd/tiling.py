@@ -102,6 +102,8 @@ class TiledEdgeSet:
     chunk_ptr: Optional[np.ndarray] = None   # int32 [S+1] first 64-edge chunk of slice s (slice-major)
     chunk_desc: Optional[np.ndarray] = None  # int32 [n_chunks, 4]: slot0, slot1, split | multi << 16, j0
     desc_wide: bool = False                  # chunk_desc is int32 [n_chunks, 8], see wide_descriptors()
+    slot_idx: Optional[np.ndarray] = None    # int32 [E]: the block-major slot of every slice-major edge - replaces the
+                                             # descriptors of a set with tiles of a few edges (EXPLICIT_MIN_SHARE)
     ell: Optional[np.ndarray] = None         # uint16 [owned agents padded to slices, ell_k]: "direct" pass 2, see build_ell()
     ell_k: int = 0                           # 0: pass 2 runs through phases C + D like pass 1
     runs: Optional["RunForm"] = None         # the set's primary edges in the run form (see split_primary_runs)
@@ -115,6 +117,8 @@ class TiledEdgeSet:
 
 WIDE_SEGMENTS = 6      # tiles a 64-edge chunk may span in the wide descriptor format
 WIDE_MIN_SHARE = 0.01  # a set whose chunks span > 2 tiles more often than this gets wide descriptors
+EXPLICIT_MIN_SHARE = 0.02   # a set whose chunks span > 6 tiles (every lane walks the tile tables: a 5x cliff in phases A
+                            # and D) more often than this carries the slot of every edge explicitly instead (slot_idx)
 
 
 def wide_descriptors(sptr: np.ndarray, jpos_flat: np.ndarray, seg: np.ndarray, chunk_ptr: np.ndarray,
@@ -155,7 +159,8 @@ def wide_descriptors(sptr: np.ndarray, jpos_flat: np.ndarray, seg: np.ndarray, c
 
 def build_tiled(name: str, agent_index, venue_index, n_venues: int, v_pcontact: np.ndarray,
                 n_slices: int, slice_agents: int, agent_class: Optional[np.ndarray] = None,
-                sv_max: int = SV_MAX, eb_target: int = EB_TARGET, wide: Optional[bool] = None) -> TiledEdgeSet:
+                sv_max: int = SV_MAX, eb_target: int = EB_TARGET, wide: Optional[bool] = None,
+                explicit: Optional[bool] = None) -> TiledEdgeSet:
     agent = np.asarray(agent_index, dtype=np.int64).ravel()
     venue = np.asarray(venue_index, dtype=np.int64).ravel()
     E = len(agent)
@@ -235,15 +240,22 @@ def build_tiled(name: str, agent_index, venue_index, n_venues: int, v_pcontact: 
                            t0 - np.repeat(np.arange(S) * J, n_chunks)], axis=1).astype(np.int32)
     if wide is None:
         wide = bool(len(multi)) and float(multi.mean()) > WIDE_MIN_SHARE
+    slot_idx = None
     if wide:
-        chunk_desc, _ = wide_descriptors(sptr, jpos_sj.reshape(-1), seg, chunk_ptr, first_edge, chunk_end, t0, J)
+        chunk_desc, nseg = wide_descriptors(sptr, jpos_sj.reshape(-1), seg, chunk_ptr, first_edge, chunk_end, t0, J)
+        if explicit is None:
+            explicit = bool(len(nseg)) and float((nseg > WIDE_SEGMENTS).mean()) > EXPLICIT_MIN_SHARE
+    if explicit:
+        slot_idx = np.empty(E, dtype=np.int32)
+        slot_idx[pos_sm] = pos_bm.astype(np.int32)
     return TiledEdgeSet(
         name=name, n_venues=n_venues, n_edges=E, n_slices=S, n_blocks=J,
         blk_v0=blk_v0.astype(np.int32), blk_e0=blk_start.astype(np.int32),
         e_lv=e_lv, e_cls=e_cls, a_la=a_la,
         tile_sptr=sptr.astype(np.int32), tile_jpos=jpos_sj.reshape(-1).astype(np.int32),
         v_pcontact=np.asarray(v_pcontact, dtype=np.float32), n_slots=n_slots,
-        chunk_ptr=chunk_ptr.astype(np.int32), chunk_desc=np.ascontiguousarray(chunk_desc), desc_wide=bool(wide))
+        chunk_ptr=chunk_ptr.astype(np.int32), chunk_desc=np.ascontiguousarray(chunk_desc), desc_wide=bool(wide),
+        slot_idx=slot_idx)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -71,7 +71,8 @@ class _Session:
 
 def build_tiled_native(name: str, agent_index, venue_index, n_venues: int, v_pcontact, n_slices: int, slice_agents: int,
                        agent_class=None, sv_max: int = TL.SV_MAX, eb_target: int = TL.EB_TARGET,
-                       wide: Optional[bool] = None, device=None, n_ext_agents: Optional[int] = None) -> TL.TiledEdgeSet:
+                       wide: Optional[bool] = None, device=None, n_ext_agents: Optional[int] = None,
+                       explicit: Optional[bool] = None) -> TL.TiledEdgeSet:
     if slice_agents > 65536 or sv_max > 65535:
         raise ValueError("local indices are 16-bit")
     dev = torch.device(device if device is not None else agent_index.device)
@@ -117,21 +118,30 @@ def build_tiled_native(name: str, agent_index, venue_index, n_venues: int, v_pco
         n_slots, n_chunks, n_multi = int(c[N.GJ_CC_SLOTS]), int(c[N.GJ_CC_CHUNKS]), int(c[N.GJ_CC_MULTI])
         if wide is None:
             wide = n_chunks > 0 and (n_multi / n_chunks) > TL.WIDE_MIN_SHARE
+        slot_idx = None
         if wide:
             desc = i32(n_chunks * 8)
+            se.counts[N.GJ_CC_WIDE_MULTI] = 0
             N.check(lib.gj_compile_wide_descriptors(C.byref(se.set), C.byref(out), n_chunks, N.ptr(desc),
                                                     N.ptr(se.counts), st), "gj_compile_wide_descriptors")
-            se.read_counts(name)
+            c = se.read_counts(name)
             chunk_desc = desc[: n_chunks * 8].reshape(n_chunks, 8)
+            if explicit is None:
+                explicit = n_chunks > 0 and int(c[N.GJ_CC_WIDE_MULTI]) / n_chunks > TL.EXPLICIT_MIN_SHARE
         else:
             chunk_desc = desc[: n_chunks * 4].reshape(n_chunks, 4).clone()      # (drops the upper-bound tail)
+        if explicit and E > 0:
+            slot_idx = torch.empty(E, dtype=torch.int32, device=dev)
+            N.check(lib.gj_compile_explicit_slots(C.byref(se.set), C.byref(out), N.ptr(slot_idx), st),
+                    "gj_compile_explicit_slots")
+            torch.cuda.current_stream().synchronize()
         se.ws = None
     return TL.TiledEdgeSet(
         name=name, n_venues=n_venues, n_edges=E, n_slices=S, n_blocks=J,
         blk_v0=blk_v0[: J + 1].clone(), blk_e0=blk_e0, e_lv=e_lv[:n_slots].clone(),
         e_cls=None if e_cls is None else e_cls[:n_slots].clone(), a_la=a_la[:E],
         tile_sptr=sptr, tile_jpos=jpos, v_pcontact=v_pc, n_slots=n_slots,
-        chunk_ptr=chunk_ptr, chunk_desc=chunk_desc.contiguous(), desc_wide=bool(wide))
+        chunk_ptr=chunk_ptr, chunk_desc=chunk_desc.contiguous(), desc_wide=bool(wide), slot_idx=slot_idx)
 
 
 class EllBuilder:

@@ -114,7 +114,9 @@ typedef struct gj_long_row {
 typedef struct gj_tiled_set {
   int32_t n_blocks;          /* J: venue blocks of this set                                  */
   int32_t max_block_venues;  /* largest block of this set (sizes the LDS of phases B/C)      */
-  int32_t desc_wide;         /* 0: chunk_desc holds 4, 1: 8 int32 per chunk (see chunk_desc)  */
+  int32_t desc_wide;         /* 0: chunk_desc holds 4, 1: 8 int32 per chunk (see chunk_desc); 2: no descriptors -
+                                chunk_desc holds int32 [E], the block-major slot of every slice-major edge
+                                (sets with tiles of a few edges)                                  */
   int32_t ell_k;             /* 0: pass 2 of this set runs through phases C + D.  2, 4 or 8: "direct"
                                 form - phase C is skipped, phase D reads the venues' cum from an LDS
                                 table through `ell` (sets with <= 65534 venues, see `ell`)        */
@@ -476,6 +478,8 @@ int gj_unpack_f32(int64_t n, const int32_t* index, const float* in, float* dst, 
 #define GJ_CC_RUN_PRIMARY 8   /* gj_compile_runs_pick: owned agents with an edge = primary edges               */
 #define GJ_CC_RUN_UNSORTED 9  /* != 0: the owned agents are NOT ordered by their smallest venue - no run form  */
 #define GJ_CC_RUN_WINDOW 10   /* venues in the widest slice window                                            */
+#define GJ_CC_WIDE_MULTI 11   /* gj_compile_wide_descriptors: chunks that span more than six tiles (share > 2 %:
+                                 use gj_compile_explicit_slots)                                             */
 
 typedef struct gj_compile_set {
   const int64_t* agent;        /* [n_edges] edge_index[0]: agent ids, owned then halo, < n_ext_agents            */
@@ -519,6 +523,10 @@ int gj_compile_ell_degrees(const gj_compile_set* set, int32_t* degree, int32_t* 
  * when an agent does not fit; `counts` may be NULL).                                                               */
 int gj_compile_ell(const gj_compile_set* set, int32_t ell_k, int64_t rows, const int32_t* degree, uint16_t* ell,
                    void* workspace, int64_t workspace_bytes, int32_t* counts, void* stream);
+
+/* (optional, after gj_compile_tiles) the explicit-slot form of a set with tiles of a few edges: slots[i] (int32 [E]) = the
+ * block-major slot of slice-major edge i; gj_tiled_set.desc_wide = 2 and chunk_desc = slots.                       */
+int gj_compile_explicit_slots(const gj_compile_set* set, const gj_compile_out* out, int32_t* slots, void* stream);
 
 /* ---- run form of the set that orders the agents (gj_tiled_set.run_*; specification: tiling.split_primary_runs /
  * finish_run_form).  Three steps around the compile of the set's remaining edges:

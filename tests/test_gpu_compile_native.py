@@ -36,6 +36,9 @@ def assert_same_tiled(got, ref, what=""):
             assert np.array_equal(_host(x).reshape(np.asarray(y).shape), y), (what, k)
     for k in ("e_lv", "a_la"):
         assert np.array_equal(_host(getattr(got, k)).view(np.uint16), getattr(ref, k)), (what, k)
+    assert (got.slot_idx is None) == (ref.slot_idx is None), what
+    if ref.slot_idx is not None:
+        assert np.array_equal(_host(got.slot_idx), ref.slot_idx), (what, "slot_idx")
 
 
 CASES = [  # A, V, E, sa, svmax, eb, wide, dup

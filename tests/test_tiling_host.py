@@ -266,3 +266,26 @@ def test_compile_plan_run_form_choice_and_roundtrip(tmp_path):
     for k in ("pv_blk", "pv_win", "blk_r0", "win_lo", "win_n"):
         assert np.array_equal(np.asarray(getattr(rb.runs, k)), np.asarray(getattr(by["household"].runs, k))), k
     assert rb.n_edges == by["household"].n_edges and rb.runs.max_window == by["household"].runs.max_window
+
+
+def test_explicit_slots_replace_descriptors_for_tiny_tiles():
+    """Tiles of a few edges: more than six per 64-edge chunk is beyond the wide descriptor and every lane would walk
+    the tile tables; build_tiled then carries slot_idx, the block-major slot of every slice-major edge."""
+    rng = np.random.default_rng(3)
+    A, V, E, sa = 4000, 3000, 9000, 64
+    agent, venue = rng.integers(0, A, E), rng.integers(0, V, E)
+    pc = np.ones(V, np.float32)
+    t = build_tiled("x", agent, venue, V, pc, -(-A // sa), sa, sv_max=16, eb_target=16)
+    assert t.desc_wide and t.slot_idx is not None                       # chosen by itself: ~2 edges per tile
+    # slot_idx agrees with the tile tables (what the descriptors encode)
+    S, J = t.n_slices, t.n_blocks
+    for s_ in range(0, S, 7):
+        for j in range(0, J, 11):
+            a, b = t.tile_sptr[s_ * J + j], t.tile_sptr[s_ * J + j + 1]
+            assert np.array_equal(t.slot_idx[a:b], t.tile_jpos[s_ * J + j] + np.arange(b - a))
+    # every edge has a slot of its own, none is a pad slot
+    assert len(np.unique(t.slot_idx)) == E and (t.e_lv[t.slot_idx] != 0xFFFF).all()
+    big = build_tiled("x", agent, venue, V, pc, -(-A // sa), sa, sv_max=4096, eb_target=1 << 20)
+    assert big.slot_idx is None                                         # ordinary tiles keep their descriptors
+    forced = build_tiled("x", agent, venue, V, pc, -(-A // sa), sa, sv_max=4096, eb_target=1 << 20, explicit=True)
+    assert forced.slot_idx is not None and len(forced.slot_idx) == E

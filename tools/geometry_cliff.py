@@ -40,7 +40,8 @@ def describe(plan):
                      "tiles_nonempty": int(len(nz)), "edges_per_tile_mean": float(nz.mean()) if len(nz) else 0.0,
                      "edges_per_tile_p10": float(np.percentile(nz, 10)) if len(nz) else 0.0,
                      "desc_wide": bool(t.desc_wide), "chunks": int(len(desc)), "chunks_walk": int(walk.sum()),
-                     "walk_share": float(walk.mean()) if len(desc) else 0.0, "direct": bool(t.ell_k)})
+                     "walk_share": float(walk.mean()) if len(desc) else 0.0, "direct": bool(t.ell_k),
+                     "explicit_slots": t.slot_idx is not None, "run_form": t.runs is not None})
     return rows
 
 
@@ -49,6 +50,8 @@ def main():
     kw = dict(a.split("=") for a in sys.argv[3:])
     reorder = kw.pop("reorder", "household")
     kw = {k: int(v) for k, v in kw.items()}
+    if "desc_explicit" in kw:
+        kw["desc_explicit"] = bool(kw["desc_explicit"])
     entry.build()
     world = make_world(preset, n_agents=agents)
     if reorder != "none":
