@@ -157,6 +157,16 @@ def wide_descriptors(sptr: np.ndarray, jpos_flat: np.ndarray, seg: np.ndarray, c
     return desc.astype(np.uint32).view(np.int32), nseg
 
 
+def walk_share(t: "TiledEdgeSet") -> float:
+    """Share of a set's 64-edge chunks whose lanes have to walk the tile tables in phases A and D (more tiles in the
+    chunk than its descriptor expresses).  0 for a set with explicit slots; build_tiled keeps it <= EXPLICIT_MIN_SHARE."""
+    if t.slot_idx is not None or t.chunk_desc is None or len(t.chunk_desc) == 0:
+        return 0.0
+    d = np.asarray(t.chunk_desc.cpu() if hasattr(t.chunk_desc, "cpu") else t.chunk_desc).reshape(-1, 8 if t.desc_wide else 4)
+    flag = ((d[:, 7].view(np.uint32) >> 8) & 1) if t.desc_wide else (d[:, 2].view(np.uint32) >> 16)
+    return float((flag != 0).mean())
+
+
 def build_tiled(name: str, agent_index, venue_index, n_venues: int, v_pcontact: np.ndarray,
                 n_slices: int, slice_agents: int, agent_class: Optional[np.ndarray] = None,
                 sv_max: int = SV_MAX, eb_target: int = EB_TARGET, wide: Optional[bool] = None,

@@ -289,3 +289,21 @@ def test_explicit_slots_replace_descriptors_for_tiny_tiles():
     assert big.slot_idx is None                                         # ordinary tiles keep their descriptors
     forced = build_tiled("x", agent, venue, V, pc, -(-A // sa), sa, sv_max=4096, eb_target=1 << 20, explicit=True)
     assert forced.slot_idx is not None and len(forced.slot_idx) == E
+
+
+@pytest.mark.parametrize("sv_max,eb", [(16, 16), (64, 256), (256, 2048), (4096, 1 << 20)])
+def test_no_compiled_set_walks_the_tile_tables(sv_max, eb):
+    """The fence of the geometry cliff (round 2: one tuner candidate at 7.03 ms against 0.108; round 3 reproduced it at
+    40.9 ms against 1.13 on a C5 world with tiles of a few edges): whatever the geometry, at most
+    tiling.EXPLICIT_MIN_SHARE of a compiled set's chunks resolve their slots by walking the tile tables."""
+    from grad_june_amd import tiling as TL
+
+    rng = np.random.default_rng(sv_max)
+    A, V, E, sa = 6000, 5000, 20000, 64
+    agent, venue = rng.integers(0, A, E), (rng.zipf(1.5, E) % V)
+    t = build_tiled("x", agent, venue, V, np.ones(V, np.float32), -(-A // sa), sa, sv_max=sv_max, eb_target=eb)
+    assert TL.walk_share(t) <= TL.EXPLICIT_MIN_SHARE
+    if t.slot_idx is None:         # descriptors kept: then they do express (nearly) every chunk
+        forced = build_tiled("x", agent, venue, V, np.ones(V, np.float32), -(-A // sa), sa, sv_max=sv_max, eb_target=eb,
+                             explicit=False)
+        assert TL.walk_share(forced) <= TL.EXPLICIT_MIN_SHARE
