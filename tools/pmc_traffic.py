@@ -61,7 +61,12 @@ def main():
            "csrc_sha256": bench.csrc_hash(),       # bench.py reports this traffic only for the same kernel sources
            "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), mean over the last "
                      "8 dispatches; bytes = KiB*1024; FETCH_SIZE doubled (gfx950 reports 1/2 of streamed reads, "
-                     "MI355X_MICROARCH.md HBM section; checked against k_transmission's known 24 B/agent of reads)",
+                     "MI355X_MICROARCH.md HBM section).  What the x2 was validated on: k_transmission's 16-byte "
+                     "streams at full read volume (24 B/agent: ratio 1.001 / 0.983 in rounds 1 / 2 - in a profile taken "
+                     "early in the epidemic, as this one, the kernel skips the parameter lines of uninfected agents and "
+                     "the check below reads < 1); for the 2- and 4-byte streams of the tiled launches the corrected reads "
+                     "match the sizes of the arrays they stream (phase A, round 3: 2-byte a_la of 80 M tiled edges + "
+                     "descriptors + the transmission slices = 225 MB expected, 224.5 MB counted)",
            "per_launch_bytes": {}}
     total = 0.0
     for name, c in per.items():
