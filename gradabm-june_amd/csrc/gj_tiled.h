@@ -947,8 +947,8 @@ struct TDirect {          // a set whose pass 2 is taken straight from the venue
   int64_t plane_stride;   // elements of one plane
   int32_t K, planes;      // K entries per agent and plane (1, or 2: a pair of columns per plane)
   int32_t V, stride, nk;
-  int32_t region;         // which of the two LDS table regions its FIRST group of venue values is staged in (they alternate)
-  int32_t group_venues;   // venues per staging group (== V unless the table is larger than a region)
+  int32_t region;         // which of the two LDS table regions its venue values are staged in
+  int32_t group_venues;   // venues per staging group (== V unless the table is larger than region 0)
   int32_t _pad;
   int32_t raw, leisure;
   int32_t table[GJ_MAX_NETS_PER_SET];
@@ -980,8 +980,8 @@ struct TileDArgs {
   // "direct" form of pass 2 (sets with few venues, tiling.py build_ell): no per-edge workspace
   TDirect direct[GJ_MAX_DIRECT];
   int32_t n_direct;
-  int32_t table_floats;   // LDS floats of table region 0 (+ 64 of slack); region 1, of the same size, follows
-  int32_t table1_floats;  // LDS floats of table region 1
+  int32_t table_floats;   // LDS floats of table region 0 (+ 64 of slack); region 1 follows
+  int32_t table1_floats;  // LDS floats of table region 1 (0: none - every table is staged in region 0, one after the other)
   int32_t _pad3;
   int32_t day_type, transpose;
   const uint8_t* cls;
@@ -1183,11 +1183,8 @@ __device__ __forceinline__ void direct_sets(const TileDArgs& D, float (&acc)[kQu
                                             float* lds, int64_t base, int n_local, int tid, DirectBatch& cur,
                                             uint64_t diag_t0 = 0) {
   auto wtab_of = [&](int t) { return lds + (t & 1) * kClassWeightFloats; };
-  // the two table regions alternate from group to group (a set's first group in T.region), so that every group is
-  // staged while the one before it - in the other region - is still being read
-  auto region_of = [&](const TDirect& T, int v0) { return (T.region + (T.win_lo ? 0 : v0 / T.group_venues)) & 1; };
-  auto tab_of = [&](const TDirect& T, int v0) {
-    return lds + 2 * kClassWeightFloats + (region_of(T, v0) ? D.table_floats + kWave : 0);
+  auto tab_of = [&](const TDirect& T) {
+    return lds + 2 * kClassWeightFloats + (T.region ? D.table_floats + kWave : 0);
   };
   // a group of venue values: [lo, lo + nv) of the set's cum; the rows index it relative to `v0` (run form: the slice's
   // window, indexed from 0)
@@ -1195,7 +1192,7 @@ __device__ __forceinline__ void direct_sets(const TileDArgs& D, float (&acc)[kQu
   auto group_lo = [&](const TDirect& T, int v0) { return T.win_lo ? T.win_lo[blockIdx.x] : v0; };
   int t = 0, v0 = 0, plane = 0;
   __syncthreads();                              // the LDS is free: every lane has its sums in registers
-  direct_stage(D, D.direct[0], wtab_of(0), tab_of(D.direct[0], 0), group_lo(D.direct[0], 0), group_nv(D.direct[0], 0), tid);
+  direct_stage(D, D.direct[0], wtab_of(0), tab_of(D.direct[0]), group_lo(D.direct[0], 0), group_nv(D.direct[0], 0), tid);
   bool more = true;
   while (more) {
     const TDirect& T = D.direct[t];
@@ -1209,13 +1206,13 @@ __device__ __forceinline__ void direct_sets(const TileDArgs& D, float (&acc)[kQu
     more = direct_next(D, tn, vn, pn);
     const bool new_group = more && pn == 0;
     // the next group's values can be staged while this one is read if they go to the other region
-    const bool overlap = new_group && region_of(D.direct[tn], vn) != region_of(T, v0);
+    const bool overlap = new_group && D.direct[tn].region != T.region;
     if (overlap)
-      direct_stage(D, D.direct[tn], wtab_of(tn), tab_of(D.direct[tn], vn), group_lo(D.direct[tn], vn), group_nv(D.direct[tn], vn), tid);
+      direct_stage(D, D.direct[tn], wtab_of(tn), tab_of(D.direct[tn]), group_lo(D.direct[tn], vn), group_nv(D.direct[tn], vn), tid);
     DirectBatch nxt;
     if (more) direct_load(D, D.direct[tn], base, n_local, tid, pn, nxt);     // in flight while this item is summed
 #ifndef GJ_DIAG_NO_DIRECT_ADD
-    direct_add(D, T, acc, qmask, wtab_of(t), tab_of(T, v0), v0, nv, n_local, tid, cur);
+    direct_add(D, T, acc, qmask, wtab_of(t), tab_of(T), v0, nv, n_local, tid, cur);
 #else
     if (cur.w[0][0] == 0x12345678u && cur.cls[0] == 77u) acc[0][0] = 1.0f;     // keep the loads alive
 #endif
@@ -1225,7 +1222,7 @@ __device__ __forceinline__ void direct_sets(const TileDArgs& D, float (&acc)[kQu
 #endif
     if (new_group && !overlap) {                // same region: only once every wave is done reading this group
       __syncthreads();
-      direct_stage(D, D.direct[tn], wtab_of(tn), tab_of(D.direct[tn], vn), group_lo(D.direct[tn], vn), group_nv(D.direct[tn], vn), tid);
+      direct_stage(D, D.direct[tn], wtab_of(tn), tab_of(D.direct[tn]), group_lo(D.direct[tn], vn), group_nv(D.direct[tn], vn), tid);
     }
     if (more) cur = nxt;
     t = tn;

@@ -1045,7 +1045,7 @@ static int check_tiled(const gj_plan* plan) {
     const bool run = S.run_pv_blk || S.run_pv_win || S.run_blk_r0 || S.run_win_lo || S.run_win_n;
     if (run) {   // all or none; one window of cum per slice must fit phase D's table region
       if (!S.run_pv_blk || !S.run_pv_win || !S.run_blk_r0 || !S.run_win_lo || !S.run_win_n) return GJ_E_NULL;
-      if (S.run_max_window < 0 || S.run_max_window > 16384 || S.run_tiled_edges < 0 ||
+      if (S.run_max_window < 0 || S.run_max_window > 32768 || S.run_tiled_edges < 0 ||
           S.run_tiled_edges > plan->sets[s].n_edges || S.ell_k)
         return GJ_E_PLAN;
     }
@@ -1390,12 +1390,10 @@ static int tiled_agents(const gj_plan* plan, const gj_agent_state* st, const gj_
   D._pad3 = 0;
   if (D.n_direct) {
     // LDS of the direct form (the slice's sums are in registers by then): two class-weight buffers, then two table
-    // regions of the same size, each followed by 64 floats of slack for the last DMA piece.  Tables are staged in groups
-    // of at most a region, and the regions ALTERNATE from group to group - across sets too - so that every group is
-    // staged while the one before it is still being read.  (Round 2 gave region 0 the largest table and region 1 the
-    // rest: C3's household window then fell into the region the leisure table was being read from and waited for it -
-    // 8 % of a workgroup's time, GJ_DIAG_STAMPS.)  A window of a run-form set is staged whole.
-    const int64_t budget = (160 * 1024 / 4 - 2 * kClassWeightFloats - 2 * kWave) / 2;
+    // regions, each followed by 64 floats of slack for the last DMA piece.  Region 0 takes the largest table (in
+    // groups of venues if it is larger than everything), region 1 what is left: a set whose whole table fits there is
+    // staged while the previous set - in region 0 - is still being read.
+    const int64_t budget = 160 * 1024 / 4 - 2 * kClassWeightFloats - 2 * kWave;
     int64_t largest = 0;
     for (int t = 0; t < D.n_direct; ++t) {
       const int64_t sz = (int64_t)D.direct[t].V * D.direct[t].stride;
@@ -1404,17 +1402,18 @@ static int tiled_agents(const gj_plan* plan, const gj_agent_state* st, const gj_
     int64_t cap0 = largest < budget ? largest : budget;
     if (T->direct_table_floats > 0 && T->direct_table_floats < cap0) cap0 = T->direct_table_floats;
     if (cap0 < GJ_MAX_NETS_PER_SET) cap0 = GJ_MAX_NETS_PER_SET;
-    const int64_t cap1 = cap0;
-    int next_region = 0;
+    int64_t cap1 = budget - cap0;
+    if (T->direct_table_floats > 0 && T->direct_table_floats < cap1) cap1 = T->direct_table_floats;
+    int prev_region = -1;
     for (int t = 0; t < D.n_direct; ++t) {
       TDirect& X = D.direct[t];
       const int64_t sz = (int64_t)X.V * X.stride;
-      X.region = next_region;
-      X.group_venues = sz <= cap0 ? X.V : (int32_t)(cap0 / X.stride);
-      if (X.group_venues < 1 || (X.win_lo && sz > cap0)) return GJ_E_PLAN;   // a window is staged whole
+      X.region = (prev_region == 0 && sz <= cap1) ? 1 : 0;
+      const int64_t cap = X.region ? cap1 : cap0;
+      X.group_venues = sz <= cap ? X.V : (int32_t)(cap / X.stride);
+      if (X.group_venues < 1 || (X.win_lo && sz > cap)) return GJ_E_PLAN;   // a window is staged whole
       X._pad = 0;
-      const int64_t groups = X.win_lo ? 1 : (X.V + X.group_venues - 1) / X.group_venues;
-      next_region = (int)((X.region + groups) & 1);
+      prev_region = X.region;
     }
     D.table_floats = (int32_t)cap0;
     D.table1_floats = (int32_t)cap1;

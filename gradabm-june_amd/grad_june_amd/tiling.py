@@ -284,7 +284,7 @@ def build_tiled(name: str, agent_index, venue_index, n_venues: int, v_pcontact: 
 # of halo agents) stay in the tiled arrays.  In a world of the reference's kind - every person lives in exactly one
 # household - the household set leaves the tiled path entirely.
 RUN_MIN_SHARE = 0.25        # primary edges / owned edges below which the run form is not worth its two extra arrays
-RUN_MAX_WINDOW = 16384      # venues a slice's window may span: one of phase D's two LDS table regions (18.7 k floats)
+RUN_MAX_WINDOW = 32768      # venues a slice's window may span (LDS floats of phase D's table region; ids are 16-bit)
 
 
 @dataclass

@@ -157,7 +157,7 @@ typedef struct gj_tiled_set {
   const int32_t* run_blk_r0;  /* device [J+1]  first agent whose primary venue lies in block j (non-decreasing)        */
   const int32_t* run_win_lo;  /* device [owned slices] first venue of the slice's window                              */
   const int32_t* run_win_n;   /* device [owned slices] venues in the window (0: no primary edge in the slice)         */
-  int32_t run_max_window;     /* max run_win_n (sizes the LDS table of phase D), <= 16384                             */
+  int32_t run_max_window;     /* max run_win_n (sizes the LDS table of phase D), <= 32768                             */
   int32_t run_tiled_edges;    /* with a run form: the edges the tiled arrays above hold (the set's n_edges minus the
                                  primary ones; may be 0 - every person lives in exactly one household)               */
   /* Pass 1 in the "direct" form (NULL: through phases A + B).  For a set in the direct form of pass 2 (ell_k != 0)
