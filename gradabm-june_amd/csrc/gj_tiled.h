@@ -107,8 +107,6 @@ struct TileAArgs {
   int64_t n_agents;
   const float* trans;
   const float* qtrans;    // == trans when no quarantine collection
-  int32_t short_segments; // every set has at most a couple of batches per wave and slice: one pipeline over all sets
-  int32_t _pad;
 };
 
 __device__ __forceinline__ void load_slice(float* lds, const float* __restrict__ src, int64_t base, int n_local,
@@ -434,86 +432,6 @@ __device__ __forceinline__ void gather_explicit(const TSetA& T, fx_t* lds_acc, u
   }
 }
 
-// Short segments (a rank's share of a strong-scaled run, worlds of ~1 M agents): a wave has one or two batches per set
-// and slice, so a pipeline per set pays its first memory round trip - descriptors + local agent indices - once per set
-// (six sets: six exposed round trips of ~2-4 us in a launch of ~30 us).  Here ONE software pipeline runs over the
-// (set, batch) items of all sets: the next item's loads are issued before the current item's values are read from LDS
-// and stored.  The per-set segment bounds sit in LDS (fetched by the first lanes while the slice is loaded).
-struct ShortMeta {
-  int seg0, seg1, c_base, n_chunks;
-};
-struct ShortState {
-  int la[kUnroll];
-  int sl[kUnroll];         // explicit slots (sets without descriptors)
-  int word;                // this lane's descriptor dword of the batch (sets with descriptors)
-};
-
-template <typename Eligible>
-__device__ __forceinline__ void scatter_short(const TileAArgs& A, const ShortMeta* meta, const float* lds_x, int s, int wave,
-                                              int lane, Eligible eligible) {
-  constexpr int kU = kUnroll;
-  auto next = [&](int& t, int& b) -> bool {            // the next (set, batch) that holds chunks for this wave
-    for (;;) {
-      if (t >= 0 && t < A.n_sets && eligible(t) && ((b + 1) * kTileWaves + wave) * kU < meta[t].n_chunks) {
-        ++b;
-        return true;
-      }
-      ++t;
-      b = -1;
-      if (t >= A.n_sets) return false;
-    }
-  };
-  auto stage1 = [&](int t, int b, ShortState& st) {
-    const TSetA& T = A.sets[t];
-    const ShortMeta m = meta[t];
-    const int cc = min((b * kTileWaves + wave) * kU, m.n_chunks - 1);
-    if (T.wide == 2) {
-      const int32_t* slots = reinterpret_cast<const int32_t*>(T.chunk_desc);
-#pragma unroll
-      for (int u = 0; u < kU; ++u) st.sl[u] = at32(slots, min(m.seg0 + (cc + u) * kWave + lane, m.seg1 - 1));
-    } else if (T.wide == 1) {
-      st.word = batch_desc_load<true, kU>(T, m.c_base, m.n_chunks, cc, lane);
-    } else {
-      st.word = batch_desc_load<false, kU>(T, m.c_base, m.n_chunks, cc, lane);
-    }
-#pragma unroll
-    for (int u = 0; u < kU; ++u) st.la[u] = at32(T.a_la, min(m.seg0 + (cc + u) * kWave + lane, m.seg1 - 1));
-  };
-  auto stage2 = [&](int t, int b, const ShortState& st) {
-    const TSetA& T = A.sets[t];
-    const ShortMeta m = meta[t];
-    const int c = (b * kTileWaves + wave) * kU;
-    int slot[kU];
-    if (T.wide == 2) {
-#pragma unroll
-      for (int u = 0; u < kU; ++u) slot[u] = st.sl[u];
-    } else if (T.wide == 1) {
-      batch_slots<true, kU>(T, st.word, s * T.J, m.seg0, m.seg1, c, lane, slot);
-    } else {
-      batch_slots<false, kU>(T, st.word, s * T.J, m.seg0, m.seg1, c, lane, slot);
-    }
-#pragma unroll
-    for (int u = 0; u < kU; ++u) {
-      const int i = m.seg0 + (c + u) * kWave + lane;
-      if ((c + u < m.n_chunks) && (i < m.seg1)) put32(T.val, slot[u], lds_x[st.la[u]]);
-    }
-  };
-  int t = -1, b = -1;
-  if (!next(t, b)) return;
-  ShortState cur, nxt;
-  stage1(t, b, cur);
-  while (true) {
-    int tn = t, bn = b;
-    const bool more = next(tn, bn);
-    if (more) stage1(tn, bn, nxt);           // in flight while the current item's values are read from LDS and stored
-    stage2(t, b, cur);
-    if (!more) break;
-    cur = nxt;
-    t = tn;
-    b = bn;
-  }
-}
-
 // ---- phase A: scatter the slice's transmissions to every edge, in block-major tile order -------
 #ifndef GJ_SCATTER_WAVES_PER_SIMD
 #define GJ_SCATTER_WAVES_PER_SIMD 4      // 8: two workgroups per CU (<= 64 VGPRs; the slice's 80 KB of LDS allow it)
@@ -547,43 +465,6 @@ __global__ __launch_bounds__(kTileThreads, GJ_SCATTER_WAVES_PER_SIMD) void k_til
         scatter_set<false>(T, lds_x, s, wave, lane);
       }
     }
-  }
-}
-
-// the same for short segments (gj_tiled.short_segments): one pipeline over all sets, see scatter_short
-__global__ __launch_bounds__(kTileThreads, GJ_SCATTER_WAVES_PER_SIMD) void k_tile_scatter_short(const TileAArgs A) {
-  extern __shared__ __align__(16) float lds_x[];
-  __shared__ ShortMeta meta[GJ_MAX_SETS];
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave), lane = tid % kWave;
-  const int s = blockIdx.x;
-  const int64_t base = (int64_t)s * A.slice_agents;
-  const int n_local = (int)min((int64_t)A.slice_agents, A.n_agents - base);
-  const bool two_sources = A.qtrans != A.trans;
-  if (tid < A.n_sets) {          // the sets' segment bounds of this slice, fetched next to the slice load
-    const TSetA& T = A.sets[tid];
-    ShortMeta m = {0, 0, 0, 0};
-    if (T.active && !T.presum) {
-      const int row = s * T.J;
-      m.seg0 = T.tile_sptr[row];
-      m.seg1 = T.tile_sptr[row + T.J];
-      m.c_base = T.chunk_ptr[s];
-      m.n_chunks = T.chunk_ptr[s + 1] - m.c_base;
-    }
-    meta[tid] = m;
-  }
-  for (int pass = 0; pass < 2; ++pass) {
-    if (pass == 1 && !two_sources) break;
-    bool any = false;
-    for (int t = 0; t < A.n_sets; ++t)
-      if (A.sets[t].active && !A.sets[t].presum && (!two_sources || A.sets[t].raw == pass)) any = true;
-    if (!any) continue;
-    if (pass == 1) __syncthreads();
-    load_slice(lds_x, pass == 0 ? A.qtrans : A.trans, base, n_local, tid);
-    __syncthreads();
-    scatter_short(A, meta, lds_x, s, wave, lane, [&](int t) {
-      return A.sets[t].active && !A.sets[t].presum && (!two_sources || A.sets[t].raw == pass);
-    });
   }
 }
 

@@ -1234,18 +1234,10 @@ static int tiled_scatter(const gj_plan* plan, const gj_agent_state* st, const gj
   A.n_agents = plan->n_ext_agents;     // phase A also scatters the halo agents' values
   A.trans = st->transmission;
   A.qtrans = p->has_quarantine ? st->q_transmission : st->transmission;
-  A.short_segments = T->short_segments;
-  A._pad = 0;
   const size_t lds = slice_lds(T, sizeof(float));
   int rc = allow_lds(k_tile_scatter, lds);
   if (rc) return rc;
-  if (A.short_segments) {
-    rc = allow_lds(k_tile_scatter_short, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_tile_scatter_short, dim3((unsigned)T->n_slices), dim3(kTileThreads), lds, stream, A);
-  } else {
-    hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)T->n_slices), dim3(kTileThreads), lds, stream, A);
-  }
+  hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)T->n_slices), dim3(kTileThreads), lds, stream, A);
   rc = launch_status();
   if (rc) return rc;
   return tiled_presum(plan, st, p, G, stream);

@@ -79,7 +79,7 @@ class Tiled(C.Structure):
         ("work", _vp),
         ("agent_scratch", _vp),
         ("presum_wgs", C.c_int32),
-        ("short_segments", C.c_int32),
+        ("_pad_presum", C.c_int32),
         ("sets", TiledSet * GJ_MAX_SETS),
     ]
 

@@ -444,12 +444,8 @@ def _finish_runs(rf, t, n_agents: int, slice_agents: int, device):
 class DevicePlan:
     """The plan resident in HBM + the ctypes ``gj_plan`` that points at it."""
 
-    #: chunks (of 64 edges) per slice and set up to which phases A and D run one software pipeline over ALL sets
-    #: (gj_tiled.short_segments): 256 = two batches of 8 chunks per wave
-    SHORT_SEGMENT_CHUNKS = int(os.environ.get("GJ_SHORT_CHUNKS", "256"))
-
     def __init__(self, host: HostPlan, networks: Sequence[NetworkSpec], device, flat_cum_sets: Sequence[str] = (),
-                 split_epilogue: bool = False, direct_table_floats: int = 0, short_segments: Optional[bool] = None):
+                 split_epilogue: bool = False, direct_table_floats: int = 0):
         """flat_cum_sets: edge sets whose ``cum`` workspaces are carved from ONE contiguous buffer
         (``self.flat_cum``) so that a single collective can combine them across ranks."""
         self.host = host
@@ -588,15 +584,6 @@ class DevicePlan:
                     self.tiled_c.sets[i].presum = buf.data_ptr()
                     self.tiled_c.presum_wgs = wgs
             self.tiled_c.agent_scratch = N.ptr(self.agent_scratch)
-            if short_segments is None:       # from the plan: the longest slice segment of any set, in 64-edge chunks
-                longest = 0
-                for s_ in host.sets:
-                    cp = s_.tiled.chunk_ptr if s_.tiled is not None else None
-                    if cp is not None and len(cp) > 1:
-                        d = cp[1:] - cp[:-1]
-                        longest = max(longest, int(d.max()))
-                short_segments = 0 < longest <= self.SHORT_SEGMENT_CHUNKS
-            self.tiled_c.short_segments = 1 if short_segments else 0
             plan.tiled = C.pointer(self.tiled_c)
         self.c = plan
 

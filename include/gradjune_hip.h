@@ -179,9 +179,7 @@ typedef struct gj_tiled {
                                 per-agent sums to a separate full-occupancy epilogue launch  */
   int32_t presum_wgs;        /* workgroups (= partial tables) of the direct form of pass 1, see gj_tiled_set.presum;
                                 0: no set uses it                                                 */
-  int32_t short_segments;    /* != 0: every set has at most a couple of 64-edge-chunk batches per wave and slice (a
-                                rank's share of a strong-scaled run, a ~1 M-agent world): phases A and D run ONE
-                                software pipeline over all sets instead of one per set             */
+  int32_t _pad_presum;
   gj_tiled_set sets[GJ_MAX_SETS];
 } gj_tiled;
 

@@ -84,8 +84,7 @@ def network_specs(world, tables: Optional[dict] = None):
     return specs
 
 
-def make_engine(world, tables, device, layout="csr", split_epilogue=False, direct_table_floats=0, short_segments=None,
-                **plan_kw):
+def make_engine(world, tables, device, layout="csr", split_epilogue=False, direct_table_floats=0, **plan_kw):
     from grad_june_amd.engine import InfectionEngine
     from grad_june_amd.plan import DevicePlan, compile_plan
 
@@ -93,7 +92,7 @@ def make_engine(world, tables, device, layout="csr", split_epilogue=False, direc
     host = compile_plan(world["n_agents"], es, age=world["age"].numpy(), sex=world["sex"].numpy(), layout=layout,
                         **plan_kw)
     plan = DevicePlan(host, network_specs(world, tables), device, split_epilogue=split_epilogue,
-                      direct_table_floats=direct_table_floats, short_segments=short_segments)
+                      direct_table_floats=direct_table_floats)
     return InfectionEngine(plan)
 
 

@@ -35,15 +35,12 @@ LAYOUTS = [("csr", {}), ("tiled", dict(direct=False)),
            ("tiled", dict(slices="small", direct=("school", "leisure", "household"))),
            ("tiled", dict(sv_max=16, eb_target=64, slices="small", desc_explicit=True, direct=False)),
            ("tiled", dict(sv_max=64, eb_target=512, slices="small", desc_explicit=True)),
-           ("tiled", dict(short_segments=False, direct=False)),
-           ("tiled", dict(sv_max=16, eb_target=64, slices="small", desc_wide=True, short_segments=False, direct=False)),
            ("tiled", dict(presum=True)),
            ("tiled", dict(sv_max=64, eb_target=512, slices="small", direct_table_floats=24, presum=True))]
 LAYOUT_IDS = ["csr", "tiled", "tiled-small-tiles", "tiled-small-tiles-wide-desc", "tiled-tiny-tiles-wide-desc",
               "tiled-split-epilogue", "tiled-direct", "tiled-direct-small-tiles-venue-groups",
               "tiled-direct-split-epilogue-venue-groups", "tiled-direct-some-sets", "tiled-tiny-tiles-explicit-slots",
-              "tiled-direct-small-tiles-explicit-slots", "tiled-pipeline-per-set",
-              "tiled-tiny-tiles-wide-desc-pipeline-per-set", "tiled-direct-pass1-direct",
+              "tiled-direct-small-tiles-explicit-slots", "tiled-direct-pass1-direct",
               "tiled-direct-small-tiles-venue-groups-pass1-direct"]
 
 
