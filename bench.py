@@ -441,25 +441,31 @@ def capture_validated(runner, dev, backend, dist):
     for k in keys:
         runner.state[k].copy_(saved[k])
     runner.t = t_saved
-    ok, reason = True, "replay of one step == the eager step, every rank"
-    try:
-        runner.capture()
-        runner.step()                               # first replay: the same step again
-        torch.cuda.synchronize()
-        if not (all(torch.equal(runner.state[k], ref[k]) for k in keys) and torch.equal(runner.new_infected, ref_new)):
-            ok, reason = False, "the replayed step differs from the eager step"
-    except Exception as e:                          # capture is not supported for something in the step
-        ok, reason = False, f"capture failed: {type(e).__name__}: {e}"
-    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)     # every rank takes the same path
-    if int(flag.item()) == 0:
-        if ok:
-            reason = "another rank's replay differed or failed"
+    def agreed(ok: bool) -> bool:                   # every rank takes the same path
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag.item()) == 1
+
+    def fall_back(reason):
         runner.drop_graph()
         for k in keys:                              # the eager step's result, so that every rank continues from one state
             runner.state[k].copy_(ref[k])
         runner.t = t_saved + 1
         return False, reason
+
+    reason = "replay of one step == the eager step, every rank"
+    try:                                            # capturing executes nothing: no rank can be left waiting in a collective
+        runner.capture()
+        captured, why = True, ""
+    except Exception as e:                          # capture is not supported for something in the step
+        captured, why = False, f"capture failed: {type(e).__name__}: {e}"
+    if not agreed(captured):                        # BEFORE anyone replays: a replay's collectives need every rank
+        return fall_back(why or "capture failed on another rank")
+    runner.step()                                   # first replay: the same step again, on every rank
+    torch.cuda.synchronize()
+    same = all(torch.equal(runner.state[k], ref[k]) for k in keys) and torch.equal(runner.new_infected, ref_new)
+    if not agreed(same):
+        return fall_back("the replayed step differs from the eager step" + ("" if not same else " on another rank"))
     return True, reason
 
 
