@@ -226,3 +226,29 @@ def test_backward_through_a_run_form_set(device):
         grads[label] = np.array([float(v.grad) for v in logb.values()])
     assert np.abs(grads["plain"]).min() > 0
     assert np.allclose(grads["runs"], grads["plain"], rtol=2e-4), (grads["runs"], grads["plain"])
+
+
+@pytest.mark.parametrize("device_compile", [False, True], ids=["numpy-compile", "device-compile"])
+def test_run_form_on_the_ranks_of_a_partition(device, device_compile):
+    """What `bench.py --gpus N` builds: the household-major world cut into ranks.  On a rank the household set runs in
+    halo mode - owned agents' primary edges in the run form, the edges of halo agents (indices behind the owned slices)
+    in the tiled arrays - and the partition reproduces the single-GPU run's discrete state exactly."""
+    from grad_june_amd.benchrun import SingleGpuHotPath
+    from grad_june_amd.distributed import PartitionedHotPath
+    from grad_june_amd.synthetic import make_world, reorder_agents
+
+    world = reorder_agents(make_world("c3", n_agents=400_000, seed=31, infected_fraction=0.08), by="household")
+    specs, betas = B.network_specs(world), B.betas_of(world)
+    single = SingleGpuHotPath(world, specs, betas, device, seed=5, device_compile=device_compile)
+    parted = PartitionedHotPath(world, specs, betas, device, parts=4, seed=5, device_compile=device_compile)
+    for rk in parted.ranks:
+        t = {s.name: s.tiled for s in rk.engine.plan.host.sets}["household"]
+        assert rk.rw.modes["household"] == "halo" and rk.rw.n_halo > 1000
+        assert t.runs is not None and t.runs.n_primary == rk.rw.n_local and t.n_edges > 0
+    for _ in range(4):
+        single.step()
+        parted.step()
+    torch.cuda.synchronize()
+    for k, v in parted.state.items():
+        assert torch.equal(v, single.state[k]), k
+    assert float(single.state["is_infected"].sum()) > 1.3 * 0.08 * world["n_agents"]
