@@ -83,13 +83,52 @@ struct P2Args {
 // a1 + a2   transmission profile and quarantine-masked copy
 //   reference: grad_june/transmission.py:39-51, grad_june/policies/quarantine_policies.py:13-33
 // ------------------------------------------------------------------------------------------
+// The profile's transcendental part, exp(-lgamma(shape)) * pow(x, shape - 1) * exp(e), costs ~690 instructions with
+// libm's lgammaf (~420) and powf (~200) - and a wave pays them for all 64 lanes whenever one lane holds an infected
+// agent, which made k_transmission arithmetic-bound at the 5-25 % prevalence of the timed steps.  Round 3:
+//   1 / Gamma(shape)  by the recurrence to [1, 2] and Abramowitz & Stegun 6.1.36 (degree 8, |eps| <= 3e-7 there; measured
+//                     3.5e-7 relative in fp32), libm only for shapes outside (0.25, 16);
+//   pow(x, y)         = exp2(y * log2(x)) on the hardware's v_log_f32 / v_exp_f32 (1 ulp each): the error of the
+//                     exponent, |y log2 x| * 2^-23, is ~1e-6 relative in the result; NaN for x < 0, 0 / inf at x == 0 as powf;
+//   exp(e)            = exp2(e * log2(e)): ~|e| * 1e-7.
+// Together ~2e-6 relative against the reference's fp32 torch ops (themselves ~1e-7); the parity tests hold the
+// transmissions to 2e-5.  ~60 instructions.
+__device__ __forceinline__ float inv_gamma(float x) {
+  if (!(x > 0.25f && x < 16.0f)) return expf(-lgammaf(x));        // (also NaN)
+  float up = 1.0f, down = 1.0f;           // Gamma(x_in) = Gamma(x) * up / down
+  while (x > 2.0f) {
+    x -= 1.0f;
+    up *= x;
+  }
+  while (x < 1.0f) {
+    down *= x;
+    x += 1.0f;
+  }
+  const float z = x - 1.0f;
+  float g = 0.035868343f;
+  g = g * z - 0.193527818f;
+  g = g * z + 0.482199394f;
+  g = g * z - 0.756704078f;
+  g = g * z + 0.918206857f;
+  g = g * z - 0.897056937f;
+  g = g * z + 0.988205891f;
+  g = g * z - 0.577191652f;
+  g = g * z + 1.0f;                       // Gamma(1 + z), 0 <= z <= 1
+  return down / (g * up);
+}
+__device__ __forceinline__ float fast_pow(float x, float y) {
+  if (y == 0.0f) return 1.0f;             // powf(x, 0) == 1 for every x
+  return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));      // v_exp_f32(y * v_log_f32(x))
+}
+__device__ __forceinline__ float fast_exp(float e) { return __builtin_amdgcn_exp2f(e * 1.44269504088896341f); }
+
 __device__ __forceinline__ float transmission_value(float mx, float shp, float rt, float sh, float t_inf,
                                                     float inf, float now) {
   const float t = now - t_inf;
   const float d = t - sh;
   const float sign = (sgnf(d + 1e-10f) + 1.0f) / 2.0f;
-  const float aux = expf(-lgammaf(shp)) * powf(d * rt, shp - 1.0f);
-  const float aux2 = expf((sh - t) * rt) * rt;
+  const float aux = inv_gamma(shp) * fast_pow(d * rt, shp - 1.0f);
+  const float aux2 = fast_exp((sh - t) * rt) * rt;
   return mx * sign * aux * aux2 * inf;
 }
 
@@ -597,8 +636,8 @@ __global__ __launch_bounds__(kThreads) void k_adjoint_transmission(
   const float t = now - time0[a];
   const float d = t - sh[a];
   const float sign = (sgnf(d + 1e-10f) + 1.0f) / 2.0f;
-  const float aux = expf(-lgammaf(shp[a])) * powf(d * rt[a], shp[a] - 1.0f);
-  const float aux2 = expf((sh[a] - t) * rt[a]) * rt[a];
+  const float aux = inv_gamma(shp[a]) * fast_pow(d * rt[a], shp[a] - 1.0f);
+  const float aux2 = fast_exp((sh[a] - t) * rt[a]) * rt[a];
   const float base = mx[a] * sign * aux * aux2;              // d trans / d is_infected
   const float inf = inf0[a];
   float dtdt = 0.0f;                                         // d trans / d t
