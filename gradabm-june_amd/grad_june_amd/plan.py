@@ -578,7 +578,7 @@ class DevicePlan:
             wgs = int(min(256, max(1, -(-host.n_agents // 4096))))
             for i, s_ in enumerate(host.sets):
                 if s_.tiled is not None and s_.tiled.presum and s_.tiled.ell_k:
-                    stride = int(self.c.sets[i].cum_stride) if hasattr(self, "c") else int(plan.sets[i].cum_stride)
+                    stride = int(plan.sets[i].cum_stride)
                     buf = torch.zeros(wgs * max(1, s_.n_venues) * stride, dtype=torch.int64, device=dev)
                     self.keep[i]["presum"] = buf
                     self.tiled_c.sets[i].presum = buf.data_ptr()
