@@ -464,7 +464,21 @@ struct SymptomsArgs {
 
 __device__ __forceinline__ float dwell_sample(int kind, float loc, float scale, float z) {
   const float v = loc + scale * z;
-  return kind == 1 ? expf(v) : v;
+  return kind == 1 ? __builtin_amdgcn_exp2f(v * 1.44269504088896341f) : v;      // LogNormal: exp on v_exp_f32
+}
+// The library's own draw for an agent at stage s that is due (no reference stream to reproduce: symptoms.py:82-128 draws
+// torch.bernoulli + rsample): progress with the table's probability, dwell time = LogNormal / Normal of one Box-Muller
+// normal.  On the hardware's transcendental units (v_log_f32, v_sqrt_f32, v_cos_f32 - whose argument is in revolutions -
+// v_exp_f32): the draws of a wave's due agents were half of the fused symptoms launch with libm's logf / cosf / expf.
+// ONE definition, shared by the update and its adjoint (which must replay the same draw).
+__device__ __forceinline__ void stage_draw(const gj_symptoms_params& P, int64_t a, int s, int age, bool& onward, float& d) {
+  uint32_t r[4];
+  philox4x32_10((uint64_t)(P.agent_offset + a), P.step | (1ull << 63), P.seed, r);
+  onward = u01(r[0]) < P.progress[s * 100 + age];
+  const float ln_u = __builtin_amdgcn_logf(u01(r[1])) * 0.693147180559945309f;        // ln(u) = log2(u) * ln(2)
+  const float z = __builtin_amdgcn_sqrtf(-2.0f * ln_u) * __builtin_amdgcn_cosf(u01(r[2]));   // cos(2 pi u)
+  d = onward ? dwell_sample(P.next_kind[s], P.next_loc[s], P.next_scale[s], z)
+             : dwell_sample(P.rec_kind[s], P.rec_loc[s], P.rec_scale[s], z);
 }
 
 // One agent's stage update (symptoms.py:204-247, 82-128).  Returns true when any of the three values changed.
@@ -487,12 +501,7 @@ __device__ __forceinline__ bool symptoms_agent(const SymptomsArgs& S, int64_t a,
       onward = S.progresses[a] != 0.0f;
       d = S.dwell[a];
     } else {
-      uint32_t r[4];
-      philox4x32_10((uint64_t)(S.P.agent_offset + a), S.P.step | (1ull << 63), S.P.seed, r);
-      onward = u01(r[0]) < S.P.progress[s * 100 + age];
-      const float z = sqrtf(-2.0f * logf(u01(r[1]))) * cosf(6.2831853071795865f * u01(r[2]));
-      d = onward ? dwell_sample(S.P.next_kind[s], S.P.next_loc[s], S.P.next_scale[s], z)
-                 : dwell_sample(S.P.rec_kind[s], S.P.rec_loc[s], S.P.rec_scale[s], z);
+      stage_draw(S.P, a, s, age, onward, d);
     }
     if (onward) {
       nx = nx + 1.0f;
@@ -561,12 +570,7 @@ __global__ __launch_bounds__(kThreads) void k_adjoint_symptoms(const SymptomsAdj
       onward = S.progresses[a] != 0.0f;
       d = S.dwell[a];
     } else {
-      uint32_t r[4];
-      philox4x32_10((uint64_t)(S.P.agent_offset + a), S.P.step | (1ull << 63), S.P.seed, r);
-      onward = u01(r[0]) < S.P.progress[s * 100 + (S.cls[a] % 100)];
-      const float z = sqrtf(-2.0f * logf(u01(r[1]))) * cosf(6.2831853071795865f * u01(r[2]));
-      d = onward ? dwell_sample(S.P.next_kind[s], S.P.next_loc[s], S.P.next_scale[s], z)
-                 : dwell_sample(S.P.rec_kind[s], S.P.rec_loc[s], S.P.rec_scale[s], z);
+      stage_draw(S.P, a, s, (int)(S.cls[a] % 100), onward, d);
     }
     gc1 += gt1 * d / (float)s;              // time += dwell * (current == s) * current / s  (either branch)
     if (onward) {
