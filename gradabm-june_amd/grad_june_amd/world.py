@@ -37,6 +37,18 @@ DEVICE_COMPILE = os.environ.get("GRAD_JUNE_AMD_DEVICE_COMPILE", "auto")
 #: geometry reached the last bits - phase D adds fixed-point terms, the direct form sums in COO order), so the race
 #: between candidates decides the speed only (tests/test_gpu_api.py::test_tile_geometry_cannot_change_a_bit).
 TUNE = os.environ.get("GRAD_JUNE_AMD_TUNE", "auto")
+#: run form of the edge set the agents are ordered by (plan.compile_plan(runs=...)): "auto" (default: a household-major
+#: world - system.locality_order - whose household set is too large for the direct form keeps one edge per agent out
+#: of the tiled arrays), "off", or a comma-separated list of set names that must take it (tests: small worlds)
+RUNS = os.environ.get("GRAD_JUNE_AMD_RUNS", "auto")
+
+
+def _runs_option():
+    if RUNS == "auto":
+        return None
+    if RUNS in ("off", "0", ""):
+        return False
+    return tuple(x for x in (RUNS if isinstance(RUNS, str) else ",".join(RUNS)).split(",") if x)
 TUNE_CANDIDATES = ({}, {"eb_target": 131072, "sv_max": 16384}, {"eb_target": 65536, "sv_max": 16384})
 TUNE_MIN_EDGES, TUNE_MAX_EDGES = 200_000, 40_000_000
 N_MAX_TUNE_NETS = 16
@@ -158,7 +170,8 @@ def engine_for(data, specs: Sequence[NetworkSpec], device) -> InfectionEngine:
         if TUNE == "auto" and TUNE_MIN_EDGES <= n_edges <= TUNE_MAX_EDGES and len(specs) <= N_MAX_TUNE_NETS:
             with torch.cuda.device(device):
                 for cand in TUNE_CANDIDATES:
-                    h = compile_plan(n_agents, on_dev, age=age, sex=sex, layout="tiled", device=device, **cand)
+                    h = compile_plan(n_agents, on_dev, age=age, sex=sex, layout="tiled", device=device,
+                                     runs=_runs_option(), **cand)
                     e = InfectionEngine(DevicePlan(h, [n for n in specs if n.edge_set in h.set_index], device))
                     ms = _time_passes(e, [n for n in specs if n.edge_set in h.set_index])
                     if best is None or ms < best[0]:
@@ -170,10 +183,10 @@ def engine_for(data, specs: Sequence[NetworkSpec], device) -> InfectionEngine:
                 per_data.pop(next(iter(per_data)))
             per_data[sig] = engine
             return engine
-        host = compile_plan(n_agents, on_dev, age=age, sex=sex, layout="tiled", device=device)
+        host = compile_plan(n_agents, on_dev, age=age, sex=sex, layout="tiled", device=device, runs=_runs_option())
     else:
         host = compile_plan(n_agents, {k: {kk: vv for kk, vv in v.items() if kk != "_ei"} for k, v in sets.items()},
-                            age=age, sex=sex, layout=DEFAULT_LAYOUT)
+                            age=age, sex=sex, layout=DEFAULT_LAYOUT, runs=_runs_option())
     present = [n for n in specs if n.edge_set in host.set_index]
     engine = InfectionEngine(DevicePlan(host, present, device))
     if len(per_data) >= 4:          # worlds whose edges are rebuilt repeatedly: keep the cache small

@@ -466,6 +466,25 @@ def test_locality_order_gives_the_same_probabilities(G, device):
         _, is_infected = local()
     assert is_infected.shape[0] == n
     assert torch.equal(is_infected[original], local.data["agent"].is_infected)
+    # the household-major world with its household set in the RUN FORM (what a world too large for the direct form takes
+    # by itself; forced here): every person of the reference's world lives in one household, so the set's tiled arrays
+    # are empty - and the probabilities are still those of the original numbering
+    from grad_june_amd import world as W
+
+    try:
+        W.RUNS = "household"
+        torch.manual_seed(3)
+        runs = G.Runner.from_parameters(p2)
+        ag = runs.data["agent"]
+        ag.transmission, ag.susceptibility = trans[original].contiguous(), susc[original].contiguous()
+        next(runs.timer)
+        pc = runs.model.infection_networks(data=runs.data, timer=runs.timer, policies=runs.model.policies)
+        eng = W.engine_for(runs.data, [n_.spec() for n_ in runs.model.infection_networks.networks.values()], device)
+        t = {s_.name: s_.tiled for s_ in eng.plan.host.sets}["household"]
+        assert t.runs is not None and t.n_edges == 0 and t.runs.n_primary > 700
+    finally:
+        W.RUNS = "auto"
+    assert torch.allclose(pc, pa[original], rtol=2e-6, atol=1e-9)
 
 
 def test_api_with_device_side_compile(G, device):
