@@ -8,7 +8,7 @@
  * 200 000 agents, 5 000 venues, 300 000 random memberships.  Checks what the layout promises: every edge appears once in
  * each of the two tile orders, a venue block's slots hold local venue ids below its venue count, the slice-major local
  * agent ids are below the slice size, the tile prefix sums end at the edge count, and the ELL rows of the direct form
- * hold every owned agent's venues.
+ * hold every owned agent's venues; and the run form of a household-ordered set (gj_compile_runs_*).
  */
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
@@ -132,6 +132,48 @@ int main(void) {
   for (int64_t e = 0; e < E; ++e) vref += venue[e];
   CHECK(entries == E && vsum == vref);
   printf("ELL: K = %d columns (largest agent degree %lld), %lld entries\n", K, (long long)max_deg, (long long)entries);
+
+  /* the run form of a set the agents are ordered by: a household world - agent a lives in household a / 3 and a third of
+   * the agents visit a second, random one.  One edge per agent (its first edge to its smallest venue) leaves the tiled
+   * arrays; the others are compacted, in COO order, as the input of gj_compile_blocks / _tiles. */
+  {
+    const int64_t Eh = A + A / 3;
+    const int32_t Vh = (int32_t)((A + 2) / 3);
+    int64_t *ha = (int64_t*)malloc(Eh * 8), *hv = (int64_t*)malloc(Eh * 8);
+    for (int64_t a = 0; a < A; ++a) { ha[a] = a; hv[a] = a / 3; }
+    for (int64_t i = 0; i < A / 3; ++i) {
+      x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+      ha[A + i] = 3 * i;
+      hv[A + i] = (3 * i) / 3 + 1 + (int64_t)(x % (uint64_t)(Vh - (3 * i) / 3 - 1 > 0 ? Vh - (3 * i) / 3 - 1 : 1));   /* a LARGER venue id */
+      if (hv[A + i] >= Vh) hv[A + i] = Vh - 1;
+    }
+    int64_t *d_ha = (int64_t*)dmalloc(Eh * 8), *d_hv = (int64_t*)dmalloc(Eh * 8);
+    CHECK(d_ha && d_hv);
+    CHECK_HIP(hipMemcpy(d_ha, ha, Eh * 8, hipMemcpyHostToDevice));
+    CHECK_HIP(hipMemcpy(d_hv, hv, Eh * 8, hipMemcpyHostToDevice));
+    gj_compile_set hs = {d_ha, d_hv, NULL, Eh, A, (int64_t)S * SA, Vh, S, SA, 16384, 131072, 0};
+    int64_t hws_bytes = 0;
+    CHECK_GJ(gj_compile_workspace_bytes(&hs, &hws_bytes));
+    void* hws = dmalloc((size_t)hws_bytes);
+    int32_t *vmin = (int32_t*)dmalloc(A * 4), *pick = (int32_t*)dmalloc(A * 4), *win_lo = (int32_t*)dmalloc(S * 4),
+            *win_n = (int32_t*)dmalloc(S * 4);
+    uint8_t* keep = (uint8_t*)dmalloc(Eh);
+    CHECK(hws && vmin && pick && win_lo && win_n && keep);
+    CHECK_GJ(gj_compile_runs_pick(&hs, vmin, pick, keep, win_lo, win_n, counts, stream));
+    CHECK_HIP(hipStreamSynchronize(stream));
+    CHECK_HIP(hipMemcpy(c, counts, sizeof(c), hipMemcpyDeviceToHost));
+    CHECK(c[GJ_CC_RUN_PRIMARY] == A && c[GJ_CC_RUN_UNSORTED] == 0 && c[GJ_CC_OWNED_EDGES] == Eh);
+    CHECK(c[GJ_CC_RUN_WINDOW] >= SA / 3 && c[GJ_CC_RUN_WINDOW] <= SA / 3 + 2);       /* three agents per household */
+    int64_t *rest_a = (int64_t*)dmalloc((Eh - A) * 8), *rest_v = (int64_t*)dmalloc((Eh - A) * 8);
+    CHECK(rest_a && rest_v);
+    CHECK_GJ(gj_compile_runs_rest(&hs, keep, rest_a, rest_v, hws, hws_bytes, counts, stream));
+    CHECK_HIP(hipStreamSynchronize(stream));
+    int64_t* h_rest = (int64_t*)malloc((Eh - A) * 8);
+    CHECK_HIP(hipMemcpy(h_rest, rest_a, (Eh - A) * 8, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < Eh - A; ++i) CHECK(h_rest[i] == 3 * i);                   /* the second visits, in COO order */
+    printf("run form: %d primary edges leave the tiled arrays, %lld stay; widest slice window %d venues\n",
+           c[GJ_CC_RUN_PRIMARY], (long long)(Eh - A), c[GJ_CC_RUN_WINDOW]);
+  }
 
   /* argument errors never touch the device */
   cs.slice_agents = 70000;
