@@ -817,7 +817,7 @@ struct TilePArgs {
   int32_t day_type, transpose;
 };
 
-constexpr int kPresumQuads = 4;     // quads of agents a lane keeps in flight
+constexpr int kPresumQuads = 3;     // quads of agents a lane keeps in flight
 
 __global__ __launch_bounds__(kTileThreads) void k_tile_presum(const TilePArgs P) {
   extern __shared__ __align__(16) fx_t lds_p[];
@@ -849,29 +849,36 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_presum(const TilePArgs P)
       __syncthreads();
       for (int plane = 0; plane < T.planes; ++plane) {
         const uint16_t* ell = T.ell + plane * T.plane_stride + a_begin * 2;
-        for (int q0 = tid; q0 < n_quads; q0 += kPresumQuads * kTileThreads) {
+        // software pipeline over batches of kPresumQuads quads per lane: the next batch's rows / transmissions / classes
+        // are in flight while the current batch's terms are added (one workgroup per CU - the table fills the LDS - so
+        // nothing else hides the round trip); two register sets alternate
+        struct Batch {
           uint4 rows[kPresumQuads];
           float4 xs[kPresumQuads];
           uint32_t cl[kPresumQuads];
+        };
+        auto load = [&](int b0, Batch& B) {
 #pragma unroll
           for (int u = 0; u < kPresumQuads; ++u) {       // clamped, unconditional: every load in flight together
-            const int q = min(q0 + u * kTileThreads, n_quads - 1);
+            const int q = min(b0 + tid + u * kTileThreads, n_quads - 1);
             const int64_t a0 = a_begin + 4 * (int64_t)q;
-            rows[u] = *reinterpret_cast<const uint4*>(ell + 8 * (int64_t)q);       // rows are padded to whole slices
+            B.rows[u] = *reinterpret_cast<const uint4*>(ell + 8 * (int64_t)q);     // rows are padded to whole slices
             if (a0 + 4 <= P.n_agents) {
-              xs[u] = *reinterpret_cast<const float4*>(x + a0);
+              B.xs[u] = *reinterpret_cast<const float4*>(x + a0);
             } else {
-              xs[u] = make_float4(a0 < P.n_agents ? x[a0] : 0.0f, a0 + 1 < P.n_agents ? x[a0 + 1] : 0.0f,
-                                  a0 + 2 < P.n_agents ? x[a0 + 2] : 0.0f, 0.0f);
+              B.xs[u] = make_float4(a0 < P.n_agents ? x[a0] : 0.0f, a0 + 1 < P.n_agents ? x[a0 + 1] : 0.0f,
+                                    a0 + 2 < P.n_agents ? x[a0 + 2] : 0.0f, 0.0f);
             }
-            cl[u] = T.leisure ? *reinterpret_cast<const uint32_t*>(P.cls + a0) : 0u;
+            B.cl[u] = T.leisure ? *reinterpret_cast<const uint32_t*>(P.cls + a0) : 0u;
           }
+        };
+        auto add = [&](int b0, const Batch& B) {
 #pragma unroll
           for (int u = 0; u < kPresumQuads; ++u) {
-            const int q = q0 + u * kTileThreads;
+            const int q = b0 + tid + u * kTileThreads;
             if (q >= n_quads) continue;
-            const uint32_t w[4] = {rows[u].x, rows[u].y, rows[u].z, rows[u].w};
-            const float xv[4] = {xs[u].x, xs[u].y, xs[u].z, xs[u].w};
+            const uint32_t w[4] = {B.rows[u].x, B.rows[u].y, B.rows[u].z, B.rows[u].w};
+            const float xv[4] = {B.xs[u].x, B.xs[u].y, B.xs[u].z, B.xs[u].w};
             const int n_ok = (int)min((int64_t)4, a_end - (a_begin + 4 * (int64_t)q));   // agents of the quad in this range
             // straight-line: every entry adds - what is empty, another group's or past the range adds 0 to the scratch sum
 #pragma unroll
@@ -883,12 +890,30 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_presum(const TilePArgs P)
                 if (!T.leisure) {
                   fx_add<kFxVenue>(lds_p, flags, in ? lv : dummy, in ? xv[j] : 0.0f);
                 } else {
-                  const int cj = (cl[u] >> (8 * j)) & 0xFF;
+                  const int cj = (B.cl[u] >> (8 * j)) & 0xFF;
                   for (int k = 0; k < nk; ++k)
                     fx_add<kFxVenue>(lds_p, flags, in ? lv * nk + k : dummy, in ? wtab[k * 200 + cj] * xv[j] : 0.0f);
                 }
               }
             }
+          }
+        };
+        constexpr int kStep = kPresumQuads * kTileThreads;
+        if (n_quads > 0) {
+          Batch ba, bb;
+          int b0 = 0;
+          load(b0, ba);
+          while (true) {
+            const bool more1 = b0 + kStep < n_quads;
+            if (more1) load(b0 + kStep, bb);
+            add(b0, ba);
+            if (!more1) break;
+            b0 += kStep;
+            const bool more2 = b0 + kStep < n_quads;
+            if (more2) load(b0 + kStep, ba);
+            add(b0, bb);
+            if (!more2) break;
+            b0 += kStep;
           }
         }
       }
@@ -917,24 +942,48 @@ struct PReduceArgs {
   int32_t _pad;
 };
 
-// cum[v][k] = (beta_k * p_contact[v]) * sum over the workgroups' tables - the same expression as phase B's
+// cum[v][k] = (beta_k * p_contact[v]) * sum over the workgroups' tables - the same expression as phase B's.  A workgroup
+// takes 64 consecutive (venue, network) entries; its four waves each add up a quarter of the tables (for one table the
+// 64 entries are 512 contiguous bytes), eight loads in flight per lane, and the four partial sums meet in LDS.
 __global__ __launch_bounds__(kThreads) void k_presum_reduce(const PReduceArgs R) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= R.total) return;
+  __shared__ fx_t part[kThreads / kWave][kWave];
+  __shared__ uint32_t bad_any[kWave];
+  const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+  const int i = blockIdx.x * kWave + lane;
+  const bool in = i < R.total;
   int t = 0;
   while (t + 1 < R.n_sets && i >= R.sets[t + 1].first) ++t;
   const PReduceSet& T = R.sets[t];
-  const int e = i - T.first;
+  const int e = in ? i - T.first : 0;
   const int v = e / T.nk, k = e % T.nk;
   const int64_t idx = (int64_t)v * T.stride + k, table = (int64_t)T.V * T.stride;
   fx_t s = 0;
   bool bad = false;
-  for (int w = 0; w < R.n_wgs; ++w) {
-    const fx_t p = T.partial[w * table + idx];
-    bad |= p == (fx_t)kPresumBad;
-    s += p;
+  if (threadIdx.x < kWave) bad_any[threadIdx.x] = 0u;
+  constexpr int kWaves = kThreads / kWave;
+  for (int w0 = wave; w0 < R.n_wgs; w0 += kWaves * 8) {
+    fx_t p[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int w = w0 + u * kWaves;
+      p[u] = (in && w < R.n_wgs) ? T.partial[w * table + idx] : (fx_t)0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      bad |= p[u] == (fx_t)kPresumBad;
+      s += p[u];
+    }
   }
-  T.cum[idx] = (T.beta[k] * T.v_pc[v]) * (bad ? __builtin_nanf("") : from_fx<kFxVenue>(s));
+  part[wave][lane] = s;
+  __syncthreads();
+  if (bad) atomicOr(&bad_any[lane], 1u);
+  __syncthreads();
+  if (wave == 0 && in) {
+    fx_t total = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) total += part[w][lane];
+    T.cum[idx] = (T.beta[k] * T.v_pc[v]) * (bad_any[lane] ? __builtin_nanf("") : from_fx<kFxVenue>(total));
+  }
 }
 
 // ---- phase D: per slice, accumulate the edges' values per agent in LDS; epilogue a7-a9 -----------

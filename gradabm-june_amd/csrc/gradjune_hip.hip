@@ -1262,7 +1262,7 @@ static int tiled_presum_reduce(const gj_plan* plan, const gj_step_params* p, con
   if (R.n_sets == 0 || total == 0) return GJ_OK;
   if (total > INT32_MAX) return GJ_E_RANGE;
   R.total = (int32_t)total;
-  hipLaunchKernelGGL(k_presum_reduce, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, R);
+  hipLaunchKernelGGL(k_presum_reduce, dim3((unsigned)((total + kWave - 1) / kWave)), dim3(kThreads), 0, stream, R);
   return launch_status();
 }
 
