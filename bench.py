@@ -85,6 +85,9 @@ def parse():
     ap.add_argument("--backward", action="store_true",
                     help="row f3: time forward and backward of a T-step differentiable run (the eight log_beta as "
                          "nn.Parameter, loss = cases of the last step) instead of the forward-only hot path")
+    ap.add_argument("--backward-recompute", action="store_true",
+                    help="--backward: the memory-lean form (a step keeps its pre-state only; the backward recomputes the "
+                         "forward's two sparse passes)")
     ap.add_argument("--backward-steps", type=int, default=4, help="--backward: timesteps on the autograd graph")
     ap.add_argument("--no-events", action="store_true",
                     help="diagnostic: time the K steps as plain gj_step calls, without HIP events between the launches")
@@ -304,15 +307,19 @@ def cached_world(args, progress, make_world):
 
 def backward_bench(args, world, specs, networks, dev, progress):
     """Row f3 measured (example_scripts/run_model.py:5-11: every log_beta an nn.Parameter, ``cases.backward()``):
-    T chained differentiable steps (autograd.HotPathStep: the fused forward step + a hand-written backward that
-    recomputes the two sparse passes and runs them transposed) and the backward through all of them."""
+    T chained differentiable steps (autograd.HotPathStep: the fused forward step, which keeps its per-agent and
+    per-venue sums, + a hand-written backward that runs the two sparse passes transposed) and the backward through all
+    of them.  ``--backward-recompute``: the memory-lean form (the backward recomputes the forward's two passes first)."""
     from types import SimpleNamespace
 
+    from grad_june_amd import autograd as AG
     from grad_june_amd.autograd import HotPathStep
     from grad_june_amd.benchrun import SingleGpuHotPath
     from grad_june_amd.synthetic import algorithmic_bytes, network_edges
 
     betas = betas_of(world)
+    keep = not args.backward_recompute
+    AG.KEEP_FORWARD_SUMS = keep
     r = SingleGpuHotPath(world, specs, betas, dev, seed=args.seed, device_compile=not args.host_compile,
                          progress=progress)
     logb = {n: torch.nn.Parameter(torch.tensor(DEFAULT_LOG_BETA[n], device=dev)) for n in networks}
@@ -349,11 +356,11 @@ def backward_bench(args, world, specs, networks, dev, progress):
     b_step = algorithmic_bytes(world, networks)
     kb = kernel_bytes(world, networks)
     A = world["n_agents"]
-    # a backward step = the forward's two sparse passes recomputed (no decision) + the same two passes transposed
-    # + three elementwise adjoints (sampler/epilogue: ~13 arrays, transmission profile: ~9, q-transmission) and the
-    # per-venue dot products of d/d log_beta (two reads of every cum)
+    # a backward step = the two sparse passes transposed (+ the forward's two passes recomputed first in the
+    # memory-lean form) + three elementwise adjoints (sampler/epilogue: ~13 arrays, transmission profile: ~9,
+    # q-transmission) and the per-venue dot products of d/d log_beta (two reads of every cum)
     sparse = kb["tile_scatter"] + kb["tile_venues"] + (kb["tile_agents"] - 32 * A)
-    b_bwd = 2 * sparse + kb["transmission"] + (13 + 9) * 4 * A
+    b_bwd = (1 if keep else 2) * sparse + (0 if keep else kb["transmission"]) + (13 + 9) * 4 * A
     return {
         "metric": "differentiable simulation steps/sec (forward + backward)", "value": 1e3 / (fwd + bwd),
         "unit": "steps/s", "n_gpus": 1, "steps": T, "warmup": max(1, args.warmup // 2), "ms_per_step": fwd + bwd,
@@ -362,6 +369,8 @@ def backward_bench(args, world, specs, networks, dev, progress):
                                f"{network_edges(world, networks)} network-edges, {T} chained differentiable steps, "
                                f"loss = cases after the last step, d/d log_beta of every network"},
         "forward_ms_per_step": fwd, "backward_ms_per_step": bwd, "backward_over_forward": bwd / fwd,
+        "backward_form": ("forward sums kept by the step (4 floats per agent and step + the per-venue sums)" if keep
+                          else "forward passes recomputed (3 floats per agent and step)"),
         "runs": [{"forward_ms": x[0], "backward_ms": x[1]} for x in runs],
         "algorithmic_bytes": {"forward_step": b_step, "backward_step": b_bwd},
         "roofline": {"bound": "hbm", "kernel": "backward step (all launches)", "achieved": b_bwd / (bwd * 1e-3) / 1e9,

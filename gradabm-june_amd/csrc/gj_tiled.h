@@ -1026,6 +1026,7 @@ struct TileDArgs {
   uint64_t seed, step;
   int64_t agent_offset;
   float* acc_scratch;     // non-NULL: write the per-agent sums here and leave a7-a9 to k_tile_epilogue
+  float* agent_sums;      // non-NULL: optional output, the per-agent sums before the susceptibility factor (gj_step_io)
   // "direct" form of pass 2 (sets with few venues, tiling.py build_ell): no per-edge workspace
   TDirect direct[GJ_MAX_DIRECT];
   int32_t n_direct;
@@ -1398,6 +1399,13 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
     GJ_STAMP(3);
   }
   const bool vec = D.io_vec4 != 0;
+  if (D.agent_sums) {    // the forward's sums, kept for a backward pass
+#pragma unroll
+    for (int m = 0; m < kQ; ++m) {
+      const int i0 = 4 * (tid + m * kTileThreads);
+      if (i0 < n_local) store_quad(D.agent_sums, base + i0, n_local - i0, vec, acc[m]);
+    }
+  }
   if (D.acc_scratch) {   // split form: hand the per-agent sums to k_tile_epilogue (runs at full occupancy)
 #pragma unroll
     for (int m = 0; m < kQ; ++m) {

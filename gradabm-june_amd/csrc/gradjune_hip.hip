@@ -1022,6 +1022,7 @@ static int do_agent_gather(const gj_plan* plan, const gj_agent_state* st, const 
                            const gj_step_io* io, int sample, hipStream_t stream) {
   const int64_t n = plan->n_agents;
   if (n == 0) return GJ_OK;
+  if (io && io->agent_sums) return GJ_E_PLAN;      // the CSR kernel multiplies by the susceptibility per term: tiled layout only
   P2Args P;
   P.n_groups = G.n;
   P.any_leisure = 0;
@@ -1373,6 +1374,7 @@ static int tiled_agents(const gj_plan* plan, const gj_agent_state* st, const gj_
   D.not_infected_probs = io ? io->not_infected_probs : nullptr;
   D.new_infected = io ? io->new_infected : nullptr;
   D.trans_susc = io ? io->trans_susc : nullptr;
+  D.agent_sums = io ? io->agent_sums : nullptr;
   D.exp_noise = io ? io->exp_noise : nullptr;
   D.now = p->now;
   D.dt = p->delta_time;
@@ -1465,7 +1467,7 @@ static int tiled_agents(const gj_plan* plan, const gj_agent_state* st, const gj_
   }
   {
     uintptr_t bits = (uintptr_t)D.susceptibility | (uintptr_t)D.not_infected_probs | (uintptr_t)D.new_infected |
-                     (uintptr_t)D.trans_susc | (uintptr_t)D.acc_scratch;
+                     (uintptr_t)D.trans_susc | (uintptr_t)D.acc_scratch | (uintptr_t)D.agent_sums;
     D.io_vec4 = (bits % 16 == 0) ? 1 : 0;
   }
   int rc = allow_lds(k_tile_agents, lds);

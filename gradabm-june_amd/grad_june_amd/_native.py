@@ -10,7 +10,7 @@ import ctypes as C
 import os
 from typing import Optional
 
-GJ_ABI_VERSION = 4
+GJ_ABI_VERSION = 5
 GJ_MAX_SETS = 12
 GJ_MAX_NETS = 16
 GJ_MAX_NETS_PER_SET = 8
@@ -152,6 +152,7 @@ class StepIO(C.Structure):
         ("new_infected", _vp),
         ("exp_noise", _vp),
         ("trans_susc", _vp),
+        ("agent_sums", _vp),
     ]
 
 

@@ -14,8 +14,13 @@ reference's autograd):
 * the rest (straight-through Gumbel-softmax, clamp/exp/clamp, infect_people, transmission profile)
   is elementwise: ``gj_adjoint_sample`` and ``gj_adjoint_transmission``.
 
-The pre-state of the step is kept for the backward; the intermediates are recomputed (one extra
-forward of the two passes), so a T-step graph holds 3 per-agent floats per step plus the noise key.
+What a step keeps for its backward (``KEEP_FORWARD_SUMS``): the pre-state (3 per-agent floats) and - by default -
+the two products of the forward's sparse passes that the adjoint needs, the per-agent sums before the susceptibility
+factor (``gj_step_io.agent_sums``, one float per agent) and the per-venue sums ``cum`` (a clone, a few MB): 4 floats
+per agent and step, 160 MB per step of a 10 M-agent world out of 288 GB.  With ``GJ_BACKWARD_RECOMPUTE=1`` (or
+``autograd.KEEP_FORWARD_SUMS = False``) a step keeps the pre-state only and its backward recomputes the two passes
+first (round 2's form: 3 floats per agent and step, a backward of 2.7x the forward instead of 1.8x).  Both give the
+same gradients bit for bit - the kept sums ARE what the recomputation produces (tests/test_gpu_autograd_kept.py).
 """
 from __future__ import annotations
 
@@ -25,9 +30,28 @@ from typing import List
 
 import torch
 
+import os
+
 from . import _native as N
 from .engine import AgentBuffers
 from .plan import SPLIT_SUFFIX
+
+KEEP_FORWARD_SUMS = os.environ.get("GJ_BACKWARD_RECOMPUTE", "0") in ("", "0")
+
+
+def _keep_sums(env) -> bool:
+    return bool(env.get("keep_sums", KEEP_FORWARD_SUMS))
+
+
+def _clone_forward_cum(plan, nets):
+    """{edge set: clone of its per-venue sums} for every set a network of ``nets`` (or its twin on a split set) runs on."""
+    cum_fwd = {}
+    for _, names in _names_with_twins(plan, nets):
+        for name in names:
+            es = plan.networks[name].edge_set
+            if es not in cum_fwd:
+                cum_fwd[es] = plan.cum_of(es).clone()
+    return cum_fwd
 
 
 def _forward_sums(engine, p, bufs, acc, nets, compute_transmission: bool):
@@ -42,11 +66,7 @@ def _forward_sums(engine, p, bufs, acc, nets, compute_transmission: bool):
         engine.quarantine_transmission(bufs, p)                # the caller supplied the transmissions
     for phase in (1, 5):
         engine.step_phase(bufs, p, io, phase)
-    cum_fwd = {}
-    for net in nets:
-        es = plan.networks[net.name].edge_set
-        if es not in cum_fwd:
-            cum_fwd[es] = plan.cum_of(es).clone()
+    cum_fwd = _clone_forward_cum(plan, nets)
     for phase in (6, 4):
         engine.step_phase(bufs, p, io, phase)
     return cum_fwd
@@ -149,11 +169,14 @@ class HotPathStep(torch.autograd.Function):
         new_inf = torch.empty(n, dtype=torch.float32, device=plan.device)
         bufs = AgentBuffers(plan, **fixed, infection_time=out_t, is_infected=out_i, susceptibility=out_s,
                             transmission=trans, current_stage=stage)
-        engine.step(bufs, params, engine.io(new_infected=new_inf, exp_noise=exp_noise))
+        keep = _keep_sums(env) and plan.c.tiled is not None and bool(plan.c.tiled)
+        acc = torch.empty(n, dtype=torch.float32, device=plan.device) if keep else None
+        engine.step(bufs, params, engine.io(new_infected=new_inf, exp_noise=exp_noise, agent_sums=acc))
         ctx.env = env
         ctx.save_for_backward(susc.detach().to(torch.float32).contiguous(), inf.detach().to(torch.float32).contiguous(),
                               time.detach().to(torch.float32).contiguous())
         ctx.transmission = trans
+        ctx.kept = (acc, _clone_forward_cum(plan, nets)) if keep else None
         return out_s, out_i, out_t, new_inf
 
     @staticmethod
@@ -173,12 +196,14 @@ class HotPathStep(torch.autograd.Function):
         g_susc, g_inf, g_time, g_new = f32(g_susc), f32(g_inf), f32(g_time), f32(g_new)
         ones = torch.ones(n, dtype=torch.float32, device=dev)
         scratch = torch.zeros(plan.host.n_ext_agents, dtype=torch.float32, device=dev)
-        acc = torch.empty(n, dtype=torch.float32, device=dev)
-        # ---- recompute the forward of the two passes from the saved pre-state ----------------------------
         bufs = AgentBuffers(plan, **fixed, infection_time=time0, is_infected=inf0, susceptibility=ones,
                             transmission=scratch, current_stage=stage)
         p = params
-        cum_fwd = _forward_sums(engine, p, bufs, acc, nets, compute_transmission=True)
+        if ctx.kept is not None:      # the forward's per-agent and per-venue sums, kept by the step
+            acc, cum_fwd = ctx.kept
+        else:                         # recompute the forward of the two passes from the saved pre-state
+            acc = torch.empty(n, dtype=torch.float32, device=dev)
+            cum_fwd = _forward_sums(engine, p, bufs, acc, nets, compute_transmission=True)
         # ---- elementwise adjoint of epilogue + sampler + infect_people ------------------------------------
         x = torch.empty(n, dtype=torch.float32, device=dev)
         grad_susc = torch.empty(n, dtype=torch.float32, device=dev)
@@ -218,10 +243,13 @@ class DistributedHotPathStep(torch.autograd.Function):
         bufs = AgentBuffers(plan, **fixed, infection_time=out_t, is_infected=out_i, susceptibility=out_s,
                             transmission=hp.state["transmission"], q_transmission=hp.state["q_transmission"],
                             current_stage=stage)
-        hp.run_step(bufs, hp.engine.io(new_infected=new_inf, exp_noise=exp_noise), params_of)
+        keep = _keep_sums(env)
+        acc = torch.empty(n, dtype=torch.float32, device=plan.device) if keep else None
+        hp.run_step(bufs, hp.engine.io(new_infected=new_inf, exp_noise=exp_noise, agent_sums=acc), params_of)
         ctx.env = env
         ctx.save_for_backward(susc.detach().to(torch.float32).contiguous(), inf.detach().to(torch.float32).contiguous(),
                               time.detach().to(torch.float32).contiguous())
+        ctx.kept = (acc, _clone_forward_cum(plan, env["nets"])) if keep else None      # (cum: complete after the all-reduce)
         return out_s, out_i, out_t, new_inf
 
     @staticmethod
@@ -242,22 +270,21 @@ class DistributedHotPathStep(torch.autograd.Function):
         ones = torch.ones(n, dtype=torch.float32, device=dev)
         scratch = torch.zeros(n_ext, dtype=torch.float32, device=dev)
         scratch_q = torch.zeros(n_ext, dtype=torch.float32, device=dev) if p.has_quarantine else None
-        acc = torch.empty(n, dtype=torch.float32, device=dev)
         bufs = AgentBuffers(plan, **fixed, infection_time=time0, is_infected=inf0, susceptibility=ones,
                             transmission=scratch, q_transmission=scratch_q, current_stage=stage)
-        cum_fwd = {}
+        if ctx.kept is not None:      # the forward's per-agent and per-venue sums, kept by the step
+            acc, cum_fwd = ctx.kept
+        else:
+            acc = torch.empty(n, dtype=torch.float32, device=dev)
+            cum_fwd = {}
 
-        def keep_forward_sums():
-            for _, names in _names_with_twins(plan, nets):
-                for name in names:
-                    es = plan.networks[name].edge_set
-                    if es not in cum_fwd:
-                        cum_fwd[es] = plan.cum_of(es).clone()
+            def keep_forward_sums():
+                cum_fwd.update(_clone_forward_cum(plan, nets))
 
-        # ---- recompute the forward of the two passes from the saved pre-state, across the ranks ---------------
-        p.transpose = 0
-        engine.step_phase(bufs, p, engine.io(trans_susc=acc), 0)              # transmission (+ q * transmission)
-        hp.sparse_passes(bufs, engine.io(trans_susc=acc), p, between=keep_forward_sums)
+            # ---- recompute the forward of the two passes from the saved pre-state, across the ranks -----------
+            p.transpose = 0
+            engine.step_phase(bufs, p, engine.io(trans_susc=acc), 0)          # transmission (+ q * transmission)
+            hp.sparse_passes(bufs, engine.io(trans_susc=acc), p, between=keep_forward_sums)
         # ---- elementwise adjoint of epilogue + sampler + infect_people (owned agents) ----------------------------
         x = torch.empty(n, dtype=torch.float32, device=dev)
         grad_susc = torch.empty(n, dtype=torch.float32, device=dev)
@@ -324,14 +351,17 @@ class NetworksForward(torch.autograd.Function):
         susc = susceptibility.detach().to(device=dev, dtype=torch.float32).contiguous()
         bufs = AgentBuffers(plan, susceptibility=susc, transmission=trans, current_stage=env["stage"])
         out = torch.empty(n, dtype=torch.float32, device=dev)
+        keep = _keep_sums(env) and plan.c.tiled is not None and bool(plan.c.tiled)
+        acc = torch.empty(n, dtype=torch.float32, device=dev) if keep else None
         engine.quarantine_transmission(bufs, p)
         engine.venue_reduce(bufs, p)
-        engine.agent_gather(bufs, p, engine.io(not_infected_probs=out) if want == "probs" else engine.io(trans_susc=out),
-                            sample=False)
+        engine.agent_gather(bufs, p, engine.io(not_infected_probs=out, agent_sums=acc) if want == "probs"
+                            else engine.io(trans_susc=out, agent_sums=acc), sample=False)
         snap = N.StepParams()
         C.memmove(C.byref(snap), C.byref(p), C.sizeof(N.StepParams))
         ctx.env = dict(env, params=snap)
         ctx.save_for_backward(trans, susc)
+        ctx.kept = (acc, _clone_forward_cum(plan, env["nets"])) if keep else None
         return out
 
     @staticmethod
@@ -346,9 +376,12 @@ class NetworksForward(torch.autograd.Function):
         g = g_out.detach().to(torch.float32).contiguous()
         ones = torch.ones(n, dtype=torch.float32, device=dev)
         scratch = trans.clone()
-        acc = torch.empty(n, dtype=torch.float32, device=dev)
         bufs = AgentBuffers(plan, susceptibility=ones, transmission=scratch, current_stage=env["stage"])
-        cum_fwd = _forward_sums(engine, p, bufs, acc, nets, compute_transmission=False)
+        if ctx.kept is not None:
+            acc, cum_fwd = ctx.kept
+        else:
+            acc = torch.empty(n, dtype=torch.float32, device=dev)
+            cum_fwd = _forward_sums(engine, p, bufs, acc, nets, compute_transmission=False)
         if want == "probs":                                       # clamp(exp(-clamp(ts, 1e-6, 100) * dt), 0, 1)
             ts = susc * acc
             inside = (ts >= 1e-6) & (ts <= 100.0)

@@ -109,13 +109,14 @@ class InfectionEngine:
         return p
 
     @staticmethod
-    def io(not_infected_probs=None, new_infected=None, exp_noise=None, trans_susc=None) -> N.StepIO:
+    def io(not_infected_probs=None, new_infected=None, exp_noise=None, trans_susc=None, agent_sums=None) -> N.StepIO:
         io = N.StepIO()
         io.not_infected_probs = N.ptr(not_infected_probs)
         io.new_infected = N.ptr(new_infected)
         io.exp_noise = N.ptr(exp_noise)
         io.trans_susc = N.ptr(trans_susc)
-        io._keep = (not_infected_probs, new_infected, exp_noise, trans_susc)
+        io.agent_sums = N.ptr(agent_sums)
+        io._keep = (not_infected_probs, new_infected, exp_noise, trans_susc, agent_sums)
         return io
 
     def _prep(self, bufs: AgentBuffers, p: N.StepParams):

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GJ_ABI_VERSION 4
+#define GJ_ABI_VERSION 5
 
 #define GJ_MAX_SETS 12        /* distinct agent<->venue edge sets in a world (reference: 6)   */
 #define GJ_MAX_NETS 16        /* infection networks active in one step (reference: <= 11)      */
@@ -284,6 +284,10 @@ typedef struct gj_step_io {
   const float* exp_noise;    /* in  [2*n_agents] Exponential(1) draws, row 0 = "not infected";
                                 NULL = draw in-kernel with Philox4x32-10(seed, step, agent)  */
   float* trans_susc;         /* out [n_agents] pre-clamp sum over networks, optional (tests) */
+  float* agent_sums;         /* out [n_agents] the same sum WITHOUT the agent's susceptibility factor (trans_susc =
+                                susceptibility * agent_sums), optional: what a backward pass needs of the forward
+                                (grad_june_amd/autograd.py keeps it instead of recomputing both passes).  Tiled
+                                layout only: the CSR kernels multiply per term, as the reference does (GJ_E_PLAN) */
 } gj_step_io;
 
 /* a1 + a2: replaces TransmissionUpdater.forward (grad_june/transmission.py:38-51) and the

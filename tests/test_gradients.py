@@ -293,6 +293,45 @@ def test_hip_backward_matches_reference(device, case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
+def test_kept_forward_sums_equal_the_recomputation(device, case, monkeypatch):
+    """A differentiable step keeps the forward's per-agent sums (gj_step_io.agent_sums) and per-venue sums for its
+    backward instead of recomputing the two sparse passes (autograd.KEEP_FORWARD_SUMS).  The kept values ARE what the
+    recomputation produces - the same kernels on the same inputs, exact sums - so both forms give the same gradients
+    bit for bit, through several chained steps, a quarantine policy and the leisure networks (case g2)."""
+    import grad_june_amd as G
+    from grad_june_amd import autograd as AG
+
+    sub, world, tables, names = load_case(case)
+
+    def run(keep):
+        monkeypatch.setattr(AG, "KEEP_FORWARD_SUMS", keep)
+        model, timer = _model_and_timer(G, case, device)
+        data = _hetero(G, sub, world, device)
+        for n in names:
+            net = model.infection_networks.networks[n]
+            net.log_beta = torch.nn.Parameter(net.log_beta.detach().clone())
+        series = []
+        for i in range(int(sub["n_steps"])):
+            s = step_info(sub, i)
+            next(timer)
+            data["agent"].symptoms["current_stage"] = s["stage"].to(device)
+            model.hot_path(data, timer, exp_noise=s["noise"])
+            series.append(data["agent"].is_infected.sum())
+        params = [model.infection_networks.networks[n].log_beta for n in names]
+        g_last = torch.autograd.grad(series[-1], params, retain_graph=True, allow_unused=True)
+        g_all = torch.autograd.grad(torch.stack(series).sum(), params, allow_unused=True)
+        return [None if g is None else g.detach().cpu() for g in (*g_last, *g_all)]
+
+    kept, recomputed = run(True), run(False)
+    assert any(g is not None and float(g) != 0.0 for g in kept)
+    for a, b in zip(kept, recomputed):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(a, b), (a, b)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("factor", [1e6, 1e-9, 3e12], ids=["x1e6", "x1e-9", "x3e12"])
 def test_hip_backward_is_linear_in_the_loss_scale(device, factor):
     """The backward's sparse passes sum in fixed point with scales chosen for the forward's transmissions; the

@@ -33,7 +33,7 @@ def main():
     from grad_june_amd.synthetic import make_world, reorder_agents
 
     class Args:
-        preset, agents, seed, infected, edge_mult, world_cache = "c3", None, 1234, 0.01, 1.0, a.world_cache
+        preset, agents, seed, infected, edge_mult, world_cache, generator = "c3", None, 1234, 0.01, 1.0, a.world_cache, "numpy"
 
     world = reorder_agents(B.cached_world(Args, lambda m: print(m, file=sys.stderr), make_world), by="household")
     dev = torch.device("cuda:0")
