@@ -663,23 +663,42 @@ struct AdjBetaArgs {
   double* partial;
 };
 
-__global__ __launch_bounds__(kThreads) void k_adjoint_beta_partial(const AdjBetaArgs A) {
-  __shared__ double part[kThreads / kWave][GJ_MAX_NETS_PER_SET];
+// (1024 lanes per workgroup, two venues' loads in flight per lane: a lane's terms are added in venue order, one after the
+// other in fp64, so its loop is a chain of memory round trips - 6 M households over 256 x 256 lanes were 92 of them)
+constexpr int kAdjBetaThreads = 1024;
+__global__ __launch_bounds__(kAdjBetaThreads) void k_adjoint_beta_partial(const AdjBetaArgs A) {
+  __shared__ double part[kAdjBetaThreads / kWave][GJ_MAX_NETS_PER_SET];
   double acc[GJ_MAX_NETS_PER_SET];
 #pragma unroll
   for (int k = 0; k < GJ_MAX_NETS_PER_SET; ++k) acc[k] = 0.0;
-  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < A.n_venues; v += (int64_t)gridDim.x * blockDim.x) {
-    const double pc = (double)A.v_pc[v];
-    if (!(pc > 0.0)) continue;
-    const double w = A.weights ? A.weights[v] : 1.0;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  auto term = [&](double pc, double w, const float (&f)[GJ_MAX_NETS_PER_SET], const float (&b)[GJ_MAX_NETS_PER_SET]) {
+    if (!(pc > 0.0)) return;
 #pragma unroll
     for (int k = 0; k < GJ_MAX_NETS_PER_SET; ++k) {
       if (k >= A.nk) break;
       const double beta = (double)A.beta[k];
       if (beta == 0.0) continue;
-      const double prod = (double)A.cum_fwd[v * A.stride + k] * (double)A.cum_bwd[v * A.stride + k];
-      acc[k] += prod / (beta * pc) * w;
+      acc[k] += (double)f[k] * (double)b[k] / (beta * pc) * w;
     }
+  };
+  for (int64_t v0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v0 < A.n_venues; v0 += 2 * step) {
+    const int64_t v1 = v0 + step;
+    const bool two = v1 < A.n_venues;
+    const int64_t u1 = two ? v1 : v0;
+    const double pc0 = (double)A.v_pc[v0], pc1 = (double)A.v_pc[u1];
+    const double w0 = A.weights ? A.weights[v0] : 1.0, w1 = A.weights ? A.weights[u1] : 1.0;
+    float f0[GJ_MAX_NETS_PER_SET], b0[GJ_MAX_NETS_PER_SET], f1[GJ_MAX_NETS_PER_SET], b1[GJ_MAX_NETS_PER_SET];
+#pragma unroll
+    for (int k = 0; k < GJ_MAX_NETS_PER_SET; ++k) {
+      const bool on = k < A.nk;
+      f0[k] = on ? A.cum_fwd[v0 * A.stride + k] : 0.0f;
+      b0[k] = on ? A.cum_bwd[v0 * A.stride + k] : 0.0f;
+      f1[k] = on ? A.cum_fwd[u1 * A.stride + k] : 0.0f;
+      b1[k] = on ? A.cum_bwd[u1 * A.stride + k] : 0.0f;
+    }
+    term(pc0, w0, f0, b0);
+    if (two) term(pc1, w1, f1, b1);
   }
   const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
 #pragma unroll
@@ -691,7 +710,7 @@ __global__ __launch_bounds__(kThreads) void k_adjoint_beta_partial(const AdjBeta
   __syncthreads();
   if ((int)threadIdx.x < A.nk) {
     double x = 0.0;
-    for (int w = 0; w < kThreads / kWave; ++w) x += part[w][threadIdx.x];
+    for (int w = 0; w < kAdjBetaThreads / kWave; ++w) x += part[w][threadIdx.x];
     A.partial[(int64_t)blockIdx.x * GJ_MAX_NETS + A.cols[threadIdx.x]] += x;     // this (row, column) is this workgroup's alone
   }
 }
@@ -1643,7 +1662,7 @@ int gj_adjoint_beta_partial(int64_t n_venues, int32_t stride, int32_t nk, const 
     if (k < nk && (cols[k] < 0 || cols[k] >= GJ_MAX_NETS)) return GJ_E_RANGE;
   }
   A.partial = partial;
-  hipLaunchKernelGGL(gj::k_adjoint_beta_partial, dim3(GJ_ADJ_BETA_BLOCKS), dim3(gj::kThreads), 0, (hipStream_t)stream, A);
+  hipLaunchKernelGGL(gj::k_adjoint_beta_partial, dim3(GJ_ADJ_BETA_BLOCKS), dim3(gj::kAdjBetaThreads), 0, (hipStream_t)stream, A);
   return gj::launch_status();
 }
 

@@ -43,6 +43,16 @@ def _keep_sums(env) -> bool:
     return bool(env.get("keep_sums", KEEP_FORWARD_SUMS))
 
 
+def _ones(plan, n):
+    """A constant vector of ones on the plan's device (the adjoint runs the passes with susceptibility = 1; the phases
+    it calls only read it) - one per plan, not a fill launch per backward step."""
+    t = getattr(plan, "_adjoint_ones", None)
+    if t is None or t.numel() != n:
+        t = torch.ones(n, dtype=torch.float32, device=plan.device)
+        plan._adjoint_ones = t
+    return t
+
+
 def _clone_forward_cum(plan, nets):
     """{edge set: clone of its per-venue sums} for every set a network of ``nets`` (or its twin on a split set) runs on."""
     cum_fwd = {}
@@ -64,11 +74,9 @@ def _forward_sums(engine, p, bufs, acc, nets, compute_transmission: bool):
         engine.step_phase(bufs, p, io, 0)                      # transmission (+ q * transmission)
     else:
         engine.quarantine_transmission(bufs, p)                # the caller supplied the transmissions
-    for phase in (1, 5):
-        engine.step_phase(bufs, p, io, phase)
+    engine.step_phase(bufs, p, io, 8)                          # phase A, then B + C in one launch (cum stays in place)
     cum_fwd = _clone_forward_cum(plan, nets)
-    for phase in (6, 4):
-        engine.step_phase(bufs, p, io, phase)
+    engine.step_phase(bufs, p, io, 4)
     return cum_fwd
 
 
@@ -81,21 +89,20 @@ def _transposed_passes(engine, p, bufs, scratch, x, nets, betas, cum_fwd):
     # forward's transmissions.  A cotangent has whatever magnitude the user's loss gives it (an MSE on case counts:
     # 1e5; a normalised loss: 1e-10), so x is brought to max |x| in [0.5, 1) by a power of two first and the results
     # are scaled back - exact, the passes being linear - without a host synchronisation.
-    scale = _power_of_two_scale(x.abs().max())
-    scratch[:n].copy_(x / scale)
+    lo, hi = torch.aminmax(x)                                  # (one reduction launch; max |x| = max(-lo, hi))
+    scale = _power_of_two_scale(torch.maximum(-lo, hi))
+    torch.div(x, scale, out=scratch[:n])
     tbar = torch.empty(n, dtype=torch.float32, device=plan.device)
     io_t = engine.io(trans_susc=tbar)
     p.transpose = 1
     try:
         engine.quarantine_transmission(bufs, p)                # q * x for the masked sets
-        for phase in (1, 5):
-            engine.step_phase(bufs, p, io_t, phase)
+        engine.step_phase(bufs, p, io_t, 8)                    # phase A, then B + C in one launch: cum' is complete
         grads = [g.to(torch.float32) for g in _beta_gradients(plan, nets, betas, cum_fwd, scale)]
-        for phase in (6, 4):
-            engine.step_phase(bufs, p, io_t, phase)            # tbar = d loss / d transmission (of x / scale)
+        engine.step_phase(bufs, p, io_t, 4)                    # tbar = d loss / d transmission (of x / scale)
     finally:
         p.transpose = 0
-    return tbar * scale, grads
+    return tbar.mul_(scale), grads
 
 
 def _names_with_twins(plan, nets):
@@ -165,7 +172,8 @@ class HotPathStep(torch.autograd.Function):
         plan = engine.plan
         n = plan.host.n_agents
         out_s, out_i, out_t = (t.detach().to(torch.float32).clone().contiguous() for t in (susc, inf, time))
-        trans = torch.zeros(plan.host.n_ext_agents, dtype=torch.float32, device=plan.device)
+        n_ext = plan.host.n_ext_agents                # (one GPU: no halo slots, the step writes every transmission)
+        trans = (torch.empty if n_ext == n else torch.zeros)(n_ext, dtype=torch.float32, device=plan.device)
         new_inf = torch.empty(n, dtype=torch.float32, device=plan.device)
         bufs = AgentBuffers(plan, **fixed, infection_time=out_t, is_infected=out_i, susceptibility=out_s,
                             transmission=trans, current_stage=stage)
@@ -194,8 +202,9 @@ class HotPathStep(torch.autograd.Function):
             return None if g is None else g.detach().to(torch.float32).contiguous()
 
         g_susc, g_inf, g_time, g_new = f32(g_susc), f32(g_inf), f32(g_time), f32(g_new)
-        ones = torch.ones(n, dtype=torch.float32, device=dev)
-        scratch = torch.zeros(plan.host.n_ext_agents, dtype=torch.float32, device=dev)
+        ones = _ones(plan, n)
+        n_ext = plan.host.n_ext_agents                # (no halo slots on one GPU: the transposed pass overwrites all of it)
+        scratch = (torch.empty if n_ext == n else torch.zeros)(n_ext, dtype=torch.float32, device=dev)
         bufs = AgentBuffers(plan, **fixed, infection_time=time0, is_infected=inf0, susceptibility=ones,
                             transmission=scratch, current_stage=stage)
         p = params
@@ -267,7 +276,7 @@ class DistributedHotPathStep(torch.autograd.Function):
             return None if g is None else g.detach().to(torch.float32).contiguous()
 
         g_susc, g_inf, g_time, g_new = f32(g_susc), f32(g_inf), f32(g_time), f32(g_new)
-        ones = torch.ones(n, dtype=torch.float32, device=dev)
+        ones = _ones(plan, n)
         scratch = torch.zeros(n_ext, dtype=torch.float32, device=dev)
         scratch_q = torch.zeros(n_ext, dtype=torch.float32, device=dev) if p.has_quarantine else None
         bufs = AgentBuffers(plan, **fixed, infection_time=time0, is_infected=inf0, susceptibility=ones,
@@ -374,7 +383,7 @@ class NetworksForward(torch.autograd.Function):
         if plan.c.tiled is None or not bool(plan.c.tiled):
             raise NotImplementedError("the backward pass runs on the tiled layout")
         g = g_out.detach().to(torch.float32).contiguous()
-        ones = torch.ones(n, dtype=torch.float32, device=dev)
+        ones = _ones(plan, n)
         scratch = trans.clone()
         bufs = AgentBuffers(plan, susceptibility=ones, transmission=scratch, current_stage=env["stage"])
         if ctx.kept is not None:
