@@ -111,7 +111,14 @@ def run_case(npz, prefix, engine, device, tables):
 
     probs = torch.empty(A, device=device)
     ts = torch.empty(A, device=device)
-    engine.agent_gather(bufs, p, engine.io(not_infected_probs=probs, trans_susc=ts), sample=False)
+    if engine.plan.c.tiled:       # gj_step_io.agent_sums: the sums before the susceptibility factor (kept by a backward pass)
+        sums = torch.full((A,), float("nan"), device=device)
+        engine.agent_gather(bufs, p, engine.io(not_infected_probs=probs, trans_susc=ts, agent_sums=sums), sample=False)
+        assert torch.equal(ts, st["susceptibility"] * sums), prefix + "trans_susc == susceptibility * agent_sums"
+    else:                         # the CSR kernels multiply per term, as the reference does: no such output
+        with pytest.raises(Exception, match="plan"):
+            engine.agent_gather(bufs, p, engine.io(trans_susc=ts, agent_sums=torch.empty(A, device=device)), sample=False)
+        engine.agent_gather(bufs, p, engine.io(not_infected_probs=probs, trans_susc=ts), sample=False)
     ts_ref = np.zeros(A, dtype=np.float32)
     for name in sc["active"]:
         ts_ref += rec["ts/" + name]
@@ -182,6 +189,43 @@ def test_c100_policy_variants(device, layout):
     for v in str(npz["variants"]).split(","):
         flips += run_case(npz, v + "/", eng, device, None)
     assert flips == 0
+
+
+@pytest.mark.parametrize("layout", [l for l in LAYOUTS if l[0] == "tiled"][:8],
+                         ids=[i for l, i in zip(LAYOUTS, LAYOUT_IDS) if l[0] == "tiled"][:8])
+def test_agent_sums_do_not_depend_on_the_susceptibility(device, layout):
+    """gj_step_io.agent_sums is the per-agent sum BEFORE the susceptibility factor: the same bits whatever the
+    susceptibilities are (fractional, zero), and trans_susc is exactly susceptibility * agent_sums - in the fused step
+    as in the stand-alone pass 2.  (What the differentiable step keeps for its backward, autograd.py.)"""
+    from grad_june_amd.engine import AgentBuffers
+
+    npz = L.load_npz("june769_hot.npz")
+    world, tables = L.world_from(npz), L.tables_from(npz)
+    eng = engine_for(world, tables, device, layout)
+    rec = L.step_record(npz, "step2/")
+    sc = L.step_scalars(rec)
+    A = eng.plan.host.n_agents
+    has_q = sc["quarantine_thresholds"] is not None
+    p = eng.params(now=sc["now"], delta_time=sc["delta_time"], day_type=sc["day_type"], active=sc["active"],
+                   betas=sc["betas"], has_quarantine=has_q, q_threshold=L.q_threshold(sc["quarantine_thresholds"]))
+    gen = torch.Generator().manual_seed(5)
+    out = []
+    for susc in (None, torch.rand(A, generator=gen), torch.zeros(A)):
+        st = L.device_state(L.pre_state(rec), device)
+        if susc is not None:
+            st["susceptibility"] = susc.to(device)
+        s0 = st["susceptibility"].clone()
+        bufs = AgentBuffers(eng.plan, max_infectiousness=st["max_infectiousness"], shape=st["shape"], rate=st["rate"],
+                            shift=st["shift"], infection_time=st["infection_time"], is_infected=st["is_infected"],
+                            susceptibility=st["susceptibility"], transmission=st["transmission"],
+                            current_stage=st["current_stage"])
+        sums, ts = torch.empty(A, device=device), torch.empty(A, device=device)
+        noise = torch.from_numpy(rec["exp_noise"]).to(device).contiguous()
+        eng.step(bufs, p, eng.io(trans_susc=ts, agent_sums=sums, exp_noise=noise, new_infected=torch.empty(A, device=device)))
+        assert torch.equal(ts, s0 * sums)
+        out.append(sums)
+    assert float(out[0].abs().max()) > 0
+    assert torch.equal(out[0], out[1]) and torch.equal(out[0], out[2])
 
 
 @pytest.mark.parametrize("layout", LAYOUTS, ids=LAYOUT_IDS)
