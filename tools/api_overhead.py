@@ -111,23 +111,33 @@ def backward_cost(n=2_000_000, steps=8):
         d["agent"][k] = d["agent"][k].detach()
     for net in model.infection_networks.networks.values():
         net.log_beta.grad = None
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    series = []
-    for _ in range(steps):
-        next(timer)
-        model(d, timer)
-        series.append(d["agent"].is_infected.sum())
-    torch.cuda.synchronize()
-    tf = (time.perf_counter() - t0) / steps
-    loss = torch.stack(series).sum()
-    t0 = time.perf_counter()
-    loss.backward()
-    torch.cuda.synchronize()
-    tb = (time.perf_counter() - t0) / steps
-    grads = {k: float(v.log_beta.grad) for k, v in model.infection_networks.networks.items()}
-    print("differentiable run, %d agents: forward %.3f ms/step, backward %.3f ms/step; d cases/d log_beta = %s"
-          % (n, tf * 1e3, tb * 1e3, {k: round(v, 1) for k, v in grads.items()}))
+    # epochs of `steps` timesteps, as a calibration loop runs them: the first one also pays for the allocator's first
+    # blocks (a T-step graph keeps every step's tensors alive until its backward), the later ones reuse them
+    for epoch in range(3):
+        for k in ("susceptibility", "is_infected", "infection_time"):
+            d["agent"][k] = d["agent"][k].detach()
+        for k in ("current_stage", "next_stage", "time_to_next_stage"):
+            d["agent"].symptoms[k] = d["agent"].symptoms[k].detach()
+        for net in model.infection_networks.networks.values():
+            net.log_beta.grad = None
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        series = []
+        for _ in range(steps):
+            next(timer)
+            model(d, timer)
+            series.append(d["agent"].is_infected.sum())
+        torch.cuda.synchronize()
+        tf = (time.perf_counter() - t0) / steps
+        loss = torch.stack(series).sum()
+        t0 = time.perf_counter()
+        loss.backward()
+        torch.cuda.synchronize()
+        tb = (time.perf_counter() - t0) / steps
+        del series, loss
+        grads = {k: float(v.log_beta.grad) for k, v in model.infection_networks.networks.items()}
+        print("differentiable run, %d agents, epoch %d: forward %.3f ms/step, backward %.3f ms/step; d cases/d log_beta = %s"
+              % (n, epoch, tf * 1e3, tb * 1e3, {k: round(v, 1) for k, v in grads.items()}), flush=True)
 
 
 if __name__ == "__main__" and "--backward" in sys.argv:
