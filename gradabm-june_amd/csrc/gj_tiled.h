@@ -15,6 +15,7 @@ namespace gj {
 
 constexpr int kTileThreads = 1024;  // 16 waves: one workgroup per CU when the slice fills LDS
 constexpr int kTileWaves = kTileThreads / kWave;
+constexpr int kMaxSliceAgents = 20160;   // 8-byte sums + one flag bit per agent within 160 KiB of LDS
 constexpr int kUnroll = 8;          // 64-edge chunks a wave keeps in flight: phase D, and phase A with wide descriptors
 #ifndef GJ_UNROLL_NARROW
 #define GJ_UNROLL_NARROW 16
@@ -29,6 +30,10 @@ constexpr int kVenueUnroll = GJ_VENUE_UNROLL;  // 8-slot groups a lane keeps in 
 #define GJ_VENUE_UNROLL_C GJ_VENUE_UNROLL
 #endif
 constexpr int kVenueUnrollC = GJ_VENUE_UNROLL_C;  // same, phase C
+#ifndef GJ_CUM_BATCH
+#define GJ_CUM_BATCH 8
+#endif
+constexpr int kCumBatch = GJ_CUM_BATCH;        // venues per lane whose p_contact loads are in flight together (cum write-out)
 
 // LDS float atomics run at 0.33 lanes/clk/CU on gfx950 (measured, tools/microbench/lds_atomics.hip)
 // against 4.9 for ds_add_u64 and 7.3 for ds_add_u32, so the per-venue and per-agent sums are kept
@@ -114,7 +119,17 @@ __device__ __forceinline__ void load_slice(float* lds, const float* __restrict__
   const int n4 = n_local >> 2;   // base is a multiple of 64 floats: 16-byte aligned
   const float4* s4 = reinterpret_cast<const float4*>(src + base);
   float4* d4 = reinterpret_cast<float4*>(lds);
-  for (int i = tid; i < n4; i += kTileThreads) d4[i] = s4[i];
+  // all of a lane's loads are issued before the first LDS write: as a rolled loop (load, wait, write) the slice arrived
+  // in five dependent memory round trips at the head of every workgroup
+  constexpr int kQ = (kMaxSliceAgents + 4 * kTileThreads - 1) / (4 * kTileThreads);
+  if (n4 > 0) {
+    float4 v[kQ];
+#pragma unroll
+    for (int u = 0; u < kQ; ++u) v[u] = s4[min(tid + u * kTileThreads, n4 - 1)];      // clamped, unconditional
+#pragma unroll
+    for (int u = 0; u < kQ; ++u)
+      if (tid + u * kTileThreads < n4) d4[tid + u * kTileThreads] = v[u];
+  }
   for (int i = (n4 << 2) + tid; i < n_local; i += kTileThreads) lds[i] = src[base + i];
 }
 
@@ -729,20 +744,42 @@ __global__ __launch_bounds__(kTileThreads, GJ_VENUE_WAVES_PER_SIMD) void k_tile_
       }
     }
     __syncthreads();
-    for (int k = 0; k < nk; ++k) {
-      const float beta = T.beta[k];
-      for (int lv = tid; lv < nv; lv += kTileThreads) {
-        const float c = (beta * T.v_pc[v0 + lv]) * fx_read<kFxVenue>(sums, vflags, k * nv + lv);
-        T.cum[(int64_t)(v0 + lv) * T.stride + k] = c;
-        cumf[2 * (k * nv + lv)] = c;      // low half of the lane's own 8-byte slot
+    // cum = (beta * p_contact) * sum per venue and network.  A lane's p_contact loads are issued kCumBatch at a time:
+    // one venue per iteration (load, wait, convert, store) made this write-out a chain of nv / 1024 = 16 memory round
+    // trips per workgroup - most of what a household item (25 us) spent its time on.
+    for (int l0 = tid; l0 < nv; l0 += kCumBatch * kTileThreads) {
+      float pc[kCumBatch];
+#pragma unroll
+      for (int u = 0; u < kCumBatch; ++u) pc[u] = T.v_pc[v0 + min(l0 + u * kTileThreads, nv - 1)];   // clamped, unconditional
+      for (int k = 0; k < nk; ++k) {
+        const float beta = T.beta[k];
+#pragma unroll
+        for (int u = 0; u < kCumBatch; ++u) {
+          const int lv = l0 + u * kTileThreads;
+          if (lv < nv) {
+            const float c = (beta * pc[u]) * fx_read<kFxVenue>(sums, vflags, k * nv + lv);
+            T.cum[(int64_t)(v0 + lv) * T.stride + k] = c;
+            cumf[2 * (k * nv + lv)] = c;      // low half of the lane's own 8-byte slot
+          }
+        }
       }
     }
     if (B.mode == 1 || T.direct) return;
   } else {
     if (T.direct) return;
-    for (int k = 0; k < nk; ++k)
-      for (int lv = tid; lv < nv; lv += kTileThreads)
-        cumf[2 * (k * nv + lv)] = T.cum[(int64_t)(v0 + lv) * T.stride + k];
+    for (int k = 0; k < nk; ++k) {
+      for (int l0 = tid; l0 < nv; l0 += kCumBatch * kTileThreads) {
+        float c[kCumBatch];
+#pragma unroll
+        for (int u = 0; u < kCumBatch; ++u)
+          c[u] = T.cum[(int64_t)(v0 + min(l0 + u * kTileThreads, nv - 1)) * T.stride + k];
+#pragma unroll
+        for (int u = 0; u < kCumBatch; ++u) {
+          const int lv = l0 + u * kTileThreads;
+          if (lv < nv) cumf[2 * (k * nv + lv)] = c[u];
+        }
+      }
+    }
   }
   __syncthreads();
   // C: per slot, the venue's cum (leisure: weighted over the set's networks by the agent's class)
@@ -989,7 +1026,6 @@ __global__ __launch_bounds__(kThreads) void k_presum_reduce(const PReduceArgs R)
 // ---- phase D: per slice, accumulate the edges' values per agent in LDS; epilogue a7-a9 -----------
 constexpr int GJ_MAX_DIRECT = 6;
 constexpr int kClassWeightFloats = GJ_MAX_NETS_PER_SET * 200;
-constexpr int kMaxSliceAgents = 20160;   // 8-byte sums + one flag bit per agent within 160 KiB of LDS
 struct TDirect {          // a set whose pass 2 is taken straight from the venues' cum
   const uint16_t* ell;    // [planes][owned agents, padded to slices][K] venue ids, 0xFFFF = none
   const float* cum;       // [V * stride]
@@ -1347,8 +1383,16 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
     }
     __syncthreads();
     if (pass == 0 && D.has_q) {
-      for (int i = tid; i < n_local; i += kTileThreads)
-        if (!(D.stage[base + i] < D.q_thr)) lds_acc[i] = 0;
+      // (a lane's stage loads are issued ten at a time: one per iteration made this a chain of 20 memory round trips)
+      constexpr int kStageBatch = 10;
+      for (int i0 = tid; i0 < n_local; i0 += kStageBatch * kTileThreads) {
+        float stg[kStageBatch];
+#pragma unroll
+        for (int u = 0; u < kStageBatch; ++u) stg[u] = D.stage[base + min(i0 + u * kTileThreads, n_local - 1)];
+#pragma unroll
+        for (int u = 0; u < kStageBatch; ++u)
+          if (i0 + u * kTileThreads < n_local && !(stg[u] < D.q_thr)) lds_acc[i0 + u * kTileThreads] = 0;
+      }
       __syncthreads();
     }
   }
