@@ -89,6 +89,35 @@ __device__ __forceinline__ void put32(T* base, int idx, T v) {
   *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + (uint64_t)((uint32_t)idx * (uint32_t)sizeof(T))) = v;
 }
 
+// Non-temporal accesses for the streams that are written once and read once per step and are larger than the caches:
+// the per-edge workspace `val` (B's loads, C's stores, D's loads), the ELL rows of the direct form, the transmission
+// kernel's parameter arrays.  Measured per stream (tools/ab.py, round 3, one call each): together -12 ... -24 us per C3
+// step (venue launch -10 %, transmission -10 %).  NOT for phase A's 4-byte scattered stores (partial lines: 118 -> 176 us,
+// although the venue launch that reads them gains 33 us), nor for the 2-byte index streams, whose unaligned 64-element
+// pieces share cache lines between consecutive loads (a_la in phase A: 118 -> 134 us).
+typedef float gj_v4f __attribute__((ext_vector_type(4)));
+typedef unsigned int gj_v4u __attribute__((ext_vector_type(4)));
+typedef unsigned int gj_v2u __attribute__((ext_vector_type(2)));
+template <typename T>
+__device__ __forceinline__ T at32nt(const T* base, int idx) {
+  return __builtin_nontemporal_load(reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (uint64_t)((uint32_t)idx * (uint32_t)sizeof(T))));
+}
+template <typename T>
+__device__ __forceinline__ void put32nt(T* base, int idx, T v) {
+  __builtin_nontemporal_store(v, reinterpret_cast<T*>(reinterpret_cast<char*>(base) + (uint64_t)((uint32_t)idx * (uint32_t)sizeof(T))));
+}
+__device__ __forceinline__ uint4 load_nt(const uint4* p) {
+  const gj_v4u v = __builtin_nontemporal_load(reinterpret_cast<const gj_v4u*>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 load_nt(const float4* p) {
+  const gj_v4f v = __builtin_nontemporal_load(reinterpret_cast<const gj_v4f*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void store_nt(float4* p, float4 x) {
+  gj_v4f v = {x.x, x.y, x.z, x.w};
+  __builtin_nontemporal_store(v, reinterpret_cast<gj_v4f*>(p));
+}
 struct TSetA {            // what phases A and D need of one set
   const uint16_t* a_la;
   const int32_t* tile_sptr;
@@ -317,7 +346,7 @@ __device__ __forceinline__ void gather_set(const TSetA& T, fx_t* lds_acc, uint32
     for (int u = 0; u < kU; ++u) {
       const int i = seg0 + (c + u) * kWave + lane;
       const bool ok = (c + u < n_chunks) && (i < seg1);
-      v[u] = at32(T.val, ok ? slot[u] : 0);
+      v[u] = at32nt(T.val, ok ? slot[u] : 0);
     }
   };
   auto add = [&](int c, const int (&la)[kU], const float (&v)[kU]) {
@@ -691,8 +720,8 @@ __global__ __launch_bounds__(kTileThreads, GJ_VENUE_WAVES_PER_SIMD) void k_tile_
       for (int u = 0; u < kVenueUnroll; ++u) {     // clamped, unconditional: all loads in flight together
         const int gu = min(g + u * kTileThreads, g1 - 1);
         raw[u] = lv8[gu];
-        xa[u] = val4[2 * gu];
-        xb[u] = val4[2 * gu + 1];
+        xa[u] = load_nt(val4 + 2 * gu);           // read once, written by phase A: non-temporal
+        xb[u] = load_nt(val4 + 2 * gu + 1);
         craw[u] = T.leisure ? cls8[gu] : make_uint2(0u, 0u);
       }
 #pragma unroll
@@ -817,8 +846,8 @@ __global__ __launch_bounds__(kTileThreads, GJ_VENUE_WAVES_PER_SIMD) void k_tile_
           r[q] = (lv != 0xFFFF) ? a : 0.0f;
         }
       }
-      val4[2 * gu] = make_float4(r[0], r[1], r[2], r[3]);
-      val4[2 * gu + 1] = make_float4(r[4], r[5], r[6], r[7]);
+      store_nt(val4 + 2 * gu, make_float4(r[0], r[1], r[2], r[3]));      // whole lines, read once by phase D
+      store_nt(val4 + 2 * gu + 1, make_float4(r[4], r[5], r[6], r[7]));
     }
   }
 }
@@ -1137,7 +1166,7 @@ __device__ __forceinline__ void direct_load(const TileDArgs& D, const TDirect& T
     // for its 32 workgroups, i.e. HBM traffic)
     asm volatile("" : "+v"(q));
     if (!T.win_lo) {
-      const uint4 r = *reinterpret_cast<const uint4*>(ell + 8u * q);
+      const uint4 r = load_nt(reinterpret_cast<const uint4*>(ell + 8u * q));
       b.w[u][0] = r.x;
       b.w[u][1] = r.y;
       b.w[u][2] = r.z;

@@ -145,18 +145,18 @@ __global__ __launch_bounds__(kThreads) void k_transmission(
   const int64_t n4 = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    const float4 f = reinterpret_cast<const float4*>(inf)[i];
+    const float4 f = load_nt(reinterpret_cast<const float4*>(inf) + i);      // (non-temporal: read once per step, see gj_tiled.h)
     float4 r = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     // is_infected == 0 makes the product 0 whatever the profile (finite for every agent the reference gives a
     // finite value for), so the five parameter streams are only read where someone is infected: early in an
     // epidemic most 128-byte lines of them are never touched
     unsigned m = (f.x != 0.0f ? 1u : 0u) | (f.y != 0.0f ? 2u : 0u) | (f.z != 0.0f ? 4u : 0u) | (f.w != 0.0f ? 8u : 0u);
     if (m) {
-      const float4 a = reinterpret_cast<const float4*>(mx)[i];
-      const float4 b = reinterpret_cast<const float4*>(shp)[i];
-      const float4 c = reinterpret_cast<const float4*>(rt)[i];
-      const float4 d = reinterpret_cast<const float4*>(sh)[i];
-      const float4 e = reinterpret_cast<const float4*>(t_inf)[i];
+      const float4 a = load_nt(reinterpret_cast<const float4*>(mx) + i);
+      const float4 b = load_nt(reinterpret_cast<const float4*>(shp) + i);
+      const float4 c = load_nt(reinterpret_cast<const float4*>(rt) + i);
+      const float4 d = load_nt(reinterpret_cast<const float4*>(sh) + i);
+      const float4 e = load_nt(reinterpret_cast<const float4*>(t_inf) + i);
       // The profile (lgammaf ~420, powf ~200, two expf: ~690 instructions) is evaluated by a wave for all 64 lanes
       // whenever one of them needs it.  Each lane therefore takes ITS infected agents one after the other: a wave makes
       // as many evaluations as its busiest lane has infected agents (at 1 % prevalence ~1 instead of ~2 with one
