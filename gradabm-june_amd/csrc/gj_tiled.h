@@ -252,7 +252,7 @@ __device__ __forceinline__ void batch_slots(const TSetA& T, const int word, int 
 #ifndef GJ_SCATTER_PIPELINE
 #define GJ_SCATTER_PIPELINE 1
 #endif
-template <bool WIDE, int kU>
+template <bool WIDE, int kU, bool NT = false>
 __device__ __forceinline__ void scatter_batches(const TSetA& T, const float* lds_x, int s, int wave, int lane) {
   const int row = s * T.J;
   const int seg0 = T.tile_sptr[row], seg1 = T.tile_sptr[row + T.J];
@@ -271,7 +271,9 @@ __device__ __forceinline__ void scatter_batches(const TSetA& T, const float* lds
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
       const int i = seg0 + (c + u) * kWave + lane;
-      if ((c + u < n_chunks) && (i < seg1)) put32(T.val, slot[u], lds_x[la[u]]);
+      if ((c + u < n_chunks) && (i < seg1)) {
+        if (NT) put32nt(T.val, slot[u], lds_x[la[u]]); else put32(T.val, slot[u], lds_x[la[u]]);
+      }
     }
   };
   int c0 = wave * kU;
@@ -303,10 +305,17 @@ __device__ __forceinline__ void scatter_batches(const TSetA& T, const float* lds
 // phase A 0.182 -> 0.149 ms); on short segments they lose (C2, 309 chunks: 0.041 -> 0.071 ms), so the batch size
 // is chosen per slice and set (wave-uniform).
 constexpr int kLongSegmentChunks = 384;
+constexpr int kNtTileEdges = 1024;
 template <bool WIDE>
 __device__ __forceinline__ void scatter_set(const TSetA& T, const float* lds_x, int s, int wave, int lane) {
   const int n_chunks = T.chunk_ptr[s + 1] - T.chunk_ptr[s];
-  if (!WIDE && kUnrollNarrow != kUnroll && n_chunks >= kLongSegmentChunks) {
+  // Non-temporal stores where this slice's tiles of the set are long (mean >= kNtTileEdges edges): a tile is one
+  // contiguous run of `val`, and the partial lines at the ends of a run's pieces are what makes such stores slow
+  // (every set non-temporal: phase A 118 -> 176 us; C3's schools / universities / leisure / care homes only: -3 us, and
+  // -2 us in the venue launch that reads them - its loads no longer meet phase A's dirty lines on their way out of L2)
+  if (!WIDE && kUnrollNarrow != kUnroll && n_chunks >= kLongSegmentChunks && n_chunks * kWave >= kNtTileEdges * T.J) {
+    scatter_batches<WIDE, WIDE ? kUnroll : kUnrollNarrow, true>(T, lds_x, s, wave, lane);
+  } else if (!WIDE && kUnrollNarrow != kUnroll && n_chunks >= kLongSegmentChunks) {
     scatter_batches<WIDE, WIDE ? kUnroll : kUnrollNarrow>(T, lds_x, s, wave, lane);
   } else {
     scatter_batches<WIDE, kUnroll>(T, lds_x, s, wave, lane);
