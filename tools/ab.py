@@ -82,7 +82,8 @@ def main():
             with open(a.out, "a") as f:
                 f.write(json.dumps(row) + "\n")
             km = " ".join(f"{k[:9]}={v * 1e3:6.1f}" for k, v in d["kernel_ms"].items())
-            print(f"[r{rnd}] {label:24s} {d['ms_per_step'] * 1e3:7.1f} us/step   {km}   infected={row['checksum']['infected']:.0f}",
+            full = f"   full step {row['full_ms'] * 1e3:7.1f}" if row["full_ms"] else ""
+            print(f"[r{rnd}] {label:24s} {d['ms_per_step'] * 1e3:7.1f} us/step   {km}{full}   infected={row['checksum']['infected']:.0f}",
                   flush=True)
     print("\nbest of rounds:")
     for label, _, _ in vs:
