@@ -85,6 +85,8 @@ def parse():
     ap.add_argument("--backward", action="store_true",
                     help="row f3: time forward and backward of a T-step differentiable run (the eight log_beta as "
                          "nn.Parameter, loss = cases of the last step) instead of the forward-only hot path")
+    ap.add_argument("--tile-pad", type=int, default=1,
+                    help="experiment (with --host-compile): pad every tile to a multiple of this many edges in both orders")
     ap.add_argument("--backward-recompute", action="store_true",
                     help="--backward: the memory-lean form (a step keeps its pre-state only; the backward recomputes the "
                          "forward's two sparse passes)")
@@ -591,6 +593,8 @@ def main():
                 kw["runs"] = False
             if args.presum == "on":
                 kw["presum"] = True
+            if args.tile_pad > 1:
+                kw["tile_pad"] = args.tile_pad
             if args.sv_max:
                 kw["sv_max"] = args.sv_max
             if args.eb_target:

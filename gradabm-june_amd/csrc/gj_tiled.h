@@ -305,7 +305,10 @@ __device__ __forceinline__ void scatter_batches(const TSetA& T, const float* lds
 // phase A 0.182 -> 0.149 ms); on short segments they lose (C2, 309 chunks: 0.041 -> 0.071 ms), so the batch size
 // is chosen per slice and set (wave-uniform).
 constexpr int kLongSegmentChunks = 384;
-constexpr int kNtTileEdges = 1024;
+#ifndef GJ_NT_TILE_EDGES
+#define GJ_NT_TILE_EDGES 1024
+#endif
+constexpr int kNtTileEdges = GJ_NT_TILE_EDGES;   // (64 with tiles padded to 16 edges: tiling.build_tiled(tile_pad=16), experiment)
 template <bool WIDE>
 __device__ __forceinline__ void scatter_set(const TSetA& T, const float* lds_x, int s, int wave, int lane) {
   const int n_chunks = T.chunk_ptr[s + 1] - T.chunk_ptr[s];

@@ -268,7 +268,7 @@ def agent_class_of(age, sex) -> np.ndarray:
 def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
                  n_ext_agents: Optional[int] = None, block_order: str = "interleave",
                  layout: str = "csr", leisure_sets: Sequence[str] = ("leisure",),
-                 sv_max: int = TL.SV_MAX, eb_target: Optional[int] = None, slices=None,
+                 sv_max: int = TL.SV_MAX, eb_target: Optional[int] = None, slices=None, tile_pad: int = 1,
                  nets_per_set: Optional[Dict[str, int]] = None, progress=None,
                  desc_wide: Optional[bool] = None, device=None, direct=None, runs=None, presum=None,
                  desc_explicit: Optional[bool] = None) -> HostPlan:
@@ -326,6 +326,8 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
             if runs is not False and (forced_run or (plan_direct is None and runs is None)) and k == 1 \
                     and name not in leisure_sets:
                 rf, es_t = _split_runs(name, es, n_agents, hs.n_venues, SA, device, forced_run)
+            if device is not None and tile_pad > 1:
+                raise NotImplementedError("tile_pad is an experiment of the numpy compile (compile_plan without device=)")
             if device is not None:
                 from .tiling_native import build_tiled_native
 
@@ -336,7 +338,8 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
             else:
                 hs.tiled = TL.build_tiled(name, es_t["agent"], es_t["venue"], hs.n_venues, hs.v_pcontact, S, SA,
                                           agent_class=use_cls, sv_max=max(16, sv_max // max(1, k)),
-                                          eb_target=eb_target, wide=desc_wide, explicit=desc_explicit)
+                                          eb_target=eb_target, wide=desc_wide, explicit=desc_explicit,
+                                          tile_pad=tile_pad)
             t = hs.tiled
             if rf is not None:
                 t.runs = _finish_runs(rf, t, n_agents, SA, device)

@@ -170,7 +170,12 @@ def walk_share(t: "TiledEdgeSet") -> float:
 def build_tiled(name: str, agent_index, venue_index, n_venues: int, v_pcontact: np.ndarray,
                 n_slices: int, slice_agents: int, agent_class: Optional[np.ndarray] = None,
                 sv_max: int = SV_MAX, eb_target: int = EB_TARGET, wide: Optional[bool] = None,
-                explicit: Optional[bool] = None) -> TiledEdgeSet:
+                explicit: Optional[bool] = None, tile_pad: int = 1) -> TiledEdgeSet:
+    """``tile_pad`` (experiment, host compile only - DESIGN.md section 8, "the next lever"): every tile's run is padded
+    to a multiple of ``tile_pad`` positions in BOTH orders, so that every piece of a 64-edge chunk starts and ends on
+    a 64-byte boundary of ``val`` (tile_pad = 16).  Pad positions: local agent 0 in ``a_la``, local venue 0xFFFF in
+    ``e_lv`` - phase B skips them, phase C writes 0 into them, phase D adds that 0 to agent 0 of the slice.  Sets
+    whose tiles hold fewer than ``TILE_PAD_MIN_MEAN`` edges on average are left unpadded."""
     agent = np.asarray(agent_index, dtype=np.int64).ravel()
     venue = np.asarray(venue_index, dtype=np.int64).ravel()
     E = len(agent)
@@ -197,8 +202,13 @@ def build_tiled(name: str, agent_index, venue_index, n_venues: int, v_pcontact: 
     key = ((j * S + s) * 65536 + lv) * 65536 + la
     order = np.argsort(key, kind="stable")
     tile_of = (j * S + s)[order]                       # block-major tile id per (unpadded) position
-    tile_len_js = np.bincount(tile_of, minlength=J * S).reshape(J, S)
-    upos_js = np.zeros(J * S + 1, dtype=np.int64)      # unpadded block-major prefix
+    real_len_js = np.bincount(tile_of, minlength=J * S).reshape(J, S)
+    rpos_js = np.zeros(J * S + 1, dtype=np.int64)      # prefix of the real tile lengths: position in the sorted order
+    np.cumsum(real_len_js.reshape(-1), out=rpos_js[1:])
+    if tile_pad > 1 and E < TILE_PAD_MIN_MEAN * max(1, int((real_len_js > 0).sum())):
+        tile_pad = 1                                   # tiles of a few edges: padding would multiply the set
+    tile_len_js = -(-real_len_js // tile_pad) * tile_pad     # a tile's run in both orders (== real_len_js unpadded)
+    upos_js = np.zeros(J * S + 1, dtype=np.int64)      # block-major prefix of the tiles' runs, blocks unpadded
     np.cumsum(tile_len_js.reshape(-1), out=upos_js[1:])
     # every block occupies a multiple of PAD slots so that phases B/C can use 16-byte accesses;
     # the pad slots at a block's end carry the sentinel local venue 0xFFFF
@@ -206,7 +216,7 @@ def build_tiled(name: str, agent_index, venue_index, n_venues: int, v_pcontact: 
     blk_slots = -(-blk_len // PAD) * PAD
     blk_start = np.zeros(J + 1, dtype=np.int64)
     np.cumsum(blk_slots, out=blk_start[1:])
-    blk_ustart = np.concatenate([upos_js[0:J * S:S], [E]])
+    blk_ustart = np.concatenate([upos_js[0:J * S:S], [upos_js[-1]]])
     shift = np.repeat(blk_start[:-1] - blk_ustart[:-1], S)          # per tile (j, s): padded - unpadded
     jpos_js = np.concatenate([upos_js[:-1] + shift, [blk_start[-1]]])
     n_slots = int(blk_start[-1])
@@ -217,11 +227,12 @@ def build_tiled(name: str, agent_index, venue_index, n_venues: int, v_pcontact: 
     # slice-major position of every block-major position
     tj = tile_of // S
     ts = tile_of - tj * S
-    within = np.arange(E, dtype=np.int64) - upos_js[tile_of]
+    within = np.arange(E, dtype=np.int64) - rpos_js[tile_of]
     pos_sm = sptr[ts * J + tj] + within
     pos_bm = jpos_js[tile_of] + within                              # padded block-major slot
     la_bm = la[order]
-    a_la = np.empty(E, dtype=np.uint16)
+    E_real, E = E, int(sptr[-1])                       # from here on E counts slice-major POSITIONS (pads included)
+    a_la = np.zeros(E, dtype=np.uint16)                # (pad positions: local agent 0)
     a_la[pos_sm] = la_bm.astype(np.uint16)
     e_lv = np.full(n_slots, 0xFFFF, dtype=np.uint16)
     e_lv[pos_bm] = lv[order].astype(np.uint16)
@@ -256,8 +267,9 @@ def build_tiled(name: str, agent_index, venue_index, n_venues: int, v_pcontact: 
         if explicit is None:
             explicit = bool(len(nseg)) and float((nseg > WIDE_SEGMENTS).mean()) > EXPLICIT_MIN_SHARE
     if explicit:
-        slot_idx = np.empty(E, dtype=np.int32)
-        slot_idx[pos_sm] = pos_bm.astype(np.int32)
+        # (every slice-major position, pads included: position p of tile t sits at tile_jpos[t] + (p - sptr[t]))
+        t_of = np.searchsorted(sptr, np.arange(E, dtype=np.int64), side="right") - 1
+        slot_idx = (jpos_sj.reshape(-1)[t_of] + (np.arange(E, dtype=np.int64) - sptr[t_of])).astype(np.int32)
     return TiledEdgeSet(
         name=name, n_venues=n_venues, n_edges=E, n_slices=S, n_blocks=J,
         blk_v0=blk_v0.astype(np.int32), blk_e0=blk_start.astype(np.int32),
@@ -283,6 +295,7 @@ def build_tiled(name: str, agent_index, venue_index, n_venues: int, v_pcontact: 
 # Per primary edge ~10 bytes per step instead of ~25.  The remaining edges of the set (an agent's other venues, edges
 # of halo agents) stay in the tiled arrays.  In a world of the reference's kind - every person lives in exactly one
 # household - the household set leaves the tiled path entirely.
+TILE_PAD_MIN_MEAN = 64     # build_tiled(tile_pad > 1): mean edges per non-empty tile below which a set stays unpadded
 RUN_MIN_SHARE = 0.25        # primary edges / owned edges below which the run form is not worth its two extra arrays
 RUN_MAX_WINDOW = 32768      # venues a slice's window may span (LDS floats of phase D's table region; ids are 16-bit)
 

@@ -35,12 +35,13 @@ LAYOUTS = [("csr", {}), ("tiled", dict(direct=False)),
            ("tiled", dict(slices="small", direct=("school", "leisure", "household"))),
            ("tiled", dict(sv_max=16, eb_target=64, slices="small", desc_explicit=True, direct=False)),
            ("tiled", dict(sv_max=64, eb_target=512, slices="small", desc_explicit=True)),
+           ("tiled", dict(direct=False, tile_pad=16)), ("tiled", dict(sv_max=256, eb_target=4096, tile_pad=16)),
            ("tiled", dict(presum=True)),
            ("tiled", dict(sv_max=64, eb_target=512, slices="small", direct_table_floats=24, presum=True))]
 LAYOUT_IDS = ["csr", "tiled", "tiled-small-tiles", "tiled-small-tiles-wide-desc", "tiled-tiny-tiles-wide-desc",
               "tiled-split-epilogue", "tiled-direct", "tiled-direct-small-tiles-venue-groups",
               "tiled-direct-split-epilogue-venue-groups", "tiled-direct-some-sets", "tiled-tiny-tiles-explicit-slots",
-              "tiled-direct-small-tiles-explicit-slots", "tiled-direct-pass1-direct",
+              "tiled-direct-small-tiles-explicit-slots", "tiled-padded-to-sectors", "tiled-direct-blocks-padded-to-sectors", "tiled-direct-pass1-direct",
               "tiled-direct-small-tiles-venue-groups-pass1-direct"]
 
 

@@ -90,6 +90,44 @@ def test_layout_and_emulation(A, V, E, sa, svmax, eb, wide):
     assert np.allclose(acc_l, ref_l2, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("A,V,E,sa,svmax,eb", [(5000, 40, 60000, 512, 16, 20000), (3000, 6, 30000, 128, 65535, 1 << 30),
+                                               (2000, 3000, 6000, 64, 16, 16)])
+@pytest.mark.parametrize("explicit", [None, True], ids=["descriptors", "explicit-slots"])
+def test_tiles_padded_to_whole_sectors(A, V, E, sa, svmax, eb, explicit):
+    """build_tiled(tile_pad=16), the experiment of DESIGN section 8: every tile's run is a multiple of 16 positions in both
+    orders (pads: local agent 0 / local venue 0xFFFF), so every piece of a 64-edge chunk covers whole 64-byte sectors
+    of `val`; both passes give what the unpadded layout gives; a set of tiny tiles is left alone."""
+    rng = np.random.default_rng(A + E)
+    agent, venue = random_set(rng, A, V, E)
+    S = -(-A // sa)
+    pc = rng.random(V).astype(np.float32)
+    cls = rng.integers(0, 200, A).astype(np.uint8)
+    kw = dict(agent_class=cls, sv_max=svmax, eb_target=eb, explicit=explicit, wide=True if explicit else None)
+    t0 = build_tiled("x", agent, venue, V, pc, S, sa, **kw)
+    t = build_tiled("x", agent, venue, V, pc, S, sa, tile_pad=16, **kw)
+    J = t.n_blocks
+    lens = np.diff(t.tile_sptr)
+    tiny = E < 64 * (np.diff(t0.tile_sptr) > 0).sum()
+    if tiny:                                      # mean tile below 64 edges: unpadded, the same arrays
+        assert np.array_equal(t.a_la, t0.a_la) and np.array_equal(t.e_lv, t0.e_lv)
+        return
+    assert (lens % 16 == 0).all() and (t.tile_jpos % 16 == 0).all() and (t.tile_sptr % 16 == 0).all()
+    assert (t.e_lv != 0xFFFF).sum() == E and t.n_edges == t.tile_sptr[-1] == len(t.a_la) and t.n_edges < E + 16 * S * J
+    # a chunk's pieces: starts and lengths are multiples of 16 (whole sectors of 4-byte values)
+    if t.slot_idx is not None:
+        assert len(t.slot_idx) == t.n_edges
+        brk = np.flatnonzero(np.diff(t.slot_idx) != 1) + 1
+        assert (brk % 16 == 0).all() and (t.slot_idx[np.concatenate([[0], brk])] % 16 == 0).all()
+    x = rng.random(S * sa).astype(np.float32)
+    tab = rng.random(200).astype(np.float32)
+    for table in (None, tab):
+        _, cum0 = emulate_pass1(t0, x, sa, beta=0.7, table=table)
+        _, cum = emulate_pass1(t, x, sa, beta=0.7, table=table)
+        assert np.array_equal(cum, cum0)
+        assert np.allclose(emulate_pass2(t, cum, A, sa, weight_table=table), emulate_pass2(t0, cum0, A, sa, weight_table=table),
+                           rtol=1e-6, atol=1e-7)
+
+
 def test_empty_set_and_slice_choice():
     t = build_tiled("e", np.zeros(0, np.int64), np.zeros(0, np.int64), 0, np.zeros(0, np.float32), 4, 64)
     assert t.n_blocks == 0 and t.n_edges == 0
