@@ -1371,9 +1371,17 @@ __device__ __forceinline__ void load_quad(const float* p, int64_t a0, int n_ok, 
     for (int j = 0; j < 4; ++j) v[j] = (j < n_ok) ? p[a0 + j] : 0.0f;
   }
 }
+// NT: a dense per-agent OUTPUT of the step (probabilities, new cases, sums) - nobody reads it before the next launches
+// have streamed hundreds of MB, so it is stored non-temporally instead of sitting in L2 as 80 MB of dirty lines that the
+// transmission kernel and phase A of the next step then meet (C3: -6 ... -12 us per step, three rounds of tools/ab.py)
+template <bool NT = false>
 __device__ __forceinline__ void store_quad(float* p, int64_t a0, int n_ok, bool vec, const float (&v)[4]) {
   if (vec && n_ok >= 4) {
-    *reinterpret_cast<float4*>(p + a0) = make_float4(v[0], v[1], v[2], v[3]);
+    if (NT) {
+      store_nt(reinterpret_cast<float4*>(p + a0), make_float4(v[0], v[1], v[2], v[3]));
+    } else {
+      *reinterpret_cast<float4*>(p + a0) = make_float4(v[0], v[1], v[2], v[3]);
+    }
   } else {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -1488,7 +1496,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
 #pragma unroll
     for (int m = 0; m < kQ; ++m) {
       const int i0 = 4 * (tid + m * kTileThreads);
-      if (i0 < n_local) store_quad(D.agent_sums, base + i0, n_local - i0, vec, acc[m]);
+      if (i0 < n_local) store_quad<true>(D.agent_sums, base + i0, n_local - i0, vec, acc[m]);
     }
   }
   if (D.acc_scratch) {   // split form: hand the per-agent sums to k_tile_epilogue (runs at full occupancy)
@@ -1540,9 +1548,9 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
 #pragma unroll
     for (int j = 0; j < 4; ++j) p[j] = not_infected_prob(ts[j], D.dt);
 #ifndef GJ_DIAG_STAMPS
-    if (D.trans_susc) store_quad(D.trans_susc, a0, n_ok, vec, ts);
+    if (D.trans_susc) store_quad<true>(D.trans_susc, a0, n_ok, vec, ts);
 #endif
-    if (D.not_infected_probs) store_quad(D.not_infected_probs, a0, n_ok, vec, p);
+    if (D.not_infected_probs) store_quad<true>(D.not_infected_probs, a0, n_ok, vec, p);
     if (!D.sample) continue;
     float nw[4], th[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (own_noise) {
@@ -1572,7 +1580,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
       }
       if (j < n_ok && nw[j] != 0.0f) infected |= 1u << (4 * m_run + j);
     }
-    if (D.new_infected) store_quad(D.new_infected, a0, n_ok, vec, nw);
+    if (D.new_infected) store_quad<true>(D.new_infected, a0, n_ok, vec, nw);
     // a9 where nw is neither 0 nor 1 (a NaN probability under injected noise): on the spot, with the value itself
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
