@@ -97,6 +97,7 @@ __device__ __forceinline__ void put32(T* base, int idx, T v) {
 // pieces share cache lines between consecutive loads (a_la in phase A: 118 -> 134 us).
 typedef float gj_v4f __attribute__((ext_vector_type(4)));
 typedef unsigned int gj_v4u __attribute__((ext_vector_type(4)));
+typedef unsigned int gj_v2u __attribute__((ext_vector_type(2)));
 template <typename T>
 __device__ __forceinline__ T at32nt(const T* base, int idx) {
   return __builtin_nontemporal_load(reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (uint64_t)((uint32_t)idx * (uint32_t)sizeof(T))));
