@@ -50,8 +50,11 @@ def main():
     kw = dict(a.split("=") for a in sys.argv[3:])
     reorder = kw.pop("reorder", "household")
     kw = {k: int(v) for k, v in kw.items()}
-    if "desc_explicit" in kw:
-        kw["desc_explicit"] = bool(kw["desc_explicit"])
+    for flag in ("desc_explicit", "direct", "runs"):      # booleans: 0 / 1
+        if flag in kw:
+            kw[flag] = bool(kw[flag])
+            if flag != "desc_explicit" and kw[flag]:
+                del kw[flag]                               # (True = the compile's own choice)
     entry.build()
     world = make_world(preset, n_agents=agents)
     if reorder != "none":
