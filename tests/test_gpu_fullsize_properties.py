@@ -9,8 +9,11 @@
 
 C2 (1 M agents, 15 M edges) and C3 (10 M agents, 120 M network-edges: the world bench.py times, same seed) run at
 full size; C4's partitioning runs as 8 agent partitions of that C3 world on the one GPU; C5 (power-law venues up to
-50 000 attendees) at 1 M agents here and at 20 M agents in test_c5_20m_against_fp64_device_sums.
+50 000 attendees) at 1 M agents here and at 20 M and 100 M agents (BASELINE configs[4]'s full size, one GPU) in
+test_c5_20m_against_fp64_device_sums.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -195,19 +198,23 @@ def test_c3_full_size_eight_partitions_equal_unpartitioned(device):
     assert single.state["is_infected"].sum().item() > 0.04 * world["n_agents"]
 
 
-def test_c5_20m_against_fp64_device_sums(device):
-    """BASELINE.json configs[4]'s shape at the largest size one GPU takes as a single partition:
-    20 M agents, power-law venue sizes up to 50 000 attendees (a venue then spans every slice and holds far more edges
+@pytest.mark.parametrize("agents", [20_000_000, 100_000_000], ids=["20m", "100m-the-full-config"])
+def test_c5_20m_against_fp64_device_sums(device, agents):
+    """BASELINE.json configs[4]'s shape on ONE GPU as a single partition - at 20 M agents and at the configuration's
+    full size, 100 M agents / 129 M venues / 900 M set-edges (11 s on an MI355X: the world is drawn and the graph
+    compiled on the device) -, power-law venue sizes up to 50 000 attendees (a venue then spans every slice and holds far more edges
     than a slice has agents: the LDS-overflow / multi-block case).  The world is drawn on the device
     (synthetic.make_world_torch: the numpy generator needs minutes at this size) and EVERY venue sum and EVERY agent's
     probability is checked against fp64 sums taken from the same edge lists - in particular every venue with more
     than 20 480 attendees; plus linearity of pass 1 and run-to-run determinism."""
     from grad_june_amd.synthetic import make_world_torch
 
-    world = make_world_torch("c5", 20_000_000, seed=1234, device=device, infected_fraction=0.03)
+    world = make_world_torch("c5", agents, seed=1234, device=device, infected_fraction=0.03)
     A = world["n_agents"]
     giant = {k: int((v["people"] > 20480).sum()) for k, v in world["edge_sets"].items()}
     assert all(n >= 10 for n in giant.values()), giant
+    print(f"c5 world: {A} agents, {sum(len(v['people']) for v in world['edge_sets'].values())} venues, "
+          f"{sum(v['agent'].numel() for v in world['edge_sets'].values())} set-edges, venues above 20 480 attendees: {giant}")
     specs, betas = B.network_specs(world), B.betas_of(world)
     r = SingleGpuHotPath(world, specs, betas, device, seed=3, layout="tiled", device_compile=True)
     run_stages(r)
