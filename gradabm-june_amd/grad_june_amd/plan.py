@@ -292,7 +292,10 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
     (its ELL rows + per-workgroup LDS tables of fixed-point sums, k_tile_presum; bit-identical results).  Off by
     default: measured on C3 (round 3, tools/ab.py) it moves 0.2 GB less per step and is 15 % SLOWER - the 64-bit LDS
     atomics it takes out of the venue launch (115 M per step) cost the same there, and its own launch pays a memory
-    round trip per batch (one workgroup per CU: the tables fill the LDS).
+    round trip per batch (one workgroup per CU: the tables fill the LDS).  A second attempt in the same round (batches
+    software-pipelined, a parallel table reduction) brought it to 8 % slower: still opt-in.
+    tile_pad: experiment of the numpy compile (tiling.build_tiled): tiles padded to a multiple of this many positions in
+    both orders (16 = whole 64-byte sectors of the workspace); measured -1 % on C3, not adopted, not in the device compile.
     """
     if len(edge_sets) > N.GJ_MAX_SETS:
         raise ValueError(f"at most {N.GJ_MAX_SETS} edge sets")
