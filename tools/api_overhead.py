@@ -53,7 +53,7 @@ def main():
         torch.cuda.synchronize()
     print("Runner, 769 agents, 11 networks: %.3f ms per timestep (60 steps)" % ((time.perf_counter() - t0) / 60 * 1e3))
 
-    for n in (2_000_000,):
+    for n in ([int(a) for a in sys.argv[1:] if a.isdigit()] or [2_000_000]):
         world = make_world("c3", n_agents=n)
         d = hetero_from(world, dev)
         pp = default_parameters(dev)
