@@ -25,7 +25,6 @@ same gradients bit for bit - the kept sums ARE what the recomputation produces (
 from __future__ import annotations
 
 import ctypes as C
-import math
 from typing import List
 
 import torch
