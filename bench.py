@@ -37,6 +37,10 @@ def parse():
     ap.add_argument("--preset", default="c3", choices=["c2", "c3", "c5"])
     ap.add_argument("--agents", type=int, default=None)
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--geography", default="random", choices=["random", "clustered"],
+                    help="random: agents dealt to venue slots uniformly at random (SURVEY 8d's specification; every "
+                         "committed headline figure); clustered: the same presets on a world with a geography - households "
+                         "of neighbours, venues in the own / a neighbouring super area, a stated leak (synthetic.GEOGRAPHY)")
     ap.add_argument("--infected", type=float, default=0.01)
     ap.add_argument("--layout", default="tiled", choices=["tiled", "csr"],
                     help="tiled: LDS propagation-blocked kernels (default); csr: deterministic CSR kernels")
@@ -111,6 +115,9 @@ def parse():
                     help="profiling runs: only the warm-up and the timed region(s) of the headline configuration (no "
                          "quarantine / high-prevalence / full-step regions, no CPU baseline), so that a profile's last "
                          "dispatches are the timed steps")
+    ap.add_argument("--sustained-seconds", type=float, default=2.0,
+                    help="one GPU: after the timed regions, this many seconds of steps in blocks of 25 with the state reset "
+                         "before every block - ms/step min / median / max and the last quarter's mean (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=150.0,
                     help="wall-clock bound of the CPU baseline (SURVEY 8d protocol: 3 warm-up + 10 timed steps, no_grad "
                          "and autograd on; a leg that would exceed the bound stops early and says so in `sample`)")
@@ -187,7 +194,8 @@ def cpu_baseline(world, networks, betas, tables, budget_s):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, int(os.environ.get("GJ_CPU_THREADS", "16"))))
+    # every core this process may run on (GJ_CPU_THREADS lowers it for experiments)
+    cores = max(1, min(avail, int(os.environ.get("GJ_CPU_THREADS", str(avail)))))
     torch.set_num_threads(cores)
     w = {"n_agents": world["n_agents"], "age": torch.from_numpy(world["age"]), "sex": torch.from_numpy(world["sex"]),
          "edge_sets": {k: {kk: torch.from_numpy(vv) for kk, vv in v.items()} for k, v in world["edge_sets"].items()}}
@@ -226,7 +234,8 @@ def cpu_baseline(world, networks, betas, tables, budget_s):
     sps = 1.0 / float(np.mean(t_ng))
     sps_ag = 1.0 / float(np.mean(t_ag))
     n_edges = sum(len(world["edge_sets"][_es(n_)]["agent"]) for n_ in networks)
-    return {"value": sps, "unit": "steps/s", "cores": cores, "kind": "port",
+    return {"value": sps, "unit": "steps/s", "cores": cores, "cores_visible": avail,
+            "cores_host": os.cpu_count(), "kind": "port",
             "sample": f"{len(t_ng)} timed full steps of the same workload after {w_ng} warm-up steps, torch CPU ops, "
                       f"no_grad (wall-clock bound {budget_s:g} s for both legs)",
             "edges_per_s": sps * n_edges,
@@ -274,13 +283,14 @@ def cached_world(args, progress, make_world):
             progress("world drawn on the device")
             return w
         return make_world(args.preset, n_agents=args.agents, seed=args.seed, infected_fraction=args.infected,
-                          edge_mult=args.edge_mult, progress=progress)
+                          edge_mult=args.edge_mult, progress=progress, geography=args.geography)
 
     if not args.world_cache:
         return gen()
     os.makedirs(args.world_cache, exist_ok=True)
     path = os.path.join(args.world_cache,
-                        f"{args.preset}_{args.agents}_{args.seed}_{args.infected}_{args.edge_mult}_{args.generator}.npz")
+                        f"{args.preset}_{args.agents}_{args.seed}_{args.infected}_{args.edge_mult}_{args.generator}"
+                        + ("" if args.geography == "random" else "_" + args.geography) + ".npz")
     if not os.path.exists(path):
         w = gen()
         flat = {"n_agents": w["n_agents"], "age": w["age"], "sex": w["sex"], "networks": ",".join(w["networks"])}
@@ -380,6 +390,48 @@ def backward_bench(args, world, specs, networks, dev, progress):
                      "traffic": None},
         "loss": runs[-1][2], "grad_log_beta": dict(zip(networks, runs[-1][3])),
     }
+
+
+def sustained_region(runner, seconds: float, ms_per_step_hint: float, block: int = 25):
+    """A sustained-clock figure: at least ``seconds`` of GPU work as blocks of ``block`` production steps (gj_step, no
+    events between the launches), the epidemic state put back to the block's start state before every block (so every
+    block computes the same 25 steps at the headline prevalence instead of drifting into a saturated epidemic).  Each
+    block is bracketed by two HIP events on the launch stream; the reset copies (3 arrays) lie OUTSIDE the brackets,
+    so ``ms_per_step`` figures are the steps' alone - the GPU still executes them, i.e. the card is busy throughout.
+    Returns min / median / max over the blocks and the mean of the last quarter (clocks and temperature settled)."""
+    keys = ("is_infected", "susceptibility", "infection_time")
+    start = {k: runner.state[k].clone() for k in keys}
+    t0 = runner.t
+    n_blocks = max(8, int(np.ceil(seconds * 1e3 / max(1e-3, ms_per_step_hint * block))))
+    events = []
+    torch.cuda.synchronize()
+    w0 = time.perf_counter()
+    for _ in range(n_blocks):
+        for k in keys:
+            runner.state[k].copy_(start[k])
+        runner.t = t0
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(block):
+            runner.step()
+        b.record()
+        events.append((a, b))
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - w0
+    ms = np.array([a.elapsed_time(b) / block for a, b in events])
+    infected = float(runner.state["is_infected"].double().sum())
+    for k in keys:
+        runner.state[k].copy_(start[k])
+    runner.t = t0
+    q = max(1, len(ms) // 4)
+    return {"seconds_of_gpu_work": float(ms.sum() * block / 1e3), "wall_seconds": wall, "blocks": int(n_blocks),
+            "steps_per_block": block, "steps": int(n_blocks * block),
+            "ms_per_step": {"min": float(ms.min()), "median": float(np.median(ms)), "max": float(ms.max()),
+                            "first_quarter_mean": float(ms[:q].mean()), "last_quarter_mean": float(ms[-q:].mean())},
+            "steps_per_s_last_quarter": 1e3 / float(ms[-q:].mean()),
+            "infected_after_a_block": infected,
+            "method": "blocks of production steps (gj_step) between two HIP events on the launch stream; the state is "
+                      "reset before every block, the reset copies lie outside the events"}
 
 
 def auto_parts(n_agents: int) -> int:
@@ -542,7 +594,7 @@ def main():
 
         rw, share = stream_rank_share(
             iter_world(args.preset, n_agents=args.agents, seed=args.seed, infected_fraction=args.infected,
-                       edge_mult=args.edge_mult, progress=progress),
+                       edge_mult=args.edge_mult, progress=progress, geography=args.geography),
             rank, world_size, reorder=None if reorder == "none" else reorder, progress=progress)
         world = {"n_agents": share["n_agents"], "networks": share["networks"], "state": share["state"],
                  "edge_sets": {k: {"n_edges": e, "n_venues": v} for k, (e, v) in share["sizes"].items()}}
@@ -577,7 +629,8 @@ def main():
                                     total_edges=None if share is None else share["total_edges"],
                                     device_compile=device_compile,
                                     production_at_one_rank=world_size == 1)   # diagnostic: the overlapped multi-rank step
-        extra = {"exchange": {"modes": runner.rw.modes, "halo_agents_rank0": int(runner.rw.n_halo),
+        extra = {"exchange": {"modes": runner.rw.modes, "venue_classes": None if share is None else share.get("classes"),
+                              "halo_agents_rank0": int(runner.rw.n_halo),
                               "halo_bytes_per_step_rank0": runner.halo.bytes_per_step if runner.halo else 0,
                               "partial_sum_floats": int(runner.flat_cum.numel()) if runner.flat_cum is not None else 0}}
     else:
@@ -745,6 +798,10 @@ def main():
     if single:
         del kept
 
+    sustained = None
+    if single and args.sustained_seconds > 0 and not args.only_headline:
+        sustained = sustained_region(runner, args.sustained_seconds, 1e3 * elapsed / args.steps)
+
     full = None
     if not distributed and hasattr(runner, "enable_full_step") and not args.only_headline:
         # second timed region: the "full step" of SURVEY section 8d (hot path + symptoms + result reductions)
@@ -795,9 +852,11 @@ def main():
         "config": {"workload": f"{args.preset}: {world['n_agents']} agents, {len(networks)} infection networks on "
                                f"{len(world['edge_sets'])} edge sets, {n_edges} network-edges, seed {args.seed}, "
                                f"{args.infected:.0%} infected, Philox noise"
+                               + ("" if args.geography == "random" else f", {args.geography} geography")
                                + (f", quarantine below stage {args.quarantine:g}" if args.quarantine else ""),
                    "preset": args.preset, "n_agents": world["n_agents"], "network_edges": n_edges,
-                   "parallelism": f"agents partitioned over {world_size} GPU(s)", "agent_order": reorder},
+                   "parallelism": f"agents partitioned over {world_size} GPU(s)", "agent_order": reorder,
+                   "geography": args.geography},
         "edges_per_s": sps * n_edges,
         "algorithmic_bytes_per_step": b_step,
         "step_roofline_frac": b_step * sps / (HBM_PEAK_GBS * 1e9 * world_size),
@@ -828,6 +887,8 @@ def main():
         out["exposed_collective_ms_per_step"] = max(0.0, 1e3 * elapsed / args.steps - kernels_only)
         out["kernels_ms_per_step_rank0"] = kernels_only
     out.update(extra)
+    if sustained:
+        out["sustained"] = sustained
     if full:
         out["full_step"] = full
     if high:
@@ -837,6 +898,17 @@ def main():
     # HBM traffic of the dominant kernel from the committed PMC profile of this exact workload AND these exact kernel
     # sources (tools/pmc_traffic.py stamps the profile with a hash of csrc/ + the ABI header): a profile of other
     # kernels is not reported
+    # Two fractions per launch and for the step, side by side: "algorithmic" prices SURVEY 8d's int32-index byte model
+    # (what `roofline.achieved` must use), "measured" the bytes the chip actually moved (PMC).  The tiled launches move
+    # FEWER bytes than the model (16-bit indices, the direct and run forms; the fused epilogue of k_tile_agents never
+    # makes the (8 N + 64) A separate per-agent passes the model prices, which is why its algorithmic fraction can
+    # exceed 1) - so the measured fraction is the one that reads as HBM utilisation.
+    ms_step = 1e3 * elapsed / args.steps
+    by_kernel = {k: {"ms_per_launch": kt[k], "algorithmic_bytes": kb[k] * share_f,
+                     "algorithmic_frac": kb[k] * share_f / (kt[k] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "measured_bytes": None, "measured_frac": None} for k in kt if k in kb}
+    out["roofline_by_kernel"] = by_kernel
+    out["measured_traffic_frac"] = None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pmc = json.load(f)
@@ -846,6 +918,14 @@ def main():
             out["roofline"]["traffic"] = pmc["per_launch_bytes"][dom]["total"]
             out["roofline"]["traffic_source"] = ("profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, "
                                                  "kernel sources " + pmc["csrc_sha256"][:12] + ")")
+            out["roofline"]["measured_achieved"] = out["roofline"]["traffic"] / (kt[dom] * 1e-3) / 1e9
+            out["roofline"]["measured_frac"] = out["roofline"]["measured_achieved"] / HBM_PEAK_GBS
+            for k, e in by_kernel.items():
+                if k in pmc["per_launch_bytes"]:
+                    e["measured_bytes"] = pmc["per_launch_bytes"][k]["total"]
+                    e["measured_frac"] = e["measured_bytes"] / (kt[k] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            out["measured_traffic_bytes_per_step"] = pmc["per_step_total_bytes"]
+            out["measured_traffic_frac"] = pmc["per_step_total_bytes"] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS
         elif same_workload and world_size == 1:
             out["roofline"]["traffic_source"] = "none: profiles/pmc_traffic.json was taken with other kernel sources"
     except (OSError, KeyError):

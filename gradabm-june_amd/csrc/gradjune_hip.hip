@@ -89,7 +89,8 @@ struct P2Args {
 //   1 / Gamma(shape)  by the recurrence to [1, 2] and Abramowitz & Stegun 6.1.36 (degree 8, |eps| <= 3e-7 there; measured
 //                     3.5e-7 relative in fp32), libm only for shapes outside (0.25, 16);
 //   pow(x, y)         = exp2(y * log2(x)) on the hardware's v_log_f32 / v_exp_f32 (1 ulp each): the error of the
-//                     exponent, |y log2 x| * 2^-23, is ~1e-6 relative in the result; NaN for x < 0, 0 / inf at x == 0 as powf;
+//                     exponent, |y log2 x| * 2^-23, is ~1e-6 relative in the result; 0 / inf at x == 0 as powf; x < 0: NaN for a
+//                     non-integer y and +-|x|^y for an integer one, as powf / torch.pow;
 //   exp(e)            = exp2(e * log2(e)): ~|e| * 1e-7.
 // Together ~2e-6 relative against the reference's fp32 torch ops (themselves ~1e-7); the parity tests hold the
 // transmissions to 2e-5.  ~60 instructions.
@@ -118,6 +119,17 @@ __device__ __forceinline__ float inv_gamma(float x) {
 }
 __device__ __forceinline__ float fast_pow(float x, float y) {
   if (y == 0.0f) return 1.0f;             // powf(x, 0) == 1 for every x
+  if (x < 0.0f) {
+    // torch.pow / powf of a negative base: finite for an INTEGER exponent (sign by its parity), NaN otherwise.  A
+    // constant integer shape with t < shift is the case that matters (transmission.py:45-49: sign == 0 there, and
+    // 0 * finite == 0 where 0 * NaN would poison the venue sums).  Rare: not worth libm's powf in the
+    // instruction stream of a launch that lives on its occupancy.
+    const float yi = truncf(y);
+    if (yi != y) return __builtin_nanf("");
+    const float r = __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(-x));
+    const float h = 0.5f * yi;
+    return (truncf(h) != h) ? -r : r;     // odd exponent: the base's sign survives
+  }
   return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));      // v_exp_f32(y * v_log_f32(x))
 }
 __device__ __forceinline__ float fast_exp(float e) { return __builtin_amdgcn_exp2f(e * 1.44269504088896341f); }

@@ -145,6 +145,7 @@ class SingleGpuHotPath:
         st["next_stage"] = torch.where(st["is_infected"] > 0, st["current_stage"] + 1, st["current_stage"]).contiguous()
         st["time_to_next_stage"] = torch.zeros(A, dtype=torch.float32, device=dev)
         self._series = torch.zeros(n_rows, 5, dtype=torch.float64, device=dev)
+        self._n_rows = n_rows
         self._edges = (C.c_int32 * 4)(0, 18, 65, 100)
         self._row = 0
 
@@ -154,11 +155,14 @@ class SingleGpuHotPath:
         st = self.state
         p = self._sym_p
         p.time, p.seed, p.step, p.agent_offset = float(self.t), self.seed, self.t, 0
+        row = self._series[self._row % self._n_rows]
+        if self._row >= self._n_rows:        # the ring wrapped: the kernel ACCUMULATES into its row (atomics), so zero it first
+            row.zero_()
         N.check(lib.gj_symptoms_step_stats(self.new_infected.numel(), N.ptr(self.engine.plan.agent_class),
                                            N.ptr(self.new_infected), N.ptr(st["current_stage"]), N.ptr(st["next_stage"]),
                                            N.ptr(st["time_to_next_stage"]), C.byref(p), None, None,
                                            N.ptr(st["is_infected"]), 3, self._edges, 7,
-                                           N.ptr(self._series[self._row % 4096]), N.current_stream()),
+                                           N.ptr(row), N.current_stream()),
                 "gj_symptoms_step_stats")
         self._row += 1
 

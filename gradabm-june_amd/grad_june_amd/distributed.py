@@ -15,6 +15,12 @@ per edge set one of two exchanges is used (decided once, identically on every ra
 A heavy-tailed set (power-law venue sizes) is ``split`` into a halo half (its small venues) and a partial-sum half
 (its large ones), see ``mode_of``.
 
+Round 4: the exchange is decided PER VENUE (``classify_venues``): a venue whose attendees all live on one
+rank is *local* (computed there, never communicated), one with few remote attendees is a *halo* venue, one that spans
+ranks / is large goes the *partial-sum* way - and only those venues are in the all-reduce buffer.  A set that has both
+kinds is cut in two (the "split" form: ``<set>`` keeps the local + halo venues, ``<set>~big`` the partial-sum ones);
+the per-set rule of rounds 1-3 (``mode_of``) remains as ``GJ_EXCHANGE_RULE=set`` for comparison.
+
 Per step:  transmission -> [all_to_all halo] -> phase A, phase B -> [all_reduce partial sums]
            -> phase C, phase D.   Pass 2 and the epilogue are purely local.
 Sampling noise is Philox keyed by the GLOBAL agent id, so results do not depend on the partition.
@@ -34,6 +40,33 @@ from .plan import SPLIT_SUFFIX
 HALO_MAX_MEAN_DEGREE = 8.0     # sets whose venues average more attendees use partial sums
 SPLIT_MIN_WEIGHTED_SIZE = 64.0  # venue size seen by the average EDGE of a small-mean set above which the set is split
 PIPELINE_MIN_EDGES = 20_000_000  # set-edges per rank from which the largest partial-sum set gets its own all-reduce
+#: "venue" (default): per-venue classes from the venue's own attendees (classify_venues); "set": the per-set rule of
+#: rounds 1-3 (mode_of: global sizes only) - kept so that tools/rank_share.py can measure one against the other
+EXCHANGE_RULE = os.environ.get("GJ_EXCHANGE_RULE", "venue")
+PARTIAL_COST_FACTOR = 1.0        # a venue goes the partial-sum way when its halo floats exceed this x its all-reduce floats
+MIN_SPLIT_HALO_FLOATS = 4096     # ... and a set is only cut in two when that saves at least this many halo floats per step
+MIN_SPLIT_VENUE_SHARE = 0.10     # ... and takes at least this share of the set's venues out of the all-reduce
+
+
+def classify_venues(agent: np.ndarray, venue: np.ndarray, n_venues: int, bounds: np.ndarray, nets_on_set: int = 1,
+                    factor: float = PARTIAL_COST_FACTOR):
+    """Exchange class of every venue of one edge set, from the venue's own attendee list (global data: every rank
+    computes the same answer).  With n attendees living on T ranks:
+
+      T <= 1                 *local*: the owning rank computes it, nothing is communicated;
+      halo floats n (T - 1)  what the halo form moves per step (every touching rank receives the attendees it does not
+                             own) against the 2 k (R - 1) floats a venue with k networks costs in an all-reduce over
+                             R ranks: *halo* while n (T - 1) <= factor * 2 k (R - 1), else *partial-sum*.
+
+    A boundary household is a halo venue, a school with one pupil from the next rank or a 50 000-attendee venue a
+    partial-sum one.  Returns (partial[V] bool, n[V], T[V])."""
+    R = len(bounds) - 1
+    owner = np.searchsorted(bounds, agent, side="right") - 1
+    cnt = np.bincount(venue * R + owner, minlength=n_venues * R).reshape(n_venues, R)
+    n = cnt.sum(1)
+    T = (cnt > 0).sum(1)
+    del cnt
+    return n * (T - 1) > factor * 2.0 * max(1, nets_on_set) * (R - 1), n, T
 
 
 def reduce_groups(floats: Dict[str, int], min_floats: int = 1 << 16) -> List[List[str]]:
@@ -78,7 +111,7 @@ class RankWorld:
     sex: np.ndarray
     edge_sets: Dict[str, dict]         # local COO: agent = extended index, venue = local/global id
     modes: Dict[str, str]
-    venue_global: Dict[str, Optional[np.ndarray]]   # halo sets: global id of each local venue
+    venue_global: Dict[str, Optional[np.ndarray]]   # the set's venue id of each local venue (None: the same numbering)
 
     @property
     def n_halo(self) -> int:
@@ -140,12 +173,18 @@ class RankPartitioner:
         self.venue_global = {r: {} for r in self.ranks}
         self.total_edges = 0
         self.sizes: Dict[str, tuple] = {}          # global (edges, venues) per set
+        self.classes: Dict[str, dict] = {}         # per set: venues by exchange class (global counts; reporting)
 
     def add_set(self, name: str, agent, venue, people) -> str:
         agent = np.asarray(agent, dtype=np.int64).ravel()
         venue = np.asarray(venue, dtype=np.int64).ravel()
         people = np.asarray(people)
-        mode = self.mode_override.get(name) or mode_of(len(agent), len(people), self.world_size, people)
+        mode = self.mode_override.get(name)
+        big = None
+        if mode is None and (EXCHANGE_RULE == "set" or self.world_size == 1):
+            mode = mode_of(len(agent), len(people), self.world_size, people)
+        elif mode is None:
+            mode, big = self._mode_by_venue(name, agent, venue, len(people))
         self.total_edges += len(agent)
         self.sizes[name] = (len(agent), len(people))
         self._n_sets_seen += 1
@@ -153,16 +192,46 @@ class RankPartitioner:
             mode = self._split_or_fallback(name, len(people))
         self._n_sets_added += 2 if mode == "split" else 1
         if mode == "split":
-            # two edge sets with venue numberings of their own: the small venues exchange halo transmissions, the
-            # large ones partial sums; every network on the set gets a twin on the second (expand_split_networks)
-            big = people > HALO_MAX_MEAN_DEGREE
+            # two edge sets with venue numberings of their own: the local + halo venues exchange halo transmissions, the
+            # others partial sums; every network on the set gets a twin on the second (expand_split_networks).  (The
+            # forced / per-set form of rounds 2-3 cuts by size: venues of up to HALO_MAX_MEAN_DEGREE attendees are halo.)
+            if big is None:
+                big = people > HALO_MAX_MEAN_DEGREE
             e_big = big[venue]
             for part, sel_v, sel_e, m in ((name, ~big, ~e_big, "halo"), (name + SPLIT_SUFFIX, big, e_big, "partial")):
                 remap = np.cumsum(sel_v) - 1
-                self._add_part(part, agent[sel_e], remap[venue[sel_e]], people[sel_v], m)
+                self._add_part(part, agent[sel_e], remap[venue[sel_e]], people[sel_v], m, np.flatnonzero(sel_v))
             return mode
         self._add_part(name, agent, venue, people, mode)
         return mode
+
+    def _mode_by_venue(self, name: str, agent: np.ndarray, venue: np.ndarray, n_venues: int):
+        """The set's exchange mode from its venues' classes: "halo" (every venue local or halo), "partial" (next to none
+        of them), or "split" with the mask of the partial-sum venues."""
+        k = self._nets_on.get(name, 1)
+        partial, n, T = classify_venues(agent, venue, n_venues, self.bounds, k)
+        used = n > 0
+        n_part, n_ex = int((partial & used).sum()), int((~partial & used).sum())
+        halo_saved = float((n * (T - 1))[partial].sum())
+        self.classes[name] = {"venues": int(used.sum()), "local": int((T == 1).sum()),
+                              "halo": int((~partial & (T > 1)).sum()), "partial_sum": n_part,
+                              "edges_in_partial_sum_venues": int(n[partial].sum())}
+        if n_part == 0 or halo_saved < MIN_SPLIT_HALO_FLOATS:
+            mode = "halo"
+        elif n_ex < MIN_SPLIT_VENUE_SHARE * (n_part + n_ex):
+            mode = "partial"
+        else:
+            return "split", partial
+        # the set runs whole: what its venues' classes are IN EFFECT (the counts by the cost rule are kept beside them)
+        c = self.classes[name]
+        c["by_cost"] = {k: c[k] for k in ("local", "halo", "partial_sum")}
+        if mode == "halo":
+            c["halo"], c["partial_sum"], c["edges_in_partial_sum_venues"] = c["halo"] + n_part, 0, 0
+        else:
+            c["local"], c["halo"], c["partial_sum"] = 0, 0, c["venues"]
+            c["edges_in_partial_sum_venues"] = int(n.sum())
+        c["set_runs_as"] = mode
+        return mode, None
 
     def _split_or_fallback(self, name: str, n_venues: int) -> str:
         """A split set becomes two edge sets and every network on it gets a twin: only while GJ_MAX_SETS,
@@ -183,7 +252,10 @@ class RankPartitioner:
                       f"{self._n_sets_added} sets and {self._n_nets} networks so far) - runs in {mode} mode")
         return mode
 
-    def _add_part(self, name: str, agent: np.ndarray, venue: np.ndarray, people: np.ndarray, mode: str) -> None:
+    def _add_part(self, name: str, agent: np.ndarray, venue: np.ndarray, people: np.ndarray, mode: str,
+                  part_venues: Optional[np.ndarray] = None) -> None:
+        """``part_venues``: the set's venue ids of this part's venues (a split set's half has a numbering of its own);
+        ``venue_global`` then maps a rank's local venues to ids of the WHOLE set."""
         self.modes[name] = mode
         b = self.bounds
         if len(self.ranks) > 2:
@@ -199,7 +271,7 @@ class RankPartitioner:
             idx = mine_idx[r]
             if mode in ("partial", "local"):
                 self.local_sets[r][name] = {"agent_global": agent[idx], "venue": venue[idx], "people": people}
-                self.venue_global[r][name] = None
+                self.venue_global[r][name] = part_venues
                 continue
             touched = np.zeros(len(people), dtype=bool)
             touched[venue[idx]] = True
@@ -209,7 +281,7 @@ class RankPartitioner:
             remap[vg] = np.arange(len(vg))
             ag = agent[keep]
             self.local_sets[r][name] = {"agent_global": ag, "venue": remap[venue[keep]], "people": people[vg]}
-            self.venue_global[r][name] = vg
+            self.venue_global[r][name] = vg if part_venues is None else part_venues[vg]
             self.halo_lists[r].append(np.unique(ag[(ag < b[r]) | (ag >= b[r + 1])]))
 
     def finish(self, age, sex, slice_agents: Optional[int] = None) -> Dict[int, "RankWorld"]:
@@ -304,10 +376,10 @@ def stream_rank_share(pieces, rank: int, world_size: int, reorder: Optional[str]
     pick = (lambda v: v[a0:a1]) if order is None else (lambda v: v[order[a0:a1]])
     age = header["age"] if order is None else header["age"][order]
     sex = header["sex"] if order is None else header["sex"][order]
-    total_edges, sizes = part.total_edges, dict(part.sizes)
+    total_edges, sizes, classes = part.total_edges, dict(part.sizes), dict(part.classes)
     rw = part.finish(age, sex, slice_agents)[rank]
     share = {"networks": header["networks"], "state": {k: np.ascontiguousarray(pick(v)) for k, v in state.items()},
-             "n_agents": header["n_agents"], "total_edges": total_edges, "sizes": sizes,
+             "n_agents": header["n_agents"], "total_edges": total_edges, "sizes": sizes, "classes": classes,
              "original_id": (np.arange(a0, a1) if order is None else order[a0:a1])}
     return rw, share
 

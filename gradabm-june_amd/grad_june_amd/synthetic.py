@@ -12,6 +12,12 @@ Presets (BASELINE.json configs):
         shared leisure set; every edge set 15 M edges (90 M set-edges, 120 M network-edges)
   "c5"  power-law venue degrees (Zipf alpha=2 truncated to [1, 50 000])
 All presets scale with ``n_agents`` (edges per agent are kept).
+
+``geography="random"`` (default; SURVEY 8d's specification): agents are dealt to venue slots uniformly at random - no
+locality at all.  ``geography="clustered"``: the same presets (venue-size distributions, memberships per agent, exact
+``people[v]`` = degree) on a world that HAS a geography, as the reference's worlds do (june_world_loader: people live in
+areas inside super areas, ``population/super_area``; venues belong to a super area; leisure attaches the people of the
+k nearest super areas to each super-area venue, leisure_loader.py:38-73) - see ``GEOGRAPHY``.
 """
 from __future__ import annotations
 
@@ -47,6 +53,89 @@ NETWORKS = {
 }
 
 
+# ---- geography of the "clustered" worlds ---------------------------------------------------------------------------
+# Agents are numbered along the geography: agent a lives in super area a // SUPER_AREA_AGENTS (JUNE's super areas are
+# MSOAs of ~8 000 residents, its areas output areas of ~300), and the super areas are the cells of a square grid
+# visited along a Hilbert curve, so that a contiguous range of agent ids - a rank of the multi-GPU partition - is a
+# compact region of the map.  A membership of an agent in a set goes
+#     with probability 1 - p_near - p_leak  to a venue of its own super area,
+#     with probability p_near               to a venue of one of the <= 8 surrounding super areas (the "k nearest super
+#                                           areas" of leisure_loader.py:38-73; catchment areas of schools, local commutes),
+#     with probability p_leak               to a venue anywhere in the world (long commutes, universities, care visits),
+# and the venues of a set are laid out along the same curve (a venue larger than a super area spans neighbouring ones).
+# Households are formed from CONSECUTIVE agents (a household's members are neighbours in the id order): p = None.
+# The probabilities are stated, not fitted: companies leak most (London's commuting is city-wide), schools least.
+SUPER_AREA_AGENTS = 5000
+GEOGRAPHY = {
+    "household": None,
+    "care_home": (0.20, 0.02),
+    "company": (0.30, 0.30),
+    "school": (0.15, 0.01),
+    "university": (0.40, 0.10),
+    "leisure": (0.40, 0.02),
+}
+
+
+def hilbert_cells(grid: int):
+    """(x, y) of the cells of a ``grid`` x ``grid`` map in the order a Hilbert curve (of the enclosing power-of-two
+    square) visits them: consecutive cells are neighbours or close, any contiguous run of cells is a compact region."""
+    order = 1
+    while order < grid:
+        order *= 2
+    d = np.arange(order * order, dtype=np.int64)
+    x = np.zeros_like(d)
+    y = np.zeros_like(d)
+    t = d.copy()
+    s = 1
+    while s < order:
+        rx = 1 & (t // 2)
+        ry = 1 & (t ^ rx)
+        flip = (ry == 0) & (rx == 1)          # rotate the quadrant
+        x_f = np.where(flip, s - 1 - x, x)
+        y_f = np.where(flip, s - 1 - y, y)
+        swap = ry == 0
+        x, y = np.where(swap, y_f, x_f), np.where(swap, x_f, y_f)
+        x += s * rx
+        y += s * ry
+        t //= 4
+        s *= 2
+    keep = (x < grid) & (y < grid)
+    return x[keep], y[keep]
+
+
+def super_area_map(n_agents: int, sa_agents: int = SUPER_AREA_AGENTS):
+    """The map of a clustered world: ``n_sa`` super areas of ``sa_agents`` consecutive agents each, their grid cells and
+    ``nb[n_sa, 8]`` / ``nb_n[n_sa]`` = the surrounding super areas that exist (at least one for n_sa > 1)."""
+    n_sa = max(1, -(-int(n_agents) // sa_agents))
+    grid = int(np.ceil(np.sqrt(n_sa)))
+    x, y = hilbert_cells(grid)
+    x, y = x[:n_sa], y[:n_sa]
+    cell = np.full((grid + 2, grid + 2), -1, dtype=np.int64)
+    cell[x + 1, y + 1] = np.arange(n_sa)
+    nb = np.stack([cell[x + 1 + dx, y + 1 + dy] for dx in (-1, 0, 1) for dy in (-1, 0, 1) if (dx, dy) != (0, 0)], axis=1)
+    order = np.argsort(nb < 0, axis=1, kind="stable")            # existing neighbours first
+    nb = np.take_along_axis(nb, order, axis=1)
+    nb_n = (nb >= 0).sum(1)
+    return {"n_sa": n_sa, "sa_agents": sa_agents, "x": x, "y": y, "nb": nb, "nb_n": nb_n}
+
+
+def _membership_keys(rng, agent: np.ndarray, n_agents: int, geo, mix) -> np.ndarray:
+    """Where on the curve (in units of agents) each membership looks for its venue."""
+    if mix is None:                                   # households: neighbours in the id order
+        return agent + rng.uniform(-1.5, 1.5, len(agent))
+    p_near, p_leak = mix
+    sa = geo["sa_agents"]
+    home = agent // sa
+    u = rng.random(len(agent))
+    target = home.copy()
+    near = (u >= 1.0 - p_near - p_leak) & (u < 1.0 - p_leak) & (geo["nb_n"][home] > 0)
+    pick = (rng.random(int(near.sum())) * geo["nb_n"][home[near]]).astype(np.int64)
+    target[near] = geo["nb"][home[near], pick]
+    leak = u >= 1.0 - p_leak
+    target[leak] = rng.integers(0, geo["n_sa"], int(leak.sum()))
+    return (target + rng.random(len(agent))) * float(sa)
+
+
 def _venue_sizes(rng, dist, n_edges: int) -> np.ndarray:
     """Draw venue sizes until they sum to ``n_edges`` (last venue takes the remainder)."""
     kind = dist[0]
@@ -77,7 +166,9 @@ def _venue_sizes(rng, dist, n_edges: int) -> np.ndarray:
     return sizes[sizes > 0]
 
 
-def _edge_set(rng, n_agents: int, n_edges: int, dist) -> dict:
+def _edge_set(rng, n_agents: int, n_edges: int, dist, geo=None, mix=None) -> dict:
+    """``geo`` (a ``super_area_map``) + ``mix`` (the set's entry of GEOGRAPHY): the clustered form - memberships are
+    dealt to the venue slots in the order of where they look for a venue, the slots lie along the curve."""
     sizes = _venue_sizes(rng, dist, n_edges)
     V = len(sizes)
     venue = np.repeat(np.arange(V, dtype=np.int64), sizes)
@@ -87,7 +178,10 @@ def _edge_set(rng, n_agents: int, n_edges: int, dist) -> dict:
     if extra:
         parts.append(rng.choice(n_agents, extra, replace=False).astype(np.int64))
     agent = np.concatenate(parts)
-    rng.shuffle(agent)
+    if geo is None:
+        rng.shuffle(agent)
+    else:
+        agent = agent[np.argsort(_membership_keys(rng, agent, n_agents, geo, mix), kind="stable")]
     # no duplicate (agent, venue) pair: move the few collisions to the next venue
     for _ in range(4):
         key = agent * V + venue
@@ -104,7 +198,8 @@ def _edge_set(rng, n_agents: int, n_edges: int, dist) -> dict:
 
 
 def iter_world(preset: str = "c3", n_agents: Optional[int] = None, seed: int = 1234,
-               infected_fraction: float = 0.01, sets=None, edge_mult: float = 1.0, progress=None):
+               infected_fraction: float = 0.01, sets=None, edge_mult: float = 1.0, progress=None,
+               geography: str = "random"):
     """The world of ``make_world`` piece by piece, in the order the generator draws them:
         ("header", {"preset", "n_agents", "age", "sex", "networks"})
         ("set", name, {"agent", "venue", "people"})     once per edge set
@@ -113,15 +208,18 @@ def iter_world(preset: str = "c3", n_agents: Optional[int] = None, seed: int = 1
     spec = PRESETS[preset]
     if n_agents is None:
         n_agents = {"c2": 1_000_000, "c3": 10_000_000, "c5": 100_000_000}[preset]
+    if geography not in ("random", "clustered"):
+        raise ValueError(f"geography {geography!r}: 'random' or 'clustered'")
     rng = np.random.default_rng(seed)
     A = int(n_agents)
+    geo = super_area_map(A) if geography == "clustered" else None
     yield ("header", {"preset": preset, "n_agents": A, "age": rng.integers(0, 100, A, dtype=np.int64),
                       "sex": rng.integers(0, 2, A, dtype=np.int64), "networks": list(NETWORKS[preset]),
                       "n_sets": len([s for s in spec if sets is None or s in sets])})
     for name, (per_agent, dist) in spec.items():
         if sets is not None and name not in sets:
             continue
-        es = _edge_set(rng, A, int(round(per_agent * edge_mult * A)), dist)
+        es = _edge_set(rng, A, int(round(per_agent * edge_mult * A)), dist, geo, GEOGRAPHY.get(name, (0.3, 0.05)))
         if progress:
             progress(f"generated edge set {name}: {len(es['agent'])} edges")
         yield ("set", name, es)
@@ -158,10 +256,11 @@ def epidemic_state(n_agents: int, infected_fraction: float, seed: int) -> Dict:
 
 
 def make_world(preset: str = "c3", n_agents: Optional[int] = None, seed: int = 1234,
-               infected_fraction: float = 0.01, sets=None, edge_mult: float = 1.0, progress=None) -> Dict:
+               infected_fraction: float = 0.01, sets=None, edge_mult: float = 1.0, progress=None,
+               geography: str = "random") -> Dict:
     """Returns {"n_agents", "age", "sex", "edge_sets", "networks", "state"} as numpy arrays."""
-    world: Dict = {"edge_sets": {}}
-    for piece in iter_world(preset, n_agents, seed, infected_fraction, sets, edge_mult, progress):
+    world: Dict = {"edge_sets": {}, "geography": geography}
+    for piece in iter_world(preset, n_agents, seed, infected_fraction, sets, edge_mult, progress, geography):
         if piece[0] == "header":
             world.update(piece[1])
         elif piece[0] == "set":

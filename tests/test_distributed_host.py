@@ -55,7 +55,7 @@ def test_partition_matches_single_rank(R):
     world = small_world()
     x = world["state"]["transmission"]
     ref = reference_pass(world, x)
-    modes = choose_modes(world, R)
+    modes = choose_modes(world, R)                 # the per-set rule (rounds 1-3), forced: every set whole
     assert set(modes.values()) == {"halo", "partial"}
     rws = [build_rank_world(world, r, R, modes, slice_agents=256) for r in range(R)]
     b = partition_bounds(world["n_agents"], R)
@@ -94,26 +94,35 @@ def test_partition_matches_single_rank(R):
 @pytest.mark.parametrize("R", [2, 5])
 def test_heavy_tailed_sets_are_split(R):
     """BASELINE config 5's power-law venues: a set whose mean venue is small but whose edges lie in huge venues is cut
-    into a halo half (venues of <= 8 attendees) and a partial-sum half; per agent the two halves add up to the
-    single-rank pass, and no rank's halo is blown up by a big venue."""
-    from grad_june_amd.distributed import SPLIT_SUFFIX, mode_of
+    into a local + halo half and a partial-sum half, venue by venue (classify_venues: n attendees on T ranks are a
+    partial-sum venue when the halo form would move more floats, n (T - 1), than the venue costs in the all-reduce,
+    2 k (R - 1)); per agent the two halves add up to the single-rank pass, and no rank's halo is blown up by a big venue."""
+    from grad_june_amd.distributed import SPLIT_SUFFIX, classify_venues, mode_of
 
     world = make_world("c5", n_agents=6000, seed=2)
     world["state"]["transmission"] = np.random.default_rng(1).random(6000).astype(np.float32)
     x = world["state"]["transmission"]
     ref = reference_pass(world, x)
     modes = choose_modes(world, R)
-    assert set(modes.values()) == {"split"}
+    assert set(modes.values()) == {"split"}           # (the per-set rule of rounds 1-3, GJ_EXCHANGE_RULE=set: cut at 8 attendees)
     assert mode_of(15, 10, R, np.array([1, 1, 1, 1, 1, 1, 1, 1, 1, 6])) == "halo"          # small mean, no tail
     assert mode_of(15_000_000, 6_000_000, R) == "halo" and mode_of(100, 5, R) == "partial" and mode_of(1, 1, 1) == "local"
-    rws = [build_rank_world(world, r, R, slice_agents=256) for r in range(R)]
     b = partition_bounds(world["n_agents"], R)
+    rws = [build_rank_world(world, r, R, slice_agents=256) for r in range(R)]
     xs = []
     for rw in rws:
         assert set(rw.edge_sets) == {n + sfx for n in world["edge_sets"] for sfx in ("", SPLIT_SUFFIX)}
         for n in world["edge_sets"]:
             assert rw.modes[n] == "halo" and rw.modes[n + SPLIT_SUFFIX] == "partial"
-            assert rw.edge_sets[n]["people"].max() <= 8 and rw.edge_sets[n + SPLIT_SUFFIX]["people"].min() > 8
+            es = world["edge_sets"][n]
+            k = 3 if n == "leisure" else 1            # pub, gym, grocery share the leisure set
+            partial, n_att, T = classify_venues(es["agent"], es["venue"], len(es["people"]), b, k)
+            assert np.array_equal(partial, n_att * (T - 1) > 2 * k * (R - 1)) and partial.any() and not partial.all()
+            # the partial-sum half holds exactly those venues, whole; the other half only venues this rank touches
+            assert np.array_equal(np.sort(rw.edge_sets[n + SPLIT_SUFFIX]["people"]), np.sort(es["people"][partial]))
+            kept = rw.venue_global[n]                 # the set's ids of the venues this rank keeps of the other half
+            assert not partial[kept].any() and (n_att[kept] * (T[kept] - 1) <= 2 * k * (R - 1)).all()
+            assert np.array_equal(rw.venue_global[n + SPLIT_SUFFIX], np.flatnonzero(partial))
         xe = np.zeros(rw.n_ext, dtype=np.float32)
         xe[: rw.n_local] = x[b[rw.rank]:b[rw.rank + 1]]
         xs.append(xe)
@@ -138,6 +147,80 @@ def test_heavy_tailed_sets_are_split(R):
     assert rws[0].n_halo < 0.8 * forced.n_halo
 
 
+def _ranks_equal_single_rank(world, R, slice_agents=256):
+    """Every rank's pass 1 + pass 2 on its part (default exchange rule: per-venue classes) against the single-rank
+    pass; returns the rank worlds and the partitioner's class counts."""
+    from grad_june_amd.distributed import SPLIT_SUFFIX, RankPartitioner
+
+    x = world["state"]["transmission"]
+    ref = reference_pass(world, x)
+    b = partition_bounds(world["n_agents"], R)
+    part = RankPartitioner(world["n_agents"], R, networks=world["networks"], n_sets=len(world["edge_sets"]))
+    for name, es in world["edge_sets"].items():
+        part.add_set(name, es["agent"], es["venue"], es["people"])
+    classes = dict(part.classes)
+    by_rank = part.finish(world["age"], world["sex"], slice_agents)
+    rws = [by_rank[r] for r in range(R)]
+    xs = []
+    for rw in rws:
+        xe = np.zeros(rw.n_ext, dtype=np.float32)
+        xe[: rw.n_local] = x[b[rw.rank]:b[rw.rank + 1]]
+        xs.append(xe)
+    emulate_exchange(rws, xs)
+    hosts = [compile_plan(rw.n_local, rw.edge_sets, age=rw.age, sex=rw.sex, n_ext_agents=rw.n_ext, layout="tiled",
+                          slices=(rw.n_slices, rw.slice_agents), sv_max=512, eb_target=4096) for rw in rws]
+    pre = {}
+    for rw, host, xe in zip(rws, hosts, xs):
+        for s in host.sets:
+            if rw.modes[s.name] == "partial":
+                pad = np.pad(xe, (0, host.n_slices * host.slice_agents - len(xe)))
+                pre.setdefault(s.name, []).append(emulate_pass1(s.tiled, pad, host.slice_agents, beta=1.0)[1])
+    total = {n: np.sum(v, axis=0) for n, v in pre.items()}
+    for rw, host, xe in zip(rws, hosts, xs):
+        cums, accs = rank_pass(rw, host, xe, lambda name, c: total[name])
+        lo, hi = b[rw.rank], b[rw.rank + 1]
+        for name in world["edge_sets"]:
+            both = sum(accs[n] for n in (name, name + SPLIT_SUFFIX) if n in accs)
+            assert np.allclose(both, ref[name][1][lo:hi], rtol=1e-5, atol=1e-6), name
+            for n in (name, name + SPLIT_SUFFIX):
+                if n in cums:
+                    vg = rw.venue_global[n]
+                    assert np.allclose(cums[n], ref[name][0] if vg is None else ref[name][0][vg], rtol=1e-5, atol=1e-7), n
+    return rws, classes
+
+
+@pytest.mark.parametrize("R", [2, 4, 8])
+def test_clustered_world_venues_are_classified_one_by_one(R):
+    """A world with a geography (synthetic.GEOGRAPHY: households of neighbours, venues in the own / a neighbouring
+    super area, a stated leak) under the household-major order: households are rank-local (no communication), only
+    venues that reach across a rank boundary are communicated, and the halo is a small fraction of the random world's."""
+    from grad_june_amd.synthetic import reorder_agents
+
+    n = 120_000
+    out = {}
+    for geography in ("clustered", "random"):
+        w = reorder_agents(make_world("c3", n_agents=n, seed=11, geography=geography), by="household")
+        w["state"]["transmission"] = np.random.default_rng(2).random(n).astype(np.float32)
+        out[geography] = _ranks_equal_single_rank(w, R)
+    rws, classes = out["clustered"]
+    rws_rnd, classes_rnd = out["random"]
+    hh = classes["household"]
+    assert hh["partial_sum"] == 0 and hh["local"] >= 0.995 * hh["venues"] and "household~big" not in rws[0].edge_sets
+    assert all(rw.modes["household"] == "halo" for rw in rws)
+    halo = max(rw.n_halo for rw in rws)
+    assert halo < 0.35 * max(rw.n_halo for rw in rws_rnd)      # (a 15 000-agent rank is three super areas: mostly border)
+    # small venues with every attendee on one rank never reach the all-reduce: the partial-sum buffer holds fewer
+    # venues than the sets have (the per-set rule of rounds 1-3 all-reduced every care home and company)
+    for s in ("care_home", "company"):
+        c = classes[s]
+        assert c["local"] + c["halo"] + c["partial_sum"] == c["venues"]
+        if s + "~big" in rws[0].edge_sets:
+            assert len(rws[0].edge_sets[s + "~big"]["people"]) == c["partial_sum"] < c["venues"]
+    # the random world has no locality to use: only venues of one or two attendees are ever local there
+    assert classes_rnd["company"]["local"] < classes["company"]["local"]
+    assert classes_rnd["household"]["local"] < 0.9 * classes_rnd["household"]["venues"]
+
+
 def test_single_rank_is_all_local():
     world = small_world(2000)
     rw = build_rank_world(world, 0, 1)
@@ -155,7 +238,8 @@ def _gloo_worker(rank, R, port, ok):
         world = small_world(3000, seed=9)
         x = world["state"]["transmission"]
         b = partition_bounds(3000, R)
-        rw = build_rank_world(world, rank, R, slice_agents=128)
+        rw = build_rank_world(world, rank, R, slice_agents=128)      # per-venue classes: most sets come in two halves
+        assert any(n.endswith("~big") for n in rw.edge_sets) and {"halo", "partial"} <= set(rw.modes.values())
         xe = torch.zeros(rw.n_ext)
         xe[: rw.n_local] = torch.from_numpy(x[b[rank]:b[rank + 1]])
         halo = HaloExchange(rw, "cpu")
@@ -169,12 +253,15 @@ def _gloo_worker(rank, R, port, ok):
         pad = np.pad(xe.numpy(), (0, host.n_slices * host.slice_agents - rw.n_ext))
         for s in host.sets:
             cum = emulate_pass1(s.tiled, pad, host.slice_agents, beta=1.0)[1]
+            whole = ref[s.name.split("~")[0]][0]                     # the whole set's per-venue sums, by the set's venue ids
+            vg = rw.venue_global[s.name]
+            want = whole if vg is None else whole[vg]
             if rw.modes[s.name] == "partial":
                 t = torch.from_numpy(cum.copy())
                 dist.all_reduce(t)
-                assert np.allclose(t.numpy(), ref[s.name][0], rtol=1e-5, atol=1e-7), s.name
+                assert np.allclose(t.numpy(), want, rtol=1e-5, atol=1e-7), s.name
             else:
-                assert np.allclose(cum, ref[s.name][0][rw.venue_global[s.name]], rtol=1e-5, atol=1e-7), s.name
+                assert np.allclose(cum, want, rtol=1e-5, atol=1e-7), s.name
         ok[rank] = 1
     finally:
         dist.destroy_process_group()

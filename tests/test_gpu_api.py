@@ -217,6 +217,35 @@ def test_transmission_updater_and_sampler(G, device):
     assert G.TransmissionUpdater()(data=d, timer=t).sum() == 0
 
 
+def test_transmission_profile_negative_base(G, device):
+    """transmission.py:45-49 with t < shift: ``torch.pow`` of a negative base is finite for an INTEGER exponent
+    (shape - 1) and the sign factor makes the product 0; for a non-integer exponent it is NaN and 0 * NaN = NaN
+    (the v_log/v_exp form of pow returned NaN for every negative base).  Forward and the adjoint."""
+    d = conftest_world(G, device)
+    n = 100
+    ag = d["agent"]
+    shape = torch.tensor([2.0, 3.0, 4.0, 1.0, 1.56], device=device).repeat(n // 5)
+    ag.infection_parameters = {"max_infectiousness": torch.full((n,), 1.3, device=device), "shape": shape,
+                               "rate": torch.full((n,), 0.53, device=device),
+                               "shift": torch.full((n,), 7.5, device=device)}       # positive: t - shift < 0 at t = 5
+    ag.is_infected = torch.ones(n, device=device)
+    ag.infection_time = torch.zeros(n, device=device)
+    t = day_timer(G, ["household"])
+    for _ in range(5):
+        next(t)
+    ip = {k: v.cpu() for k, v in ag.infection_parameters.items()}
+    for now_shift in (0.0, 6.0):                    # t - shift = -2.5 (negative base), then +3.5 (the ordinary branch)
+        ag.infection_time = torch.full((n,), -now_shift, device=device)
+        ref = O.transmission_update(ip["max_infectiousness"], ip["shape"], ip["rate"], ip["shift"],
+                                    ag.infection_time.cpu(), ag.is_infected.cpu(), t.now)
+        got = G.TransmissionUpdater()(data=d, timer=t).cpu()
+        assert torch.equal(torch.isnan(got), torch.isnan(ref))
+        ok = ~torch.isnan(ref)
+        assert np.allclose(got[ok].numpy(), ref[ok].numpy(), rtol=2e-5, atol=1e-12)
+        if now_shift == 0.0:
+            assert (got[shape != 1.56] == 0).all() and torch.isnan(got[shape == 1.56]).all()
+
+
 def test_is_infected_sampler_statistics(G, device):
     """infection_networks/test_is_infected_sampler.py:7-24 (mean of 2000 draws ~ 1-p, rtol 0.1)."""
     sampler = G.IsInfectedSampler()

@@ -403,10 +403,12 @@ def _grad_worker(rank, R, port, out, modes):
                 return m
 
             D.mode_of = forced
+            D.EXCHANGE_RULE = "set"        # whole sets in the forced mode (default "venue": classes venue by venue)
         torch.manual_seed(33)
         res, grads = run(DistributedRunner.from_parameters(params()))
         if modes:
             D.mode_of = real
+            D.EXCHANGE_RULE = "venue"
         gathered = [None] * R
         dist.all_gather_object(gathered, grads)
         assert gathered[0] == gathered[1], "every rank holds the whole gradient"

@@ -99,3 +99,17 @@ def test_argument_errors_do_not_need_a_gpu(lib):
     assert lib.gj_compile_capacity(ctypes.byref(cs), None, None, None) == -2
     cs.slice_agents, cs.n_edges = 64, 5                       # edges without edge lists
     assert lib.gj_compile_blocks(ctypes.byref(cs), None, 1, None, None, 0, None) == -1
+
+
+def test_building_the_library_does_not_load_the_oracle():
+    """The oracle is test infrastructure: ``__graft_entry__.build()`` - which bench.py calls before its timed regions -
+    must neither import it nor make ``oracle/`` / ``tests/`` importable (only smoke() and cpu_baseline() do)."""
+    import subprocess
+    import sys
+
+    code = ("import sys, __graft_entry__ as g; g.build(); "
+            "assert 'gj_oracle' not in sys.modules and 'gj_testlib' not in sys.modules; "
+            "assert not any(p.rstrip('/').endswith(('/oracle', '/tests')) for p in sys.path), sys.path; print('clean')")
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "clean" in r.stdout, r.stderr[-2000:]

@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """What ONE rank of an N-GPU run does, measured on one GPU: the rank's share of the benchmark world is built exactly
-as `bench.py --gpus N` builds it (streamed set by set, household-major order, exchange modes by `distributed.mode_of`),
+as `bench.py --gpus N` builds it (streamed set by set, household-major order, exchange classes venue by venue -
+`distributed.classify_venues`; `--exchange-rule set` = the per-set rule of rounds 1-3, `distributed.mode_of`),
 compiled, and stepped WITHOUT the collectives (halo slots and remote partial sums stay zero: the kernels' work does
 not depend on the values).  Prints one JSON line: the rank's kernel time per step, its halo and partial-sum volumes
 (what the two collectives would move) and the host memory the set-up needed.
 
     python tools/rank_share.py --preset c5 --agents 100000000 --of 8 [--rank 0] [--steps 20]
+    python tools/rank_share.py --geography clustered --of 8          # a world with a geography (synthetic.GEOGRAPHY)
 """
 from __future__ import annotations
 
@@ -32,14 +34,18 @@ def main():
     ap.add_argument("--eb-target", type=int, default=None)
     ap.add_argument("--sv-max", type=int, default=None)
     ap.add_argument("--slice-agents", type=int, default=None, help="agents per slice (default: sized for the owned agents)")
+    ap.add_argument("--geography", default="random", choices=["random", "clustered"])
+    ap.add_argument("--exchange-rule", default="venue", choices=["venue", "set"])
     a = ap.parse_args()
     import torch
 
     import __graft_entry__ as entry
     import bench as B
+    from grad_june_amd import distributed as D
     from grad_june_amd.distributed import DistributedHotPath, stream_rank_share
     from grad_june_amd.synthetic import iter_world
 
+    D.EXCHANGE_RULE = a.exchange_rule
     entry.build()
     dev = torch.device("cuda:0")
     t0 = time.time()
@@ -48,7 +54,7 @@ def main():
         print(f"[rank_share {time.time() - t0:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
     rw, share = stream_rank_share(iter_world(a.preset, n_agents=a.agents, seed=a.seed, infected_fraction=0.01,
-                                             progress=progress),
+                                             progress=progress, geography=a.geography),
                                   a.rank, a.of, reorder="household", progress=progress, slice_agents=a.slice_agents)
     t_part = time.time() - t0
     world = {"n_agents": share["n_agents"], "networks": share["networks"], "state": share["state"],
@@ -73,8 +79,8 @@ def main():
     out = {
         "what": f"rank {a.rank} of {a.of}: kernels of one step on its share, collectives not executed",
         "geometry": {"slice_agents": int(rw.slice_agents), "n_slices": int(rw.n_slices), "eb_target": a.eb_target, "sv_max": a.sv_max},
-        "preset": a.preset, "n_agents_world": share["n_agents"], "n_owned": int(rw.n_local), "n_halo": int(rw.n_halo),
-        "modes": rw.modes,
+        "preset": a.preset, "geography": a.geography, "exchange_rule": a.exchange_rule, "n_agents_world": share["n_agents"], "n_owned": int(rw.n_local), "n_halo": int(rw.n_halo),
+        "modes": rw.modes, "venue_classes": share["classes"],
         "local_set_edges": {k: int(len(v["agent"])) for k, v in rw.edge_sets.items()},
         "halo_all_to_all_bytes_in_per_step": 4 * int(rw.n_halo),
         "partial_sum_all_reduce_bytes_per_step": 4 * int(hp.flat_cum.numel()) if hp.flat_cum is not None else 0,
