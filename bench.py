@@ -67,10 +67,12 @@ def parse():
     ap.add_argument("--direct", default="auto", choices=["auto", "off"],
                     help="pass 2 of sets with few venues straight from an LDS table of venue values (auto) or, like the "
                          "other sets, through the per-edge workspace (off)")
-    ap.add_argument("--generator", default="numpy", choices=["numpy", "torch"],
-                    help="numpy: the seeded generator of synthetic.make_world (what every committed figure uses); torch: the "
-                         "same distributions drawn on the device in seconds (synthetic.make_world_torch - another random "
-                         "world; for 1e8-agent runs, where numpy needs half an hour)")
+    ap.add_argument("--generator", default="auto", choices=["auto", "numpy", "torch"],
+                    help="numpy: the seeded generator of synthetic.make_world (what every committed headline figure uses); "
+                         "torch: the same distributions drawn on the device in seconds (synthetic.iter_world_torch - another "
+                         "random world; N > 1: every rank draws the same seeded stream on its own GPU and cuts its share out "
+                         "there, nothing touches host memory); auto: numpy up to 4e7 agents, torch above (1e8 agents: numpy "
+                         "needs most of an hour and 18 GB per rank)")
     ap.add_argument("--runs", default="auto", choices=["auto", "off"],
                     help="run form of the edge set that orders the agents (households under --reorder household): one "
                          "edge per agent read from the per-agent arrays instead of the tiled index arrays (auto) or "
@@ -276,7 +278,7 @@ def cached_world(args, progress, make_world):
 
             n = args.agents or {"c2": 1_000_000, "c3": 10_000_000, "c5": 100_000_000}[args.preset]
             w = make_world_torch(args.preset, n, args.seed, torch.device("cuda", torch.cuda.current_device()),
-                                 infected_fraction=args.infected)
+                                 infected_fraction=args.infected, geography=args.geography)
             for es in w["edge_sets"].values():      # the partitioner and the locality order work on host arrays
                 es["agent"], es["venue"] = es["agent"].cpu().numpy(), es["venue"].cpu().numpy()
             torch.cuda.empty_cache()
@@ -534,6 +536,9 @@ def capture_validated(runner, dev, backend, dist):
 
 def main():
     args = parse()
+    if args.generator == "auto":
+        n_default = {"c2": 1_000_000, "c3": 10_000_000, "c5": 100_000_000}[args.preset]
+        args.generator = "torch" if (args.agents or n_default) > 40_000_000 else "numpy"
     if args.only_headline:
         args.no_cpu_baseline, args.high_prevalence = True, 0.0
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -590,12 +595,19 @@ def main():
         # every rank draws the world set by set from the same seeded generator and keeps only ITS share of each set
         # (no rank ever holds the whole COO, nothing is communicated)
         from grad_june_amd.distributed import stream_rank_share
-        from grad_june_amd.synthetic import iter_world
+        from grad_june_amd.synthetic import iter_world, iter_world_torch
 
-        rw, share = stream_rank_share(
-            iter_world(args.preset, n_agents=args.agents, seed=args.seed, infected_fraction=args.infected,
-                       edge_mult=args.edge_mult, progress=progress, geography=args.geography),
-            rank, world_size, reorder=None if reorder == "none" else reorder, progress=progress)
+        if args.generator == "torch":
+            n = args.agents or {"c2": 1_000_000, "c3": 10_000_000, "c5": 100_000_000}[args.preset]
+            pieces = iter_world_torch(args.preset, n, args.seed, dev, infected_fraction=args.infected,
+                                      geography=args.geography, progress=progress)
+        else:
+            pieces = iter_world(args.preset, n_agents=args.agents, seed=args.seed, infected_fraction=args.infected,
+                                edge_mult=args.edge_mult, progress=progress, geography=args.geography)
+        rw, share = stream_rank_share(pieces, rank, world_size, reorder=None if reorder == "none" else reorder,
+                                      progress=progress)
+        del pieces
+        torch.cuda.empty_cache()
         world = {"n_agents": share["n_agents"], "networks": share["networks"], "state": share["state"],
                  "edge_sets": {k: {"n_edges": e, "n_venues": v} for k, (e, v) in share["sizes"].items()}}
     else:

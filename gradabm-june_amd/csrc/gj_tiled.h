@@ -34,6 +34,9 @@ constexpr int kVenueUnrollC = GJ_VENUE_UNROLL_C;  // same, phase C
 #define GJ_CUM_BATCH 8
 #endif
 constexpr int kCumBatch = GJ_CUM_BATCH;        // venues per lane whose p_contact loads are in flight together (cum write-out)
+#ifndef GJ_DMA_WIDE
+#define GJ_DMA_WIDE 0
+#endif
 
 // LDS float atomics run at 0.33 lanes/clk/CU on gfx950 (measured, tools/microbench/lds_atomics.hip)
 // against 4.9 for ds_add_u64 and 7.3 for ds_add_u32, so the per-venue and per-agent sums are kept
@@ -1273,8 +1276,20 @@ __device__ __forceinline__ void direct_stage(const TileDArgs& D, const TDirect& 
   const float* src = T.cum + (int64_t)v0 * T.stride;
   const int n = nv * T.stride;
   const int lane = tid % kWave, wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+#if GJ_DMA_WIDE
+  // gfx950's 16-byte LDS-DMA (global_load_lds_dwordx4): 1 KiB per wave-instruction instead of 256 bytes - a quarter of
+  // the instructions for the whole pieces, the 4-byte form for the remainder (a lane must not read past the table).
+  // Only when both ends are 16-byte aligned (wave-uniform; a run-form window starts at any venue)
+  const bool aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(tab)) & 15u) == 0;
+  const int n_wide = aligned ? (n / (4 * kWave)) * (4 * kWave) : 0;
+  for (int p = wave; (p + 1) * 4 * kWave <= n_wide; p += kTileWaves)
+    __builtin_amdgcn_global_load_lds(src + p * 4 * kWave + 4 * lane, tab + p * 4 * kWave, 16, 0, 0);
+  for (int p = wave; n_wide + p * kWave < n; p += kTileWaves)
+    __builtin_amdgcn_global_load_lds(src + min(n_wide + p * kWave + lane, n - 1), tab + n_wide + p * kWave, 4, 0, 0);
+#else
   for (int p = wave; p * kWave < n; p += kTileWaves)
     __builtin_amdgcn_global_load_lds(src + min(p * kWave + lane, n - 1), tab + p * kWave, 4, 0, 0);
+#endif
 #endif
 }
 

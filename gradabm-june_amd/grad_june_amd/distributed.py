@@ -61,6 +61,14 @@ def classify_venues(agent: np.ndarray, venue: np.ndarray, n_venues: int, bounds:
     A boundary household is a halo venue, a school with one pupil from the next rank or a 50 000-attendee venue a
     partial-sum one.  Returns (partial[V] bool, n[V], T[V])."""
     R = len(bounds) - 1
+    if isinstance(agent, torch.Tensor):          # the same on the device (a streamed 1e8-agent world never leaves it)
+        b = torch.as_tensor(np.asarray(bounds), device=agent.device)
+        owner = torch.searchsorted(b, agent, right=True) - 1
+        cnt = torch.bincount(venue * R + owner, minlength=n_venues * R).view(n_venues, R)
+        n = cnt.sum(1)
+        T = (cnt > 0).sum(1)
+        del cnt, owner
+        return n * (T - 1) > factor * 2.0 * max(1, nets_on_set) * (R - 1), n, T
     owner = np.searchsorted(bounds, agent, side="right") - 1
     cnt = np.bincount(venue * R + owner, minlength=n_venues * R).reshape(n_venues, R)
     n = cnt.sum(1)
@@ -176,13 +184,21 @@ class RankPartitioner:
         self.classes: Dict[str, dict] = {}         # per set: venues by exchange class (global counts; reporting)
 
     def add_set(self, name: str, agent, venue, people) -> str:
-        agent = np.asarray(agent, dtype=np.int64).ravel()
-        venue = np.asarray(venue, dtype=np.int64).ravel()
-        people = np.asarray(people)
+        """``agent`` / ``venue`` / ``people``: numpy arrays, or torch tensors (any device) - the part is then cut out with
+        torch ops where the tensors live and the rank world's edge lists stay there (``compile_plan(device=...)``)."""
+        on_torch = isinstance(agent, torch.Tensor)
+        if on_torch:
+            agent, venue = agent.to(torch.int64).reshape(-1), venue.to(torch.int64).reshape(-1)
+            people = torch.as_tensor(people, device=agent.device)
+        else:
+            agent = np.asarray(agent, dtype=np.int64).ravel()
+            venue = np.asarray(venue, dtype=np.int64).ravel()
+            people = np.asarray(people)
         mode = self.mode_override.get(name)
         big = None
         if mode is None and (EXCHANGE_RULE == "set" or self.world_size == 1):
-            mode = mode_of(len(agent), len(people), self.world_size, people)
+            mode = mode_of(len(agent), len(people), self.world_size,
+                           people.cpu().numpy() if on_torch and self.world_size > 1 else (None if on_torch else people))
         elif mode is None:
             mode, big = self._mode_by_venue(name, agent, venue, len(people))
         self.total_edges += len(agent)
@@ -197,10 +213,14 @@ class RankPartitioner:
             # forced / per-set form of rounds 2-3 cuts by size: venues of up to HALO_MAX_MEAN_DEGREE attendees are halo.)
             if big is None:
                 big = people > HALO_MAX_MEAN_DEGREE
+            if on_torch and not isinstance(big, torch.Tensor):
+                big = torch.as_tensor(big, device=agent.device)
             e_big = big[venue]
+            xp = torch if on_torch else np
             for part, sel_v, sel_e, m in ((name, ~big, ~e_big, "halo"), (name + SPLIT_SUFFIX, big, e_big, "partial")):
-                remap = np.cumsum(sel_v) - 1
-                self._add_part(part, agent[sel_e], remap[venue[sel_e]], people[sel_v], m, np.flatnonzero(sel_v))
+                remap = xp.cumsum(sel_v, 0) - 1
+                ids = torch.nonzero(sel_v).reshape(-1) if on_torch else np.flatnonzero(sel_v)
+                self._add_part(part, agent[sel_e], remap[venue[sel_e]], people[sel_v], m, ids)
             return mode
         self._add_part(name, agent, venue, people, mode)
         return mode
@@ -212,7 +232,7 @@ class RankPartitioner:
         partial, n, T = classify_venues(agent, venue, n_venues, self.bounds, k)
         used = n > 0
         n_part, n_ex = int((partial & used).sum()), int((~partial & used).sum())
-        halo_saved = float((n * (T - 1))[partial].sum())
+        halo_saved = float((n * (T - 1))[partial].sum()) if n_part else 0.0
         self.classes[name] = {"venues": int(used.sum()), "local": int((T == 1).sum()),
                               "halo": int((~partial & (T > 1)).sum()), "partial_sum": n_part,
                               "edges_in_partial_sum_venues": int(n[partial].sum())}
@@ -258,6 +278,8 @@ class RankPartitioner:
         ``venue_global`` then maps a rank's local venues to ids of the WHOLE set."""
         self.modes[name] = mode
         b = self.bounds
+        if isinstance(agent, torch.Tensor):
+            return self._add_part_torch(name, agent, venue, people, mode, part_venues)
         if len(self.ranks) > 2:
             # every rank's own edges with one stable sort by owner (COO order kept inside a rank)
             owner = np.searchsorted(b, agent, side="right") - 1
@@ -284,7 +306,33 @@ class RankPartitioner:
             self.venue_global[r][name] = vg if part_venues is None else part_venues[vg]
             self.halo_lists[r].append(np.unique(ag[(ag < b[r]) | (ag >= b[r + 1])]))
 
+    def _add_part_torch(self, name, agent, venue, people, mode, part_venues) -> None:
+        """``_add_part`` with torch ops on the tensors' device; the part's ``people`` go to the host (the graph
+        compile takes p_contact from there), everything per edge stays."""
+        b = self.bounds
+        V = int(people.numel())
+        for r in self.ranks:
+            mine = (agent >= int(b[r])) & (agent < int(b[r + 1]))
+            if mode in ("partial", "local"):
+                self.local_sets[r][name] = {"agent_global": agent[mine], "venue": venue[mine],
+                                            "people": people.cpu().numpy()}
+                self.venue_global[r][name] = None if part_venues is None else part_venues.cpu().numpy()
+                continue
+            touched = torch.zeros(V, dtype=torch.bool, device=agent.device)
+            touched[venue[mine]] = True
+            keep = touched[venue]                                  # every edge of a touched venue, local or remote, COO order
+            vg = torch.nonzero(touched).reshape(-1)
+            remap = torch.full((V,), -1, dtype=torch.int64, device=agent.device)
+            remap[vg] = torch.arange(vg.numel(), device=agent.device)
+            ag = agent[keep]
+            self.local_sets[r][name] = {"agent_global": ag, "venue": remap[venue[keep]], "people": people[vg].cpu().numpy()}
+            self.venue_global[r][name] = (vg if part_venues is None else part_venues[vg]).cpu().numpy()
+            self.halo_lists[r].append(torch.unique(ag[(ag < int(b[r])) | (ag >= int(b[r + 1]))]))
+
     def finish(self, age, sex, slice_agents: Optional[int] = None) -> Dict[int, "RankWorld"]:
+        if any(isinstance(x, torch.Tensor) for hl in self.halo_lists.values() for x in hl) or any(
+                isinstance(ls["agent_global"], torch.Tensor) for sets in self.local_sets.values() for ls in sets.values()):
+            return self._finish_torch(age, sex, slice_agents)
         age, sex = np.asarray(age), np.asarray(sex)
         out = {}
         for r in self.ranks:
@@ -321,6 +369,65 @@ class RankPartitioner:
                                dict(self.venue_global[r]))
         self.local_sets = self.halo_lists = self.venue_global = None      # consumed
         return out
+
+
+def _finish_torch_impl(self, age, sex, slice_agents):
+    """``RankPartitioner.finish`` for parts cut out on a device: the extended indices are computed there, the edge lists
+    stay there; the halo list, age and sex of the extended range come to the host (small)."""
+    out = {}
+    for r in self.ranks:
+        a0, a1 = int(self.bounds[r]), int(self.bounds[r + 1])
+        n_local = a1 - a0
+        hl = self.halo_lists[r]
+        dev = None
+        for ls in self.local_sets[r].values():
+            if isinstance(ls["agent_global"], torch.Tensor):
+                dev = ls["agent_global"].device
+        halo_t = torch.unique(torch.cat(hl)) if hl else torch.zeros(0, dtype=torch.int64, device=dev)
+        halo_global = halo_t.cpu().numpy()
+        owner = np.searchsorted(self.bounds, halo_global, side="right") - 1
+        halo_from = np.bincount(owner, minlength=self.world_size).astype(np.int64)
+        sa = slice_agents
+        if sa is None:
+            _, sa = TL.choose_slices(n_local + len(halo_global) if os.environ.get("GJ_RANK_SLICES", "owned") == "ext"
+                                     else n_local)
+        n_local_pad = -(-n_local // sa) * sa if len(halo_global) else n_local
+        n_ext = n_local_pad + len(halo_global)
+        n_slices = max(1, -(-n_ext // sa))
+        edge_sets = {}
+        for name, ls in self.local_sets[r].items():
+            g = ls.pop("agent_global")
+            if not isinstance(g, torch.Tensor):
+                g = torch.as_tensor(g, device=dev)
+            ext = g - a0
+            rem = (g < a0) | (g >= a1)
+            if len(halo_global):
+                ext = torch.where(rem, n_local_pad + torch.searchsorted(halo_t, g), ext)
+            elif bool(rem.any()):
+                raise RuntimeError("a remote attendee without a halo list")
+            edge_sets[name] = {"agent": ext, "venue": ls["venue"], "people": ls["people"]}
+
+        def ext_attr(v):
+            if isinstance(v, torch.Tensor):
+                o = torch.full((n_ext,), int(v[0]), dtype=v.dtype, device=v.device)   # (padding rows: agent 0's, as finish())
+                o[:n_local] = v[a0:a1]
+                if len(halo_global):
+                    o[n_local_pad:] = v[halo_t.to(v.device)]
+                return o.cpu().numpy()
+            v = np.asarray(v)
+            o = np.full(n_ext, v[0], dtype=v.dtype)
+            o[:n_local] = v[a0:a1]
+            o[n_local_pad:] = v[halo_global]
+            return o
+
+        out[r] = RankWorld(r, self.world_size, self.bounds, n_local, sa, n_local_pad, n_ext, n_slices, halo_global,
+                           halo_from, ext_attr(age), ext_attr(sex), edge_sets, dict(self.modes),
+                           dict(self.venue_global[r]))
+    self.local_sets = self.halo_lists = self.venue_global = None      # consumed
+    return out
+
+
+RankPartitioner._finish_torch = _finish_torch_impl
 
 
 def build_rank_worlds(world: dict, world_size: int, ranks: Optional[Sequence[int]] = None,
@@ -378,9 +485,10 @@ def stream_rank_share(pieces, rank: int, world_size: int, reorder: Optional[str]
     sex = header["sex"] if order is None else header["sex"][order]
     total_edges, sizes, classes = part.total_edges, dict(part.sizes), dict(part.classes)
     rw = part.finish(age, sex, slice_agents)[rank]
-    share = {"networks": header["networks"], "state": {k: np.ascontiguousarray(pick(v)) for k, v in state.items()},
+    host = lambda v: v.cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+    share = {"networks": header["networks"], "state": {k: np.ascontiguousarray(host(pick(v))) for k, v in state.items()},
              "n_agents": header["n_agents"], "total_edges": total_edges, "sizes": sizes, "classes": classes,
-             "original_id": (np.arange(a0, a1) if order is None else order[a0:a1])}
+             "original_id": (np.arange(a0, a1) if order is None else host(order[a0:a1]))}
     return rw, share
 
 
@@ -781,6 +889,8 @@ class DistributedHotPath:
                 w = torch.full((V,), 1.0 if self.rank == 0 else 0.0, dtype=torch.float64, device=self.device)
             else:
                 es = rw.edge_sets[set_name]
+                host = lambda t: t.cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+                es = {"agent": host(es["agent"]), "venue": host(es["venue"])}
                 ext = np.asarray(es["agent"], dtype=np.int64)
                 gid = np.where(ext < rw.n_local, ext + self.a0,
                                rw.halo_global[np.clip(ext - rw.n_local_pad, 0, max(0, rw.n_halo - 1))] if rw.n_halo

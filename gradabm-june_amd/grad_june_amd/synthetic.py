@@ -270,8 +270,18 @@ def make_world(preset: str = "c3", n_agents: Optional[int] = None, seed: int = 1
     return world
 
 
-def locality_permutation(n_agents: int, agent: np.ndarray, venue: np.ndarray):
-    """(order, new_of) of ``reorder_agents`` from the edge set that defines the locality order."""
+def locality_permutation(n_agents: int, agent, venue):
+    """(order, new_of) of ``reorder_agents`` from the edge set that defines the locality order (numpy arrays, or torch
+    tensors on any device - the same permutation)."""
+    if not isinstance(agent, np.ndarray) and hasattr(agent, "device"):
+        import torch
+
+        first = torch.full((n_agents,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=agent.device)
+        first.scatter_reduce_(0, agent, venue, reduce="amin", include_self=True)
+        order = torch.sort(first, stable=True)[1]
+        new_of = torch.empty_like(order)
+        new_of[order] = torch.arange(n_agents, device=agent.device)
+        return order, new_of
     first = np.full(n_agents, np.iinfo(np.int64).max, dtype=np.int64)
     np.minimum.at(first, agent, venue)
     order = np.argsort(first, kind="stable")            # new position -> original id
@@ -280,15 +290,19 @@ def locality_permutation(n_agents: int, agent: np.ndarray, venue: np.ndarray):
     return order, new_of
 
 
-def make_world_torch(preset: str, n_agents: int, seed: int, device, infected_fraction: float = 0.01) -> Dict:
-    """A world of the same shape as ``make_world``'s, drawn with torch's generator ON ``device`` in seconds (the
-    numpy generator needs minutes for 10^8 edges): the edge lists stay on the device as int64 tensors - what
-    ``compile_plan(device=...)`` takes - and the per-agent arrays come back as numpy.  A different random world than
-    ``make_world(seed)``, with the same distributions (venue sizes, memberships per agent, unsorted COO; the rare
-    duplicate (agent, venue) pairs are kept - the reference's format allows them).  For the large-size property
-    tests, which check the kernels against sums taken from the very same edge lists."""
+def iter_world_torch(preset: str, n_agents: int, seed: int, device, infected_fraction: float = 0.01,
+                     geography: str = "random", progress=None):
+    """``iter_world`` drawn with torch's generator ON ``device``: the same pieces in the same order, every array a
+    device tensor (int64 edge lists, ``people``; float32 state; int64 age / sex).  A 10^8-agent world streams in
+    seconds where the numpy generator needs most of an hour, and nothing touches host memory - what the ranks of
+    ``bench.py --gpus N`` consume (``distributed.stream_rank_share``: every rank draws the SAME seeded stream on its own
+    GPU and keeps its share of each set before the next one is drawn; identical GPUs give identical streams).
+    A different random world than ``iter_world(seed)``, with the same distributions; the rare duplicate
+    (agent, venue) pairs are kept - the reference's format allows them."""
     import torch
 
+    if geography not in ("random", "clustered"):
+        raise ValueError(f"geography {geography!r}: 'random' or 'clustered'")
     dev = torch.device(device)
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
@@ -318,9 +332,32 @@ def make_world_torch(preset: str, n_agents: int, seed: int, device, infected_fra
         sizes[last] -= cs[last] - n_edges
         return sizes[sizes > 0]
 
-    world = {"preset": preset, "n_agents": A, "networks": list(NETWORKS[preset]), "edge_sets": {},
-             "age": torch.randint(0, 100, (A,), device=dev, generator=g).cpu().numpy(),
-             "sex": torch.randint(0, 2, (A,), device=dev, generator=g).cpu().numpy()}
+    geo = None
+    if geography == "clustered":
+        m = super_area_map(A)
+        geo = {"sa": m["sa_agents"], "n_sa": m["n_sa"], "nb": torch.from_numpy(m["nb"]).to(dev),
+               "nb_n": torch.from_numpy(m["nb_n"]).to(dev)}
+
+    def keys_of(agent, mix):        # synthetic._membership_keys on the device
+        E = agent.numel()
+        if mix is None:
+            return agent.double() + (3.0 * torch.rand(E, device=dev, dtype=torch.float64, generator=g) - 1.5)
+        p_near, p_leak = mix
+        home = agent // geo["sa"]
+        u = torch.rand(E, device=dev, generator=g)
+        target = home.clone()
+        near = (u >= 1.0 - p_near - p_leak) & (u < 1.0 - p_leak) & (geo["nb_n"][home] > 0)
+        h = home[near]
+        pick = (torch.rand(h.numel(), device=dev, generator=g) * geo["nb_n"][h]).to(torch.int64).clamp_(max=7)
+        target[near] = geo["nb"][h, pick]
+        leak = u >= 1.0 - p_leak
+        target[leak] = torch.randint(0, geo["n_sa"], (int(leak.sum()),), device=dev, generator=g)
+        return (target.double() + torch.rand(E, device=dev, dtype=torch.float64, generator=g)) * float(geo["sa"])
+
+    yield ("header", {"preset": preset, "n_agents": A, "networks": list(NETWORKS[preset]), "n_sets": len(spec),
+                      "geography": geography,
+                      "age": torch.randint(0, 100, (A,), device=dev, generator=g),
+                      "sex": torch.randint(0, 2, (A,), device=dev, generator=g)})
     for name, (per_agent, dist) in spec.items():
         E = int(round(per_agent * A))
         sizes = sizes_for(dist, E)
@@ -330,22 +367,49 @@ def make_world_torch(preset: str, n_agents: int, seed: int, device, infected_fra
         parts = [torch.arange(A, device=dev).repeat(base)] if base else []
         if extra:
             parts.append(torch.randperm(A, device=dev, generator=g)[:extra])
-        agent = torch.cat(parts)[torch.randperm(E, device=dev, generator=g)]       # memberships dealt to venue slots
+        agent = torch.cat(parts)
+        del parts
+        if geo is None:
+            agent = agent[torch.randperm(E, device=dev, generator=g)]                # memberships dealt to venue slots
+        else:
+            agent = agent[torch.sort(keys_of(agent, GEOGRAPHY.get(name, (0.3, 0.05))), stable=True)[1]]
         perm = torch.randperm(E, device=dev, generator=g)                           # unsorted COO
         agent, venue = agent[perm].contiguous(), venue[perm].contiguous()
-        world["edge_sets"][name] = {"agent": agent, "venue": venue, "people": sizes.cpu().numpy()}
-    rng = np.random.default_rng(seed)
-    inf = (rng.random(A) < infected_fraction).astype(np.float32)
-    world["state"] = {
-        "max_infectiousness": rng.lognormal(0.0, 0.5, A).astype(np.float32),
-        "shape": rng.normal(1.56, 0.08, A).astype(np.float32),
-        "rate": rng.normal(0.53, 0.03, A).astype(np.float32),
-        "shift": rng.normal(-2.12, 0.1, A).astype(np.float32),
+        del perm
+        if progress:
+            progress(f"drew edge set {name} on the device: {E} edges")
+        yield ("set", name, {"agent": agent, "venue": venue, "people": sizes})
+        del agent, venue
+    f32 = dict(device=dev, dtype=torch.float32, generator=g)
+    inf = (torch.rand(A, **f32) < infected_fraction).float()
+    yield ("state", {
+        "max_infectiousness": torch.exp(0.5 * torch.randn(A, **f32)),
+        "shape": 1.56 + 0.08 * torch.randn(A, **f32),
+        "rate": 0.53 + 0.03 * torch.randn(A, **f32),
+        "shift": -2.12 + 0.1 * torch.randn(A, **f32),
         "is_infected": inf,
-        "susceptibility": (1.0 - inf).astype(np.float32),
-        "infection_time": (-10.0 * rng.random(A)).astype(np.float32) * inf,
-        "current_stage": np.where(inf > 0, rng.integers(2, 6, A), 1).astype(np.float32),
-    }
+        "susceptibility": 1.0 - inf,
+        "infection_time": -10.0 * torch.rand(A, **f32) * inf,
+        "current_stage": torch.where(inf > 0, torch.randint(2, 6, (A,), device=dev, generator=g).float(),
+                                     torch.ones(A, device=dev)),
+    })
+
+
+def make_world_torch(preset: str, n_agents: int, seed: int, device, infected_fraction: float = 0.01,
+                     geography: str = "random") -> Dict:
+    """A world of the same shape as ``make_world``'s, drawn with torch's generator ON ``device`` in seconds
+    (``iter_world_torch`` assembled): the edge lists stay on the device as int64 tensors - what
+    ``compile_plan(device=...)`` takes - and the per-agent arrays come back as numpy.  For the large-size property
+    tests, which check the kernels against sums taken from the very same edge lists."""
+    world: Dict = {"edge_sets": {}}
+    for piece in iter_world_torch(preset, n_agents, seed, device, infected_fraction, geography):
+        if piece[0] == "header":
+            world.update({k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in piece[1].items()})
+        elif piece[0] == "set":
+            es = piece[2]
+            world["edge_sets"][piece[1]] = {"agent": es["agent"], "venue": es["venue"], "people": es["people"].cpu().numpy()}
+        else:
+            world["state"] = {k: v.cpu().numpy() for k, v in piece[1].items()}
     return world
 
 

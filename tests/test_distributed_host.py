@@ -221,6 +221,41 @@ def test_clustered_world_venues_are_classified_one_by_one(R):
     assert classes_rnd["household"]["local"] < 0.9 * classes_rnd["household"]["venues"]
 
 
+@pytest.mark.parametrize("geography", ["random", "clustered"])
+@pytest.mark.parametrize("R", [2, 8])
+def test_torch_streamed_share_equals_the_numpy_partition(geography, R):
+    """``bench.py --gpus N`` draws the world with torch's generator on every rank's own GPU (iter_world_torch) and cuts
+    the rank's part out with torch ops where the tensors live (here: CPU tensors, the same code path): array for array
+    what the numpy partitioner makes of the assembled world - per-venue classes, split halves, halo lists, extended
+    indices, the owned agents' state."""
+    from grad_june_amd.distributed import stream_rank_share
+    from grad_june_amd.synthetic import iter_world_torch, make_world_torch, reorder_agents
+
+    n = 60_000
+    w = make_world_torch("c3", n, 7, "cpu", geography=geography)
+    wn = dict(w, edge_sets={k: {"agent": es["agent"].numpy(), "venue": es["venue"].numpy(), "people": es["people"]}
+                            for k, es in w["edge_sets"].items()})
+    wn = reorder_agents(wn, by="household")
+    for r in (0, R - 1):
+        ref = build_rank_world(wn, r, R)
+        got, share = stream_rank_share(iter_world_torch("c3", n, 7, "cpu", geography=geography), r, R, reorder="household")
+        assert (ref.n_local, ref.n_local_pad, ref.n_ext, ref.n_slices, ref.slice_agents) == \
+               (got.n_local, got.n_local_pad, got.n_ext, got.n_slices, got.slice_agents)
+        assert ref.modes == got.modes and list(ref.edge_sets) == list(got.edge_sets)
+        assert np.array_equal(ref.halo_global, got.halo_global) and np.array_equal(ref.halo_from, got.halo_from)
+        assert np.array_equal(ref.age, got.age) and np.array_equal(ref.sex, got.sex)
+        for k in ref.edge_sets:
+            for f in ("agent", "venue", "people"):
+                b = got.edge_sets[k][f]
+                assert np.array_equal(ref.edge_sets[k][f], b.numpy() if isinstance(b, torch.Tensor) else b), (k, f)
+            v1, v2 = ref.venue_global[k], got.venue_global[k]
+            assert (v1 is None and v2 is None) or np.array_equal(v1, v2), k
+        a0, a1 = ref.bounds[r], ref.bounds[r + 1]
+        for k, v in share["state"].items():
+            assert np.array_equal(v, wn["state"][k][a0:a1]), k
+        assert np.array_equal(share["original_id"], wn["original_id"][a0:a1])
+
+
 def test_single_rank_is_all_local():
     world = small_world(2000)
     rw = build_rank_world(world, 0, 1)

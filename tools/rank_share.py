@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--sv-max", type=int, default=None)
     ap.add_argument("--slice-agents", type=int, default=None, help="agents per slice (default: sized for the owned agents)")
     ap.add_argument("--geography", default="random", choices=["random", "clustered"])
+    ap.add_argument("--generator", default="numpy", choices=["numpy", "torch"],
+                    help="torch: the world is drawn on the device and the share cut out there (synthetic.iter_world_torch)")
     ap.add_argument("--exchange-rule", default="venue", choices=["venue", "set"])
     a = ap.parse_args()
     import torch
@@ -43,7 +45,7 @@ def main():
     import bench as B
     from grad_june_amd import distributed as D
     from grad_june_amd.distributed import DistributedHotPath, stream_rank_share
-    from grad_june_amd.synthetic import iter_world
+    from grad_june_amd.synthetic import iter_world, iter_world_torch
 
     D.EXCHANGE_RULE = a.exchange_rule
     entry.build()
@@ -53,9 +55,15 @@ def main():
     def progress(msg):
         print(f"[rank_share {time.time() - t0:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
-    rw, share = stream_rank_share(iter_world(a.preset, n_agents=a.agents, seed=a.seed, infected_fraction=0.01,
-                                             progress=progress, geography=a.geography),
-                                  a.rank, a.of, reorder="household", progress=progress, slice_agents=a.slice_agents)
+    if a.generator == "torch":
+        n = a.agents or {"c2": 1_000_000, "c3": 10_000_000, "c5": 100_000_000}[a.preset]
+        pieces = iter_world_torch(a.preset, n, a.seed, dev, infected_fraction=0.01, geography=a.geography, progress=progress)
+    else:
+        pieces = iter_world(a.preset, n_agents=a.agents, seed=a.seed, infected_fraction=0.01, progress=progress,
+                            geography=a.geography)
+    rw, share = stream_rank_share(pieces, a.rank, a.of, reorder="household", progress=progress, slice_agents=a.slice_agents)
+    del pieces
+    torch.cuda.empty_cache()
     t_part = time.time() - t0
     world = {"n_agents": share["n_agents"], "networks": share["networks"], "state": share["state"],
              "edge_sets": {k: {"n_edges": e, "n_venues": v} for k, (e, v) in share["sizes"].items()}}
@@ -79,7 +87,7 @@ def main():
     out = {
         "what": f"rank {a.rank} of {a.of}: kernels of one step on its share, collectives not executed",
         "geometry": {"slice_agents": int(rw.slice_agents), "n_slices": int(rw.n_slices), "eb_target": a.eb_target, "sv_max": a.sv_max},
-        "preset": a.preset, "geography": a.geography, "exchange_rule": a.exchange_rule, "n_agents_world": share["n_agents"], "n_owned": int(rw.n_local), "n_halo": int(rw.n_halo),
+        "preset": a.preset, "geography": a.geography, "generator": a.generator, "exchange_rule": a.exchange_rule, "n_agents_world": share["n_agents"], "n_owned": int(rw.n_local), "n_halo": int(rw.n_halo),
         "modes": rw.modes, "venue_classes": share["classes"],
         "local_set_edges": {k: int(len(v["agent"])) for k, v in rw.edge_sets.items()},
         "halo_all_to_all_bytes_in_per_step": 4 * int(rw.n_halo),
