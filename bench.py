@@ -183,6 +183,24 @@ def kernel_bytes(world, networks):
     }
 
 
+def cgroup_cpu_quota():
+    """CPUs the container may use (cgroup v2 cpu.max / v1 cfs quota), or None when no quota is set / visible."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            per = float(f.read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(world, networks, betas, tables, budget_s):
     """The CPU oracle (= the reference's ATen op sequence) timed on this host.  Protocol of SURVEY 8d: 3 warm-up
     + 10 timed steps of the same workload, once under no_grad and once with autograd on (the reference's default:
@@ -196,8 +214,14 @@ def cpu_baseline(world, networks, betas, tables, budget_s):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    # every core this process may run on (GJ_CPU_THREADS lowers it for experiments)
-    cores = max(1, min(avail, int(os.environ.get("GJ_CPU_THREADS", str(avail)))))
+    # every core this process may USE: the affinity mask bounded by the container's CPU quota
+    # (cgroup cpu.max; the GPU box shows all 256 host cores to a job that is given 16 - with 256 threads the oracle
+    # runs five times slower than with 16).  GJ_CPU_THREADS overrides.
+    quota = cgroup_cpu_quota()
+    share = avail if quota is None else max(1, min(avail, int(round(quota))))
+    if quota is None and avail > 64 and torch.cuda.is_available():
+        share = 16 * max(1, torch.cuda.device_count())         # no quota visible: the pool's documented share per GPU
+    cores = max(1, min(avail, int(os.environ.get("GJ_CPU_THREADS", str(share)))))
     torch.set_num_threads(cores)
     w = {"n_agents": world["n_agents"], "age": torch.from_numpy(world["age"]), "sex": torch.from_numpy(world["sex"]),
          "edge_sets": {k: {kk: torch.from_numpy(vv) for kk, vv in v.items()} for k, v in world["edge_sets"].items()}}
@@ -236,7 +260,7 @@ def cpu_baseline(world, networks, betas, tables, budget_s):
     sps = 1.0 / float(np.mean(t_ng))
     sps_ag = 1.0 / float(np.mean(t_ag))
     n_edges = sum(len(world["edge_sets"][_es(n_)]["agent"]) for n_ in networks)
-    return {"value": sps, "unit": "steps/s", "cores": cores, "cores_visible": avail,
+    return {"value": sps, "unit": "steps/s", "cores": cores, "cores_visible": avail, "cores_cgroup_quota": quota,
             "cores_host": os.cpu_count(), "kind": "port",
             "sample": f"{len(t_ng)} timed full steps of the same workload after {w_ng} warm-up steps, torch CPU ops, "
                       f"no_grad (wall-clock bound {budget_s:g} s for both legs)",
@@ -394,16 +418,19 @@ def backward_bench(args, world, specs, networks, dev, progress):
     }
 
 
-def sustained_region(runner, seconds: float, ms_per_step_hint: float, block: int = 25):
+def sustained_region(runner, seconds: float, ms_per_step_hint: float, start, t_start: int, block: int = 25):
     """A sustained-clock figure: at least ``seconds`` of GPU work as blocks of ``block`` production steps (gj_step, no
     events between the launches), the epidemic state put back to the block's start state before every block (so every
     block computes the same 25 steps at the headline prevalence instead of drifting into a saturated epidemic).  Each
     block is bracketed by two HIP events on the launch stream; the reset copies (3 arrays) lie OUTSIDE the brackets,
     so ``ms_per_step`` figures are the steps' alone - the GPU still executes them, i.e. the card is busy throughout.
+    ``start`` / ``t_start``: the state and step count at the start of the FIRST timed region (after the warm-up), so
+    that a block is the first 25 steps of the headline region.
     Returns min / median / max over the blocks and the mean of the last quarter (clocks and temperature settled)."""
     keys = ("is_infected", "susceptibility", "infection_time")
-    start = {k: runner.state[k].clone() for k in keys}
-    t0 = runner.t
+    after = {k: runner.state[k].clone() for k in keys}
+    t_after = runner.t
+    t0 = t_start
     n_blocks = max(8, int(np.ceil(seconds * 1e3 / max(1e-3, ms_per_step_hint * block))))
     events = []
     torch.cuda.synchronize()
@@ -423,8 +450,8 @@ def sustained_region(runner, seconds: float, ms_per_step_hint: float, block: int
     ms = np.array([a.elapsed_time(b) / block for a, b in events])
     infected = float(runner.state["is_infected"].double().sum())
     for k in keys:
-        runner.state[k].copy_(start[k])
-    runner.t = t0
+        runner.state[k].copy_(after[k])
+    runner.t = t_after
     q = max(1, len(ms) // 4)
     return {"seconds_of_gpu_work": float(ms.sum() * block / 1e3), "wall_seconds": wall, "blocks": int(n_blocks),
             "steps_per_block": block, "steps": int(n_blocks * block),
@@ -726,6 +753,11 @@ def main():
         sync()
         return time.perf_counter() - t_a, t_issue
 
+    start_state = start_t = None
+    if not distributed and hasattr(runner, "load_state") and args.sustained_seconds > 0 and not args.only_headline:
+        start_state = {k: runner.state[k].clone() for k in ("is_infected", "susceptibility", "infection_time")}
+        start_t = runner.t
+        torch.cuda.synchronize()
     elapsed, issue = region()
     infected_first = float(runner.state["is_infected"].double().sum())    # after warm-up + the first K steps
     repeats = [elapsed]
@@ -811,8 +843,8 @@ def main():
         del kept
 
     sustained = None
-    if single and args.sustained_seconds > 0 and not args.only_headline:
-        sustained = sustained_region(runner, args.sustained_seconds, 1e3 * elapsed / args.steps)
+    if single and start_state is not None:
+        sustained = sustained_region(runner, args.sustained_seconds, 1e3 * elapsed / args.steps, start_state, start_t)
 
     full = None
     if not distributed and hasattr(runner, "enable_full_step") and not args.only_headline:

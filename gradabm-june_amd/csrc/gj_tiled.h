@@ -15,7 +15,7 @@ namespace gj {
 
 constexpr int kTileThreads = 1024;  // 16 waves: one workgroup per CU when the slice fills LDS
 constexpr int kTileWaves = kTileThreads / kWave;
-constexpr int kMaxSliceAgents = 20160;   // 8-byte sums + one flag bit per agent within 160 KiB of LDS
+constexpr int kMaxSliceAgents = 19840;   // 8-byte sums + two flag bits per agent within 160 KiB of LDS
 constexpr int kUnroll = 8;          // 64-edge chunks a wave keeps in flight: phase D, and phase A with wide descriptors
 #ifndef GJ_UNROLL_NARROW
 #define GJ_UNROLL_NARROW 16
@@ -62,21 +62,35 @@ template <int BITS>
 __device__ __forceinline__ float from_fx(fx_t v) {
   return (float)((double)(long long)v * (1.0 / (double)(1ull << BITS)));
 }
-// What cannot be summed as an integer - NaN, infinities, |x| beyond fx_max - sets the element's bit in `flags`
-// instead and the element reads back as NaN (the reference's scatter_add would give NaN / inf there; a silent clamp
-// would turn a poisoned venue into a number).
-// Branch-free on the common path (such a value adds 0 and raises its flag bit): control flow around every add lets
-// hipcc sink each global load that feeds one into the add's own block, behind an s_waitcnt of its own - a batch of
-// eight loads then costs eight memory round trips instead of one.
-template <int BITS>
-__device__ __forceinline__ void fx_add(fx_t* sums, uint32_t* flags, int i, float x) {
-  const bool ok = fabsf(x) <= fx_max<BITS>();
-  atomicAdd(&sums[i], to_fx<BITS>(ok ? x : 0.0f));
-  if (__builtin_expect(!ok, 0)) atomicOr(&flags[i >> 5], 1u << (i & 31));
+// What cannot be summed as an integer raises a flag of its element instead of adding (round 4: two flags per element,
+// so that a finite value beyond the window SATURATES instead of poisoning - the reference has no window: its sums stay
+// finite and the epilogue clamps them, base.py:136-138):
+//   x >  window (also +inf)  -> flag POS;   x < -window (also -inf) -> flag NEG;   NaN -> both.
+// An element reads back as +-kSaturated (1e30: finite, so that a zero factor downstream - p_contact of an empty venue, a
+// susceptibility of 0, a class weight of 0 - still gives 0 as it does in the reference, and large enough that whatever
+// is left saturates every later window and ends at the epilogue's clamp: exp(-100 dt)), or NaN with both flags.
+// Flags are bit arrays `flags[0 .. words)` = POS and `flags[words .. 2 words)` = NEG.
+// Branch-free on the common path: control flow around every add lets hipcc sink each global load that feeds one into
+// the add's own block, behind an s_waitcnt of its own - a batch of eight loads then costs eight round trips, not one.
+constexpr float kSaturated = 1.0e30f;
+__device__ __forceinline__ void fx_flag(uint32_t* flags, int words, int i, float x) {
+  const uint32_t bit = 1u << (i & 31);
+  if (!(x < 0.0f)) atomicOr(&flags[i >> 5], bit);             // positive, +inf or NaN
+  if (!(x > 0.0f)) atomicOr(&flags[words + (i >> 5)], bit);   // negative, -inf or NaN
 }
 template <int BITS>
-__device__ __forceinline__ float fx_read(const fx_t* sums, const uint32_t* flags, int i) {
-  return ((flags[i >> 5] >> (i & 31)) & 1u) ? __builtin_nanf("") : from_fx<BITS>(sums[i]);
+__device__ __forceinline__ void fx_add(fx_t* sums, uint32_t* flags, int words, int i, float x) {
+  const bool ok = fabsf(x) <= fx_max<BITS>();
+  atomicAdd(&sums[i], to_fx<BITS>(ok ? x : 0.0f));
+  if (__builtin_expect(!ok, 0)) fx_flag(flags, words, i, x);
+}
+__device__ __forceinline__ float fx_special(uint32_t pos, uint32_t neg, float v) {
+  return (pos & neg) ? __builtin_nanf("") : (pos ? kSaturated : (neg ? -kSaturated : v));
+}
+template <int BITS>
+__device__ __forceinline__ float fx_read(const fx_t* sums, const uint32_t* flags, int words, int i) {
+  const uint32_t pos = (flags[i >> 5] >> (i & 31)) & 1u, neg = (flags[words + (i >> 5)] >> (i & 31)) & 1u;
+  return fx_special(pos, neg, from_fx<BITS>(sums[i]));
 }
 constexpr int kFxVenue = 36, kFxAgent = 32;
 
@@ -338,7 +352,8 @@ __device__ __forceinline__ void scatter_set(const TSetA& T, const float* lds_x, 
 #define GJ_GATHER_PIPELINE 1
 #endif
 template <bool WIDE>
-__device__ __forceinline__ void gather_set(const TSetA& T, fx_t* lds_acc, uint32_t* lds_flags, int s, int wave, int lane) {
+__device__ __forceinline__ void gather_set(const TSetA& T, fx_t* lds_acc, uint32_t* lds_flags, int flag_words, int s,
+                                           int wave, int lane) {
   const int row = s * T.J;
   const int seg0 = T.tile_sptr[row], seg1 = T.tile_sptr[row + T.J];
   const int c_base = T.chunk_ptr[s];
@@ -389,7 +404,7 @@ __device__ __forceinline__ void gather_set(const TSetA& T, fx_t* lds_acc, uint32
         if ((__float_as_uint(x[u]) & 0x7FFFFFFFu) <= kLimit) {
           atomicAdd(&lds_acc[la[u]], to_fx<kFxAgent>(x[u]));
         } else {
-          atomicOr(&lds_flags[la[u] >> 5], 1u << (la[u] & 31));
+          fx_flag(lds_flags, flag_words, la[u], x[u]);
         }
       }
     }
@@ -451,7 +466,8 @@ __device__ __forceinline__ void scatter_explicit(const TSetA& T, const float* ld
 }
 
 template <int kU>
-__device__ __forceinline__ void gather_explicit(const TSetA& T, fx_t* lds_acc, uint32_t* lds_flags, int s, int wave, int lane) {
+__device__ __forceinline__ void gather_explicit(const TSetA& T, fx_t* lds_acc, uint32_t* lds_flags, int flag_words, int s,
+                                                int wave, int lane) {
   const int row = s * T.J;
   const int seg0 = T.tile_sptr[row], seg1 = T.tile_sptr[row + T.J];
   const int n_chunks = T.chunk_ptr[s + 1] - T.chunk_ptr[s];
@@ -484,7 +500,7 @@ __device__ __forceinline__ void gather_explicit(const TSetA& T, fx_t* lds_acc, u
         if ((__float_as_uint(x[u]) & 0x7FFFFFFFu) <= kLimit) {
           atomicAdd(&lds_acc[la[u]], to_fx<kFxAgent>(x[u]));
         } else {
-          atomicOr(&lds_flags[la[u] >> 5], 1u << (la[u] & 31));
+          fx_flag(lds_flags, flag_words, la[u], x[u]);
         }
       }
     }
@@ -543,6 +559,9 @@ struct TSetB {
   int32_t age75[GJ_MAX_NETS_PER_SET];      // susceptibility additionally * (age > 75)
   int32_t leisure;
   int32_t direct;                          // pass 2 runs in phase D's direct form: phase C has nothing to do
+  uint32_t term_limit;                     // bit pattern of the largest |term| a venue sum takes (<= 16384): chosen per set
+                                           // so that the largest venue's sum cannot leave the 64 bits (fill_set_b)
+  int32_t _pad_b;
   // run form (gj_tiled_set.run_*): the primary edge of the agents [blk_r0[j], blk_r0[j+1]) - value x[a], venue pv_blk[a]
   const uint16_t* pv_blk;
   const int32_t* blk_r0;
@@ -562,18 +581,18 @@ struct TileBArgs {
 
 // Phase B, a group of 8 slots that holds a value which cannot be summed (rare; kept out of line so that its registers
 // do not count against the launch's two workgroups per CU).
-__device__ __noinline__ void venue_group_slow(fx_t* sums, uint32_t* vflags, int base_k, int l0, int l1, int l2, int l3,
-                                              int l4, int l5, int l6, int l7, float x0, float x1, float x2, float x3,
-                                              float x4, float x5, float x6, float x7) {
+__device__ __noinline__ void venue_group_slow(fx_t* sums, uint32_t* vflags, int words, uint32_t limit, int base_k, int l0,
+                                              int l1, int l2, int l3, int l4, int l5, int l6, int l7, float x0, float x1,
+                                              float x2, float x3, float x4, float x5, float x6, float x7) {
   const int lv[8] = {l0, l1, l2, l3, l4, l5, l6, l7};
   const float x[8] = {x0, x1, x2, x3, x4, x5, x6, x7};
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     if (lv[q] == 0xFFFF) continue;
-    if ((__float_as_uint(x[q]) & 0x7FFFFFFFu) <= 0x46800000u) {      // |x| <= 16384 = fx_max<kFxVenue>()
+    if ((__float_as_uint(x[q]) & 0x7FFFFFFFu) <= limit) {      // |x| inside the set's window (<= 16384 = fx_max<kFxVenue>())
       atomicAdd(&sums[base_k + lv[q]], to_fx<kFxVenue>(x[q]));
     } else {
-      atomicOr(&vflags[(base_k + lv[q]) >> 5], 1u << ((base_k + lv[q]) & 31));
+      fx_flag(vflags, words, base_k + lv[q], x[q]);
     }
   }
 }
@@ -626,7 +645,8 @@ __global__ __launch_bounds__(kTileThreads, GJ_VENUE_WAVES_PER_SIMD) void k_tile_
   float* cumf = lds_s;                                            // cum of (k, lv) at float index 2*(k*nv+lv) (phase C)
   float* tabs = lds_s + 2 * ((size_t)nk * nv + 64);  // (64 scratch sums, one per lane of a wave, follow the sums)
                                                      // [nk][200] pass-1 tables, then [nk][200] pass-2 weights
-  uint32_t* vflags = reinterpret_cast<uint32_t*>(tabs + (T.leisure ? 2 * nk * 200 : 0));   // one bit per sum: not summable
+  uint32_t* vflags = reinterpret_cast<uint32_t*>(tabs + (T.leisure ? 2 * nk * 200 : 0));   // two bits per sum (fx_flag)
+  const int vwords = (nk * nv + 64 + 31) / 32;
   if (T.leisure) {
     for (int i = tid; i < nk * 200; i += kTileThreads) {
       const int k = i / 200, c = i % 200;
@@ -641,7 +661,7 @@ __global__ __launch_bounds__(kTileThreads, GJ_VENUE_WAVES_PER_SIMD) void k_tile_
   float4* val4 = reinterpret_cast<float4*>(T.val);
   if (B.mode != 2) {
     for (int i = tid; i < nk * nv + 64; i += kTileThreads) sums[i] = 0;
-    for (int i = tid; i < (nk * nv + 64 + 31) / 32; i += kTileThreads) vflags[i] = 0u;
+    for (int i = tid; i < 2 * vwords; i += kTileThreads) vflags[i] = 0u;
     __syncthreads();
     // B: each lane takes 8 consecutive slots (48 bytes), merges runs of one venue in registers and adds
     // each run to the block's LDS sums; kVenueUnroll such groups are loaded before the first is used
@@ -661,7 +681,7 @@ __global__ __launch_bounds__(kTileThreads, GJ_VENUE_WAVES_PER_SIMD) void k_tile_
       for (int q = 0; q < 8; ++q) {
         const bool last = (q == 7) || (lv[q + (q < 7)] != lv[q]);
         const bool take = last && lv[q] != 0xFFFF;
-        fx_add<kFxVenue>(sums, vflags, take ? base_k + lv[q] : dummy, take ? s8 : 0.0f);
+        fx_add<kFxVenue>(sums, vflags, vwords, take ? base_k + lv[q] : dummy, take ? s8 : 0.0f);
         if (q < 7) s8 = last ? x[q + 1] : s8 + x[q + 1];
       }
     };
@@ -672,7 +692,7 @@ __global__ __launch_bounds__(kTileThreads, GJ_VENUE_WAVES_PER_SIMD) void k_tile_
         const bool valid = lv[q] != 0xFFFF;
         const bool ok = fabsf(x[q]) <= fx_max<kFxVenue>();
         atomicAdd(&sums[valid ? base_k + lv[q] : dummy], to_fx<kFxVenue>((ok && valid) ? x[q] : 0.0f));
-        if (__builtin_expect(!ok && valid, 0)) atomicOr(&vflags[(base_k + lv[q]) >> 5], 1u << ((base_k + lv[q]) & 31));
+        if (__builtin_expect(!ok && valid, 0)) fx_flag(vflags, vwords, base_k + lv[q], x[q]);
       }
     };
 #else
@@ -686,14 +706,16 @@ __global__ __launch_bounds__(kTileThreads, GJ_VENUE_WAVES_PER_SIMD) void k_tile_
     // infinities order like their patterns - and a slot that is not the end of a run adds whatever the running sum is
     // to the lane's scratch sum instead of selecting a zero.
     auto run_sums = [&](const int (&lv)[8], const float (&x)[8], int base_k) {
-      constexpr uint32_t kLimit = 0x46800000u;          // bit pattern of fx_max<kFxVenue>() = 16384.0f
-      static_assert(kFxVenue == 36, "kLimit is the pattern of 2^(50 - kFxVenue)");
+      // (wave-uniform, at most the pattern of fx_max<kFxVenue>() = 16384.0f; smaller for a set with venues of more than
+      // 4 096 attendees, so that attendees x window stays inside the 64-bit sum: no sum can wrap)
+      const uint32_t kLimit = T.term_limit;
+      static_assert(kFxVenue == 36, "term_limit is derived from 2^(50 - kFxVenue) (fill_set_b)");
       uint32_t m = 0u;
 #pragma unroll
       for (int q = 0; q < 8; ++q) m = max(m, __float_as_uint(x[q]) & 0x7FFFFFFFu);
-      if (__builtin_expect(m > kLimit, 0)) {            // a NaN / infinity / out-of-range term: its venue reads back NaN
-        venue_group_slow(sums, vflags, base_k, lv[0], lv[1], lv[2], lv[3], lv[4], lv[5], lv[6], lv[7], x[0], x[1], x[2], x[3],
-                         x[4], x[5], x[6], x[7]);
+      if (__builtin_expect(m > kLimit, 0)) {            // a NaN / infinity / out-of-window term: saturates or poisons its venue
+        venue_group_slow(sums, vflags, vwords, kLimit, base_k, lv[0], lv[1], lv[2], lv[3], lv[4], lv[5], lv[6], lv[7], x[0],
+                         x[1], x[2], x[3], x[4], x[5], x[6], x[7]);
         return;
       }
       fx_t s8 = 0;
@@ -801,7 +823,7 @@ __global__ __launch_bounds__(kTileThreads, GJ_VENUE_WAVES_PER_SIMD) void k_tile_
         for (int u = 0; u < kCumBatch; ++u) {
           const int lv = l0 + u * kTileThreads;
           if (lv < nv) {
-            const float c = (beta * pc[u]) * fx_read<kFxVenue>(sums, vflags, k * nv + lv);
+            const float c = (beta * pc[u]) * fx_read<kFxVenue>(sums, vflags, vwords, k * nv + lv);
             T.cum[(int64_t)(v0 + lv) * T.stride + k] = c;
             cumf[2 * (k * nv + lv)] = c;      // low half of the lane's own 8-byte slot
           }
@@ -874,7 +896,7 @@ __global__ __launch_bounds__(kTileThreads, GJ_VENUE_WAVES_PER_SIMD) void k_tile_
 // and the split over workgroups cannot change a bit - and writes its table to partial[workgroup][venue][network].
 // k_presum_reduce then adds the tables up and applies beta * p_contact.  Per edge: ~3 bytes of rows instead of the
 // ~12.3 of phases A + B (a_la + val write + descriptors, e_lv + val read), and the LDS atomics leave the venue launch.
-constexpr int GJ_MAX_PRESUM = 6;              // (= GJ_MAX_DIRECT: a set in this form is in the direct form of pass 2)
+constexpr int GJ_MAX_PRESUM = 6;              // (opt-in experiment: at most six sets take pass 1 in this form)
 constexpr int64_t kPresumBad = (int64_t)0x8000000000000000ll;      // a sum that holds a value which cannot be summed
 struct TPSet {
   const uint16_t* ell;    // [planes][rows][2]
@@ -899,6 +921,12 @@ struct TilePArgs {
 };
 
 constexpr int kPresumQuads = 3;     // quads of agents a lane keeps in flight
+// (the opt-in experiment keeps round 3's rule: one flag per sum, anything that cannot be summed reads back NaN)
+__device__ __forceinline__ void fx_add_or_poison(fx_t* sums, uint32_t* flags, int i, float x) {
+  const bool ok = fabsf(x) <= fx_max<kFxVenue>();
+  atomicAdd(&sums[i], to_fx<kFxVenue>(ok ? x : 0.0f));
+  if (__builtin_expect(!ok, 0)) atomicOr(&flags[i >> 5], 1u << (i & 31));
+}
 
 __global__ __launch_bounds__(kTileThreads) void k_tile_presum(const TilePArgs P) {
   extern __shared__ __align__(16) fx_t lds_p[];
@@ -969,11 +997,11 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_presum(const TilePArgs P)
                 const int lv = (int)((w[j] >> (16 * c)) & 0xFFFF) - v0;
                 const bool in = ((unsigned)lv < (unsigned)nv) && (j < n_ok);
                 if (!T.leisure) {
-                  fx_add<kFxVenue>(lds_p, flags, in ? lv : dummy, in ? xv[j] : 0.0f);
+                  fx_add_or_poison(lds_p, flags, in ? lv : dummy, in ? xv[j] : 0.0f);
                 } else {
                   const int cj = (B.cl[u] >> (8 * j)) & 0xFF;
                   for (int k = 0; k < nk; ++k)
-                    fx_add<kFxVenue>(lds_p, flags, in ? lv * nk + k : dummy, in ? wtab[k * 200 + cj] * xv[j] : 0.0f);
+                    fx_add_or_poison(lds_p, flags, in ? lv * nk + k : dummy, in ? wtab[k * 200 + cj] * xv[j] : 0.0f);
                 }
               }
             }
@@ -1068,7 +1096,8 @@ __global__ __launch_bounds__(kThreads) void k_presum_reduce(const PReduceArgs R)
 }
 
 // ---- phase D: per slice, accumulate the edges' values per agent in LDS; epilogue a7-a9 -----------
-constexpr int GJ_MAX_DIRECT = 6;
+constexpr int GJ_MAX_DIRECT = GJ_MAX_SETS;      // every set may be in the direct or the run form (a partition's split halves:
+                                                // up to 12 sets; 6 until round 3)
 constexpr int kClassWeightFloats = GJ_MAX_NETS_PER_SET * 200;
 struct TDirect {          // a set whose pass 2 is taken straight from the venues' cum
   const uint16_t* ell;    // [planes][owned agents, padded to slices][K] venue ids, 0xFFFF = none
@@ -1426,9 +1455,10 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
   const int s = blockIdx.x;
   const int64_t base = (int64_t)s * D.slice_agents;
   const int n_local = (int)min((int64_t)D.slice_agents, D.n_agents - base);
-  uint32_t* lds_flags = reinterpret_cast<uint32_t*>(lds_acc + D.slice_agents);   // one bit per agent: sum not summable
+  uint32_t* lds_flags = reinterpret_cast<uint32_t*>(lds_acc + D.slice_agents);   // two bits per agent (fx_flag): POS words, NEG words
+  const int fwords = D.slice_agents / 32;
   for (int i = tid; i < n_local; i += kTileThreads) lds_acc[i] = 0;
-  for (int i = tid; i < D.slice_agents / 32; i += kTileThreads) lds_flags[i] = 0u;
+  for (int i = tid; i < 2 * fwords; i += kTileThreads) lds_flags[i] = 0u;
   DirectBatch first;                       // rows of the first direct item: their round trip hides behind the tiled sets
   if (D.n_direct > 0) direct_load(D, D.direct[0], base, n_local, tid, 0, first);
   __syncthreads();
@@ -1438,11 +1468,11 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
       const TSetA& T = D.sets[t];
       if (!T.active || T.direct || T.raw != pass) continue;
       if (T.wide == 2) {
-        gather_explicit<kUnroll>(T, lds_acc, lds_flags, s, wave, lane);
+        gather_explicit<kUnroll>(T, lds_acc, lds_flags, fwords, s, wave, lane);
       } else if (T.wide) {
-        gather_set<true>(T, lds_acc, lds_flags, s, wave, lane);
+        gather_set<true>(T, lds_acc, lds_flags, fwords, s, wave, lane);
       } else {
-        gather_set<false>(T, lds_acc, lds_flags, s, wave, lane);
+        gather_set<false>(T, lds_acc, lds_flags, fwords, s, wave, lane);
       }
     }
     __syncthreads();
@@ -1454,8 +1484,19 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
 #pragma unroll
         for (int u = 0; u < kStageBatch; ++u) stg[u] = D.stage[base + min(i0 + u * kTileThreads, n_local - 1)];
 #pragma unroll
-        for (int u = 0; u < kStageBatch; ++u)
-          if (i0 + u * kTileThreads < n_local && !(stg[u] < D.q_thr)) lds_acc[i0 + u * kTileThreads] = 0;
+        for (int u = 0; u < kStageBatch; ++u) {
+          const int i = i0 + u * kTileThreads;
+          if (i < n_local && !(stg[u] < D.q_thr)) {
+            lds_acc[i] = 0;
+            // a sum that merely saturated is finite in the reference: its quarantine factor of 0 makes it 0 (NaN stays NaN)
+            const uint32_t bit = 1u << (i & 31);
+            const bool pos = lds_flags[i >> 5] & bit, neg = lds_flags[fwords + (i >> 5)] & bit;
+            if (pos != neg) {
+              atomicAnd(&lds_flags[i >> 5], ~bit);
+              atomicAnd(&lds_flags[fwords + (i >> 5)], ~bit);
+            }
+          }
+        }
       }
       __syncthreads();
     }
@@ -1471,14 +1512,14 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_agents(const TileDArgs D)
     const int i0 = 4 * (tid + m * kTileThreads);
     // (the quad's four "not summable" bits sit in one word: i0 is a multiple of 4)
     const int iq = min(i0, D.slice_agents - 4);           // unconditional, clamped LDS reads (the whole quad is in LDS)
-    const uint32_t bad = (lds_flags[iq >> 5] >> (iq & 31)) & 0xFu;
+    const uint32_t pos = (lds_flags[iq >> 5] >> (iq & 31)) & 0xFu, neg = (lds_flags[fwords + (iq >> 5)] >> (iq & 31)) & 0xFu;
     fx_t raw[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) raw[j] = lds_acc[iq + j];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float v = from_fx<kFxAgent>(raw[j]);
-      acc[m][j] = (i0 < n_local) ? (((bad >> j) & 1u) ? __builtin_nanf("") : v) : 0.0f;
+      acc[m][j] = (i0 < n_local) ? (((pos | neg) >> j) & 1u ? fx_special((pos >> j) & 1u, (neg >> j) & 1u, v) : v) : 0.0f;
     }
   }
   if (D.n_direct > 0) {

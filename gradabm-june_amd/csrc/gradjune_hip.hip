@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "../../include/gradjune_hip.h"
 #include "gj_device.h"
@@ -1187,8 +1188,8 @@ static void fill_set_a(const gj_plan* plan, const gj_step_params* p, const Group
 
 // LDS of phases A and D: one slice (fp32 values in A, 64-bit fixed-point sums in D)
 static size_t slice_lds(const gj_tiled* T, size_t elem) { return (size_t)T->slice_agents * elem; }
-// phase D: 64-bit sums + one "not summable" bit per agent
-static size_t agents_lds(const gj_tiled* T) { return (size_t)T->slice_agents * sizeof(fx_t) + (size_t)T->slice_agents / 8; }
+// phase D: 64-bit sums + two flag bits per agent (saturated up / down, gj_tiled.h fx_flag)
+static size_t agents_lds(const gj_tiled* T) { return (size_t)T->slice_agents * sizeof(fx_t) + 2 * ((size_t)T->slice_agents / 8); }
 
 // pass 1 of the sets in its direct form: LDS tables of fixed-point sums per workgroup (k_tile_presum)
 static int presum_fill(const gj_plan* plan, const gj_step_params* p, const Groups& G, int g, TPSet* X) {
@@ -1318,6 +1319,22 @@ static int tiled_scatter(const gj_plan* plan, const gj_agent_state* st, const gj
   return tiled_presum(plan, st, p, G, stream);
 }
 
+// Bit pattern of the largest |term| a venue sum of this set takes: 2^14 (the window of the 2^-36 fixed point) while the
+// largest venue has at most 4 096 edges, else 2^26 / next_pow2(edges) - terms x edges then stays below 2^62 fixed-point
+// units and no sum can wrap.  A term beyond it saturates its venue (gj_tiled.h).  0 edges = not stated: 2^14.
+static uint32_t venue_term_limit(int32_t max_venue_edges) {
+  int e = 14;
+  int64_t p2 = 4096;
+  while (p2 < (int64_t)max_venue_edges && e > -20) {
+    p2 <<= 1;
+    --e;
+  }
+  const float lim = ldexpf(1.0f, e);
+  uint32_t bits;
+  memcpy(&bits, &lim, sizeof(bits));
+  return bits;
+}
+
 static int tiled_venues(const gj_plan* plan, const gj_agent_state* st, const gj_step_params* p, const Groups& G, int mode,
                         hipStream_t stream) {
   const gj_tiled* T = plan->tiled;
@@ -1373,7 +1390,8 @@ static int tiled_venues(const gj_plan* plan, const gj_agent_state* st, const gj_
     }
     const size_t n_sums = (size_t)X.nk * S.max_block_venues + 64;               // + a scratch sum per lane of a wave
     const size_t need = n_sums * sizeof(fx_t) + (X.leisure ? 2 * 200 * (size_t)X.nk : 0) * sizeof(float) +
-                        (n_sums + 31) / 32 * 4;                                       // one flag bit per sum
+                        2 * ((n_sums + 31) / 32 * 4);                                 // two flag bits per sum
+    X.term_limit = venue_term_limit(S.max_venue_edges);
     if (X.nk && need > lds) lds = need;
   }
   B.work = T->work;

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 from typing import Optional
 
-GJ_ABI_VERSION = 5
+GJ_ABI_VERSION = 6
 GJ_MAX_SETS = 12
 GJ_MAX_NETS = 16
 GJ_MAX_NETS_PER_SET = 8
@@ -67,6 +67,8 @@ class TiledSet(C.Structure):
         ("run_max_window", C.c_int32),
         ("run_tiled_edges", C.c_int32),
         ("presum", _vp),
+        ("max_venue_edges", C.c_int32),
+        ("_pad_mve", C.c_int32),
     ]
 
 

@@ -45,6 +45,8 @@ PIPELINE_MIN_EDGES = 20_000_000  # set-edges per rank from which the largest par
 EXCHANGE_RULE = os.environ.get("GJ_EXCHANGE_RULE", "venue")
 PARTIAL_COST_FACTOR = 1.0        # a venue goes the partial-sum way when its halo floats exceed this x its all-reduce floats
 MIN_SPLIT_HALO_FLOATS = 4096     # ... and a set is only cut in two when that saves at least this many halo floats per step
+MIN_SPLIT_HALO_SHARE = 0.05      # ... and at least this share of the halo floats of the whole set (a household set that
+                                 # loses 1 % of its venues to a partial-sum half loses its run form for nothing)
 MIN_SPLIT_VENUE_SHARE = 0.10     # ... and takes at least this share of the set's venues out of the all-reduce
 
 
@@ -56,7 +58,8 @@ def classify_venues(agent: np.ndarray, venue: np.ndarray, n_venues: int, bounds:
       T <= 1                 *local*: the owning rank computes it, nothing is communicated;
       halo floats n (T - 1)  what the halo form moves per step (every touching rank receives the attendees it does not
                              own) against the 2 k (R - 1) floats a venue with k networks costs in an all-reduce over
-                             R ranks: *halo* while n (T - 1) <= factor * 2 k (R - 1), else *partial-sum*.
+                             R ranks: *halo* while n (T - 1) <= factor * 2 k (R - 1) - and always up to
+                             HALO_MAX_MEAN_DEGREE (8) attendees -, else *partial-sum*.
 
     A boundary household is a halo venue, a school with one pupil from the next rank or a 50 000-attendee venue a
     partial-sum one.  Returns (partial[V] bool, n[V], T[V])."""
@@ -68,13 +71,13 @@ def classify_venues(agent: np.ndarray, venue: np.ndarray, n_venues: int, bounds:
         n = cnt.sum(1)
         T = (cnt > 0).sum(1)
         del cnt, owner
-        return n * (T - 1) > factor * 2.0 * max(1, nets_on_set) * (R - 1), n, T
+        return (n > HALO_MAX_MEAN_DEGREE) & (n * (T - 1) > factor * 2.0 * max(1, nets_on_set) * (R - 1)), n, T
     owner = np.searchsorted(bounds, agent, side="right") - 1
     cnt = np.bincount(venue * R + owner, minlength=n_venues * R).reshape(n_venues, R)
     n = cnt.sum(1)
     T = (cnt > 0).sum(1)
     del cnt
-    return n * (T - 1) > factor * 2.0 * max(1, nets_on_set) * (R - 1), n, T
+    return (n > HALO_MAX_MEAN_DEGREE) & (n * (T - 1) > factor * 2.0 * max(1, nets_on_set) * (R - 1)), n, T
 
 
 def reduce_groups(floats: Dict[str, int], min_floats: int = 1 << 16) -> List[List[str]]:
@@ -233,10 +236,11 @@ class RankPartitioner:
         used = n > 0
         n_part, n_ex = int((partial & used).sum()), int((~partial & used).sum())
         halo_saved = float((n * (T - 1))[partial].sum()) if n_part else 0.0
+        halo_all = float((n * (T - 1)).sum())
         self.classes[name] = {"venues": int(used.sum()), "local": int((T == 1).sum()),
                               "halo": int((~partial & (T > 1)).sum()), "partial_sum": n_part,
                               "edges_in_partial_sum_venues": int(n[partial].sum())}
-        if n_part == 0 or halo_saved < MIN_SPLIT_HALO_FLOATS:
+        if n_part == 0 or halo_saved < max(MIN_SPLIT_HALO_FLOATS, MIN_SPLIT_HALO_SHARE * halo_all):
             mode = "halo"
         elif n_ex < MIN_SPLIT_VENUE_SHARE * (n_part + n_ex):
             mode = "partial"

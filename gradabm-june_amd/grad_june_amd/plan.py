@@ -48,6 +48,8 @@ class HostEdgeSet:
     a_rowptr: Optional[np.ndarray]   # int32 [A+1]
     a_venue: Optional[np.ndarray]    # int32 [E]
     tiled: Optional[TL.TiledEdgeSet] = None
+    max_venue_edges: int = 0         # edges of the set's largest venue: bounds the terms of one venue sum (gj_tiled_set)
+    max_agent_edges: int = 0         # edges of the owned agent with the most edges in this set
 
 
 def p_contact(people) -> np.ndarray:
@@ -82,12 +84,16 @@ def compile_edge_set(name: str, agent_index, venue_index, people, n_agents: int,
             raise ValueError(f"{name}: agent index out of range")
         if venue_index.min() < 0 or venue_index.max() >= n_venues:
             raise ValueError(f"{name}: venue index out of range")
-    if not csr:
-        return HostEdgeSet(name, n_venues, E, None, None, p_contact(people), None, None)
-    v_rowptr, v_agent = _csr(venue_index, agent_index, n_venues)
     owned = agent_index < n_agents
+    mve = int(np.bincount(venue_index, minlength=1).max()) if E else 0
+    mae = int(np.bincount(agent_index[owned], minlength=1).max()) if E and owned.any() else 0
+    if not csr:
+        return HostEdgeSet(name, n_venues, E, None, None, p_contact(people), None, None, max_venue_edges=mve,
+                           max_agent_edges=mae)
+    v_rowptr, v_agent = _csr(venue_index, agent_index, n_venues)
     a_rowptr, a_venue = _csr(agent_index[owned], venue_index[owned], n_agents)
-    return HostEdgeSet(name, n_venues, E, v_rowptr, v_agent, p_contact(people), a_rowptr, a_venue)
+    return HostEdgeSet(name, n_venues, E, v_rowptr, v_agent, p_contact(people), a_rowptr, a_venue, max_venue_edges=mve,
+                       max_agent_edges=mae)
 
 
 def _host(a) -> np.ndarray:
@@ -97,7 +103,7 @@ def _host(a) -> np.ndarray:
     return np.asarray(a)
 
 
-def _edge_set_on_device(name: str, es: dict, n_ext: int) -> HostEdgeSet:
+def _edge_set_on_device(name: str, es: dict, n_ext: int, n_agents: Optional[int] = None) -> HostEdgeSet:
     """compile_edge_set(csr=False) for a set whose edge lists stay on the device (the index range checks are part of
     the compile kernels, tiling_native)."""
     people = _host(es["people"])
@@ -105,7 +111,19 @@ def _edge_set_on_device(name: str, es: dict, n_ext: int) -> HostEdgeSet:
     E = int(es["agent"].numel() if hasattr(es["agent"], "numel") else np.asarray(es["agent"]).size)
     if E >= 2**31 or n_ext >= 2**31 or n_venues >= 2**31:
         raise ValueError("edge set exceeds int32 indexing")
-    return HostEdgeSet(name, n_venues, E, None, None, p_contact(people), None, None)
+    mve = mae = 0
+    if E and isinstance(es["venue"], torch.Tensor):
+        mve = int(torch.bincount(es["venue"].reshape(-1), minlength=1).max())
+        a = es["agent"].reshape(-1)
+        if n_agents is not None:
+            a = a[a < n_agents]
+        mae = int(torch.bincount(a, minlength=1).max()) if a.numel() else 0
+    elif E:
+        mve = int(np.bincount(np.asarray(es["venue"]).ravel(), minlength=1).max())
+        a = np.asarray(es["agent"]).ravel()
+        a = a[a < (n_ext if n_agents is None else n_agents)]
+        mae = int(np.bincount(a, minlength=1).max()) if len(a) else 0
+    return HostEdgeSet(name, n_venues, E, None, None, p_contact(people), None, None, max_venue_edges=mve, max_agent_edges=mae)
 
 
 def _lanes_for(mean_degree: float) -> int:
@@ -202,6 +220,7 @@ def save_plan(plan: HostPlan, path) -> None:
     for s in plan.sets:
         p = f"set/{s.name}/"
         out[p + "n_venues"], out[p + "n_edges"], out[p + "v_pcontact"] = s.n_venues, s.n_edges, s.v_pcontact
+        out[p + "max_edges"] = np.array([s.max_venue_edges, s.max_agent_edges], dtype=np.int64)
         for k in ("v_rowptr", "v_agent", "a_rowptr", "a_venue"):
             if getattr(s, k) is not None:
                 out[p + k] = getattr(s, k)
@@ -232,6 +251,8 @@ def load_plan(path) -> HostPlan:
         p = f"set/{name}/"
         hs = HostEdgeSet(name, int(a[p + "n_venues"]), int(a[p + "n_edges"]), a.get(p + "v_rowptr"), a.get(p + "v_agent"),
                          a[p + "v_pcontact"], a.get(p + "a_rowptr"), a.get(p + "a_venue"))
+        if p + "max_edges" in a:
+            hs.max_venue_edges, hs.max_agent_edges = (int(x) for x in a[p + "max_edges"])
         if p + "tiled/meta" in a:
             meta = [int(x) for x in a[p + "tiled/meta"]]
             S, J, n_slots, wide = meta[:4]
@@ -311,9 +332,10 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
         raise ValueError("halo agents must start on a slice boundary (pad the owned range to a multiple of SA)")
     sets, all_blocks, all_long, work = [], [], [], []
     slot = 0
+    n_presum = 0
     for sid, (name, es) in enumerate(edge_sets.items()):
         if device is not None and not want_csr:
-            hs = _edge_set_on_device(name, es, n_ext)
+            hs = _edge_set_on_device(name, es, n_ext, n_agents)
         else:
             hs = compile_edge_set(name, _host(es["agent"]), _host(es["venue"]), _host(es["people"]), n_agents, n_ext,
                                   csr=want_csr)
@@ -348,7 +370,8 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
                 t.runs = _finish_runs(rf, t, n_agents, SA, device)
             elif plan_direct is not None:
                 t.ell, t.ell_k = plan_direct()
-                t.presum = presum is True and plan_direct.all_owned
+                t.presum = presum is True and plan_direct.all_owned and n_presum < 6      # (GJ_MAX_PRESUM)
+                n_presum += int(t.presum)
             blk_e0, blk_v0 = _host(t.blk_e0).astype(np.int64), _host(t.blk_v0).astype(np.int64)
             prim = np.diff(_host(t.runs.blk_r0).astype(np.int64)) if t.runs is not None else np.zeros(t.n_blocks, np.int64)
             for j in range(t.n_blocks):
@@ -373,6 +396,9 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
         cls = cls_all
         if len(cls) != n_ext:
             raise ValueError("age/sex must cover owned + halo agents")
+    if want_tiled and sum(s.max_agent_edges for s in sets) > TL.MAX_AGENT_EDGES:
+        raise ValueError(f"an agent with more than {TL.MAX_AGENT_EDGES} edges: its pass-2 sum (64-bit fixed point, terms "
+                         f"up to 262 144) could leave the 64 bits")
     work.sort(key=lambda w: -w[0])
     order = os.environ.get("GJ_WORK_ORDER", "heavy")       # experiments (bench.py --work-order): the default is heaviest first
     if order == "light":
@@ -536,6 +562,7 @@ class DevicePlan:
                 c = self.tiled_c.sets[i]
                 c.n_blocks = ts.n_blocks
                 c.max_block_venues = int(np.diff(_host(ts.blk_v0)).max()) if ts.n_blocks else 0
+                c.max_venue_edges = int(min(s.max_venue_edges, 2**31 - 1))
                 c.desc_wide = 1 if ts.desc_wide else 0
                 if ts.slot_idx is not None and ts.n_edges > 0:      # tiles of a few edges: explicit slots, no descriptors
                     t["chunk_desc"] = up(ts.slot_idx)

@@ -27,7 +27,8 @@ from typing import Optional
 
 import numpy as np
 
-SA_MAX = 20160        # agents per slice: 64-bit fixed-point sums + one flag bit per agent in 160 KiB of LDS (phase D)
+SA_MAX = 19840        # agents per slice: 64-bit fixed-point sums + two flag bits per agent in 160 KiB of LDS (phase D)
+MAX_AGENT_EDGES = 4096  # per owned agent, all sets: 4 096 terms of up to 262 144 stay inside phase D's 64-bit sums
 SV_MAX = 16384        # venues per block: 128 KiB of 64-bit sums in phase B, one block per CU.  (Rounds 1-2: 8192, so that
                       # two blocks shared a CU's LDS - worth 25 % then; with the direct form of pass 2 and the exact run
                       # merging the launch runs one workgroup per CU and larger blocks win: round 3, tools/ab.py on C3,

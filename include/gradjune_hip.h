@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GJ_ABI_VERSION 5
+#define GJ_ABI_VERSION 6
 
 #define GJ_MAX_SETS 12        /* distinct agent<->venue edge sets in a world (reference: 6)   */
 #define GJ_MAX_NETS 16        /* infection networks active in one step (reference: <= 11)      */
@@ -107,8 +107,13 @@ typedef struct gj_long_row {
  *   C  same workgroup (fused)  :  val[i] = cum[e_lv[i]]          (in place)
  *   D  one workgroup per slice :  acc[a_la] += val[block-major pos]; epilogue a7-a9
  * A tile is contiguous in both the slice-major (s, j) and the block-major (j, s) edge order.
- * Sums are accumulated with 64-bit fixed-point LDS atomics (resolution 2^-36 per venue, 2^-32 per agent; a value
- * beyond 16384 / 262144, an infinity or a NaN cannot be summed and makes its venue / agent read back NaN):
+ * Sums are accumulated with 64-bit fixed-point LDS atomics (resolution 2^-36 per venue, 2^-32 per agent).  The
+ * reference has no window (its sums stay finite and the epilogue clamps them, base.py:136-138); here a TERM beyond
+ * +-16384 (venue; less for sets with venues of > 4096 attendees, see max_venue_edges) / +-262144 (agent), or an
+ * infinity, SATURATES its sum: the element reads back +-1e30, which every later stage carries to the epilogue's clamp
+ * (exp(-100 dt): infected with certainty) while a zero factor - p_contact of an empty venue, susceptibility 0, a
+ * quarantine mask - still gives 0, as in the reference.  A NaN term, or saturation in both directions, reads back NaN.
+ * No sum can wrap: terms x attendees is bounded per set (max_venue_edges), edges per agent by 4096.
  * integer adds are order-independent, so results are bitwise reproducible from run to run, and
  * agree with the CSR path to fp32 rounding.                                                  */
 typedef struct gj_tiled_set {
@@ -166,11 +171,15 @@ typedef struct gj_tiled_set {
    * network) and write it to presum[workgroup][venue][network]; a second launch adds the tables up and applies
    * beta * p_contact.  Exact (integer sums), so cum is the same bit for bit as through phases A + B.              */
   int64_t* presum;            /* device [presum_wgs][n_venues * cum_stride] workspace or NULL                         */
+  int32_t max_venue_edges;    /* edges of the set's LARGEST venue (run-form primaries included).  Bounds the terms of one
+                                 venue sum: the window of a term is min(16384, 2^26 / next_pow2(max_venue_edges)), so that
+                                 no sum can leave its 64 bits.  0 = not stated: 16384, no such guarantee (ABI 6)        */
+  int32_t _pad_mve;
 } gj_tiled_set;
 
 typedef struct gj_tiled {
   int32_t n_slices;          /* S                                                            */
-  int32_t slice_agents;      /* SA (multiple of 64, <= 20160: one slice of 8-byte sums + flag bits fits LDS) */
+  int32_t slice_agents;      /* SA (multiple of 64, <= 19840: one slice of 8-byte sums + two flag bits per agent fits LDS) */
   int32_t direct_table_floats; /* 0: the direct form of pass 2 stages as many venue values through LDS at once
                                 as fit; > 0: at most this many (tests: forces several groups)   */
   int32_t n_work;            /* entries of `work`                                            */

@@ -87,3 +87,29 @@ def test_rccl_step_is_captured_and_validated_by_default(device):
     # (no wall-clock comparison of two separate processes on a shared box: tools/host_overhead.py measures the host time
     # per step of both forms inside one process)
     assert j["host_us_per_step"] > 0 and j2["host_us_per_step"] > 0
+
+
+@pytest.mark.gpu
+def test_c5_ranks_draw_and_cut_their_share_on_the_device(device):
+    """BASELINE config 5 across ranks, as the driver would start it: ``python bench.py --gpus 2 --preset c5`` (here at
+    20 M agents, two gloo ranks sharing the one GPU).  Every rank draws the same seeded world on the device
+    (synthetic.iter_world_torch), cuts its share out there (per-venue exchange classes) and compiles it with the
+    library's kernels - no rank holds the world in host memory, the set-up takes seconds, not the 7 minutes of the numpy
+    route - and the two ranks together end where the single GPU ends on the same world."""
+    import time
+
+    t0 = time.time()
+    r = _run("--gpus", "2", "--backend", "gloo", "--preset", "c5", "--agents", "20000000", "--generator", "torch",
+             "--steps", "4", "--warmup", "2", "--repeats", "1", timeout=600)
+    took = time.time() - t0
+    assert r.returncode == 0, r.stderr[-4000:]
+    j = _one_json_line(r.stdout)
+    assert j["n_gpus"] == 2 and took < 300, took
+    assert j["host_peak_rss_mb"] < 8000 and j["setup_s"]["total"] < 120, (j["host_peak_rss_mb"], j["setup_s"])
+    assert "~big" in " ".join(j["exchange"]["modes"]) and j["exchange"]["venue_classes"]["household"]["partial_sum"] > 0
+    r1 = _run("--gpus", "1", "--preset", "c5", "--agents", "20000000", "--generator", "torch", "--steps", "4",
+              "--warmup", "2", "--repeats", "1", "--only-headline", "--tune", "off", timeout=600)
+    assert r1.returncode == 0, r1.stderr[-4000:]
+    j1 = _one_json_line(r1.stdout)
+    a, b = j["state_checksum"]["infected_after_first_region"], j1["state_checksum"]["infected_after_first_region"]
+    assert b > 200_000 and abs(a - b) <= max(5.0, 1e-4 * b), (a, b)

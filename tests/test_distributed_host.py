@@ -95,8 +95,8 @@ def test_partition_matches_single_rank(R):
 def test_heavy_tailed_sets_are_split(R):
     """BASELINE config 5's power-law venues: a set whose mean venue is small but whose edges lie in huge venues is cut
     into a local + halo half and a partial-sum half, venue by venue (classify_venues: n attendees on T ranks are a
-    partial-sum venue when the halo form would move more floats, n (T - 1), than the venue costs in the all-reduce,
-    2 k (R - 1)); per agent the two halves add up to the single-rank pass, and no rank's halo is blown up by a big venue."""
+    partial-sum venue when they are more than 8 and the halo form would move more floats, n (T - 1), than the venue costs
+    in the all-reduce, 2 k (R - 1)); per agent the two halves add up to the single-rank pass, and no rank's halo is blown up by a big venue."""
     from grad_june_amd.distributed import SPLIT_SUFFIX, classify_venues, mode_of
 
     world = make_world("c5", n_agents=6000, seed=2)
@@ -117,11 +117,11 @@ def test_heavy_tailed_sets_are_split(R):
             es = world["edge_sets"][n]
             k = 3 if n == "leisure" else 1            # pub, gym, grocery share the leisure set
             partial, n_att, T = classify_venues(es["agent"], es["venue"], len(es["people"]), b, k)
-            assert np.array_equal(partial, n_att * (T - 1) > 2 * k * (R - 1)) and partial.any() and not partial.all()
+            assert np.array_equal(partial, (n_att > 8) & (n_att * (T - 1) > 2 * k * (R - 1))) and partial.any() and not partial.all()
             # the partial-sum half holds exactly those venues, whole; the other half only venues this rank touches
             assert np.array_equal(np.sort(rw.edge_sets[n + SPLIT_SUFFIX]["people"]), np.sort(es["people"][partial]))
             kept = rw.venue_global[n]                 # the set's ids of the venues this rank keeps of the other half
-            assert not partial[kept].any() and (n_att[kept] * (T[kept] - 1) <= 2 * k * (R - 1)).all()
+            assert not partial[kept].any() and ((n_att[kept] <= 8) | (n_att[kept] * (T[kept] - 1) <= 2 * k * (R - 1))).all()
             assert np.array_equal(rw.venue_global[n + SPLIT_SUFFIX], np.flatnonzero(partial))
         xe = np.zeros(rw.n_ext, dtype=np.float32)
         xe[: rw.n_local] = x[b[rw.rank]:b[rw.rank + 1]]

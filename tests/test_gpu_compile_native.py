@@ -48,7 +48,7 @@ CASES = [  # A, V, E, sa, svmax, eb, wide, dup
     (3000, 600, 30000, 128, 32, 600, None, 300),
     (64, 1, 10, 64, 16, 16, False, 0),
     (10000, 9000, 15000, 1024, 4096, 2000, True, 0),
-    (70000, 40000, 200000, 20160, 8192, 32768, None, 0),
+    (70000, 40000, 200000, 19840, 8192, 32768, None, 0),
     (1000, 5000, 300, 256, 64, 100, None, 0),          # most venues without an edge
 ]
 

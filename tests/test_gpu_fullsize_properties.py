@@ -142,6 +142,7 @@ def test_fullsize_properties(device, preset, agents):
     # -- linearity of pass 1: 2x in, exactly 2x out -------------------------------------------------
     p = tiled.params()
     for r in (tiled, csr):
+        _on_the_fixed_point_grid(r, p)
         before = [r.engine.plan.cum_of(s.name).clone() for s in r.engine.plan.host.sets]
         r.state["transmission"].mul_(2.0)
         r.engine.venue_reduce(r.bufs, p)
@@ -198,6 +199,16 @@ def test_c3_full_size_eight_partitions_equal_unpartitioned(device):
     assert single.state["is_infected"].sum().item() > 0.04 * world["n_agents"]
 
 
+def _on_the_fixed_point_grid(r, p):
+    """Pass 1 sums in 2^-36 fixed point: it is linear bit for bit in transmissions that lie ON that grid.  A transmission
+    below 2^-13 carries bits beyond it (one agent in ~1e8 at these sizes: whether a world holds one is luck), so the
+    linearity checks first round the transmissions to multiples of 2^-30 and take pass 1 again."""
+    x = r.state["transmission"]
+    x.copy_(torch.round(x * 2.0**30) / 2.0**30)
+    r.engine.venue_reduce(r.bufs, p)
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("agents", [20_000_000, 100_000_000], ids=["20m", "100m-the-full-config"])
 def test_c5_20m_against_fp64_device_sums(device, agents):
     """BASELINE.json configs[4]'s shape on ONE GPU as a single partition - at 20 M agents and at the configuration's
@@ -234,6 +245,7 @@ def test_c5_20m_against_fp64_device_sums(device, agents):
     assert int((r.probs < 1.0).sum()) > 0.5 * A
     del cum64, ts64, p64
     # pass 1 is linear, bit for bit (fixed-point sums)
+    _on_the_fixed_point_grid(r, r.params())
     before = [r.engine.plan.cum_of(s.name).clone() for s in r.engine.plan.host.sets]
     r.state["transmission"].mul_(2.0)
     r.engine.venue_reduce(r.bufs, r.params())
@@ -254,6 +266,69 @@ def test_c5_20m_against_fp64_device_sums(device, agents):
         outs.append((r.probs.clone(), r.new_infected.clone(), r.state["is_infected"].clone()))
     assert all(torch.equal(a, b) for a, b in zip(*outs))
     assert outs[0][1].sum().item() > 1000
+
+
+def test_c5_full_size_seven_partitions_equal_one(device):
+    """BASELINE.json configs[4] at its full size - 100 M agents, power-law venues up to 50 000 attendees - stepped as
+    SEVEN rank-like partitions on the one GPU against the single partition: every partition exactly a rank of the
+    multi-GPU run (per-venue exchange classes: every set comes as a local + halo half and a partial-sum half, the two
+    collectives become device copies / fp32 sums in rank order).  The world is drawn on the device
+    (synthetic.make_world_torch) and the partitions are cut out there (RankPartitioner's torch path: what
+    ``bench.py --gpus 8 --preset c5`` does per rank).  Same discrete state after three Philox steps, up to the handful of
+    decisions that may sit within fp32 rounding of a partial sum."""
+    import time
+
+    from grad_june_amd.distributed import PartitionedHotPath
+    from grad_june_amd.synthetic import make_world_torch
+
+    t0 = time.time()
+    world = make_world_torch("c5", 100_000_000, seed=1234, device=device, infected_fraction=0.03)
+    specs, betas = B.network_specs(world), B.betas_of(world)
+    parted = PartitionedHotPath(world, specs, betas, device, parts=7, seed=5, device_compile=True)
+    t_parts = time.time() - t0
+    modes = {m for rk in parted.ranks for m in rk.rw.modes.values()}
+    assert modes == {"halo", "partial"} and any(n.endswith("~big") for n in parted.ranks[0].rw.edge_sets)
+    for _ in range(3):
+        parted.step()
+    torch.cuda.synchronize()
+    got = {k: v.clone() for k, v in parted.state.items()}
+    halo = [rk.rw.n_halo for rk in parted.ranks]
+    del parted
+    torch.cuda.empty_cache()
+    single = SingleGpuHotPath(world, specs, betas, device, seed=5, layout="tiled", device_compile=True)
+    for _ in range(3):
+        single.step()
+    torch.cuda.synchronize()
+    print(f"c5 at 1e8 agents as 7 partitions: built in {t_parts:.0f} s, halo agents per partition {min(halo)}..{max(halo)}")
+    differ = int((got["is_infected"] != single.state["is_infected"]).sum())
+    assert differ <= 10, differ
+    assert abs(float(got["is_infected"].double().sum()) - float(single.state["is_infected"].double().sum())) <= 10
+    assert single.state["is_infected"].sum().item() > 0.031 * world["n_agents"]
+
+
+def test_clustered_world_partitions_equal_unpartitioned(device):
+    """A world with a geography (synthetic.GEOGRAPHY) under the household-major order, 2 M agents as 8 partitions:
+    households are rank-local (no halo set-up for them at all), the venues that reach across a partition boundary are
+    halo or partial-sum venues one by one - and the run ends in the unpartitioned run's state."""
+    from grad_june_amd.distributed import PartitionedHotPath
+    from grad_june_amd.synthetic import reorder_agents
+
+    world = reorder_agents(make_world("c3", n_agents=2_000_000, seed=21, infected_fraction=0.03, geography="clustered"),
+                           by="household")
+    specs, betas = B.network_specs(world), B.betas_of(world)
+    single = SingleGpuHotPath(world, specs, betas, device, seed=5, layout="tiled", device_compile=True)
+    parted = PartitionedHotPath(world, specs, betas, device, parts=8, seed=5, device_compile=True)
+    rw0 = parted.ranks[0].rw
+    assert rw0.modes["household"] == "halo" and "household~big" not in rw0.edge_sets
+    assert max(rk.rw.n_halo for rk in parted.ranks) < 0.25 * rw0.n_local          # the random world: ~1.1x the owned agents
+    assert len(rw0.edge_sets["company~big"]["people"]) < len(world["edge_sets"]["company"]["people"])
+    for _ in range(3):
+        single.step()
+        parted.step()
+    torch.cuda.synchronize()
+    differ = int((parted.state["is_infected"] != single.state["is_infected"]).sum())
+    assert differ <= 2, differ
+    assert single.state["is_infected"].sum().item() > 0.035 * world["n_agents"]
 
 
 def test_c2_full_size_against_the_oracle(device):

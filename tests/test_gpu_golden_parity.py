@@ -306,10 +306,12 @@ def test_no_active_network(device, layout):
 @pytest.mark.parametrize("poison", ["nan", "inf", "huge"])
 @pytest.mark.parametrize("layout", LAYOUTS, ids=LAYOUT_IDS)
 def test_non_finite_transmissions_propagate(device, layout, poison):
-    """A NaN / infinite / out-of-range infectiousness is not turned into a number: the reference's scatter_add and
-    torch.clamp (base.py:78-83, 136-140) carry it to every co-attendee of the poisoned agent's venues, and so do the
-    kernels - the tiled layout sums in fixed point and flags what it cannot represent (gj_tiled.h fx_add), both
-    epilogues clamp NaN-preservingly.  Everyone else gets exactly the clean run's probability."""
+    """A NaN infectiousness poisons, a huge finite one SATURATES - as in the reference, whose scatter_add and torch.clamp
+    (base.py:78-83, 136-140) carry a NaN to every co-attendee of the poisoned agent's venues and clamp a huge finite sum
+    to 100, i.e. p = exp(-100 dt): infected with certainty, while an already infected co-attendee (susceptibility 0:
+    0 * 3e30 == 0) keeps the clean run's probability.  The tiled layout sums in fixed point and flags what lies beyond
+    its window (gj_tiled.h fx_flag: the element reads back +-1e30 or NaN); both epilogues clamp NaN-preservingly.
+    Everyone else gets exactly the clean run's probability."""
     import gj_oracle as O
     from grad_june_amd.engine import AgentBuffers
 
@@ -348,18 +350,66 @@ def test_non_finite_transmissions_propagate(device, layout, poison):
     clean = ~touched
     assert np.abs(got[clean].numpy() - ref_clean["not_infected_probs"][clean].numpy()).max() <= 1e-5
     want_nan = torch.isnan(ref["not_infected_probs"])
-    if poison == "nan":
-        assert bool(want_nan[hit].all()) and bool(torch.isnan(got[hit]).all())
-    else:
-        # inf / 3e30: the reference saturates (ts -> 100, p = exp(-100)) where the sum stays +inf or finite, and gives NaN
-        # where inf meets a zero factor; the fixed-point path reports every unsummable element as NaN.  Either way the
-        # poisoned agents are set apart from the clean ones - never a plausible probability.
-        g = got[hit]
-        assert bool((torch.isnan(g) | (g <= 1e-30)).all())
-    # co-attendees the reference leaves untouched (susceptibility 0: 0 * 3e30 == 0) may read NaN here (0 * "unsummable")
     rest = touched & ~hit
     r = got[rest]
+    if poison == "nan":
+        assert bool(want_nan[hit].all()) and bool(torch.isnan(got[hit]).all())
+    elif poison == "huge" and not layout[1].get("presum"):
+        # finite and beyond every window: THE REFERENCE'S VALUES - exp(-100) for the susceptible co-attendees, who are all
+        # infected under the recorded noise, and the clean probability for the already infected ones
+        assert not bool(torch.isnan(got).any()) and not bool(want_nan.any())
+        assert np.abs(got.numpy() - ref["not_infected_probs"].numpy()).max() <= 1e-5
+        assert bool((got[hit] <= 1e-30).all()) and bool((ref["new_infected"][hit] > 0.5).all())
+        assert torch.equal(st["is_infected"].cpu(), ref["is_infected"])
+        assert bool(((r - ref_clean["not_infected_probs"][rest]).abs() <= 1e-5).all())
+        return
+    else:
+        # +inf: the reference saturates where the sum stays +inf (ts -> 100, p = exp(-100)) and gives NaN where inf meets a
+        # zero factor (susceptibility 0); the fixed-point path treats +inf as saturation throughout (exp(-100) / the clean
+        # probability).  (The opt-in pass-1-direct experiment keeps round 3's rule: NaN for whatever it cannot sum.)
+        g = got[hit]
+        assert bool((torch.isnan(g) | (g <= 1e-30)).all())
+    # co-attendees the reference leaves untouched (susceptibility 0) read the clean probability - or NaN where a true
+    # infinity met the zero
     assert bool((torch.isnan(r) | ((r - ref_clean["not_infected_probs"][rest]).abs() <= 1e-5)).all())
+
+
+@pytest.mark.parametrize("term, saturates", [(1000.0, False), (10000.0, True)])
+def test_large_venue_sums_saturate_and_never_wrap(device, term, saturates):
+    """20 000 attendees with a transmission of 1 000 / 10 000 each in ONE venue: 2e7 is summed exactly; 2e8 is beyond
+    what the 2^-36 fixed point holds in 64 bits (1.3e8) and used to wrap silently.  The window of a TERM is chosen per
+    set from its largest venue (gj_tiled_set.max_venue_edges: 2^26 / 32 768 = 2 048 here), so terms x attendees cannot
+    leave the 64 bits: terms of 10 000 saturate the venue, and its attendees end at the reference's clamp, exp(-100)."""
+    import gj_oracle as O
+    from grad_june_amd.engine import AgentBuffers
+
+    n = 20_000
+    world = {"n_agents": n, "age": torch.zeros(n, dtype=torch.int64), "sex": torch.zeros(n, dtype=torch.int64),
+             "edge_sets": {"school": {"agent": torch.arange(n), "venue": torch.zeros(n, dtype=torch.int64),
+                                      "people": torch.tensor([n])}}}
+    eng = L.make_engine(world, None, device, layout="tiled")
+    assert eng.plan.tiled_c.sets[0].max_venue_edges == n
+    st = {k: torch.zeros(n, device=device) for k in ("max_infectiousness", "shape", "rate", "shift", "infection_time",
+                                                     "is_infected", "current_stage")}
+    st["susceptibility"] = torch.ones(n, device=device)
+    st["susceptibility"][::7] = 0.0
+    st["transmission"] = torch.full((n,), term, device=device)
+    beta = 0.5
+    p = eng.params(now=1.0, delta_time=1.0, day_type=0, active=["school"], betas={"school": beta})
+    bufs = AgentBuffers(eng.plan, **{k: st[k] for k in ("max_infectiousness", "shape", "rate", "shift", "infection_time",
+                                                        "is_infected", "susceptibility", "transmission", "current_stage")})
+    eng.venue_reduce(bufs, p)
+    cum = float(eng.plan.cum_of("school")[0, 0])
+    exact = beta * (1.0 / (n - 1)) * term * n
+    probs = torch.empty(n, device=device)
+    eng.agent_gather(bufs, p, eng.io(not_infected_probs=probs), sample=False)
+    ref_ts = torch.clamp(torch.tensor(exact) * st["susceptibility"].cpu(), 1e-6, 100.0)
+    ref_p = torch.exp(-ref_ts).clamp(0.0, 1.0)
+    if saturates:
+        assert np.isfinite(cum) and cum >= exact                     # +1e30 x beta x p_contact: finite, never a wrapped sum
+    else:
+        assert abs(cum - exact) <= 1e-6 * exact
+    assert np.abs(probs.cpu().numpy() - ref_p.numpy()).max() <= 1e-6
 
 
 def O_sample(p, noise):
