@@ -116,7 +116,8 @@ class RankWorld:
     n_local_pad: int                   # first halo index: n_local rounded up to a slice boundary
     n_ext: int                         # n_local_pad + n_halo
     n_slices: int
-    halo_global: np.ndarray            # int64 [n_halo] global ids of the halo agents, by (owner, id)
+    halo_global: np.ndarray            # int64 [n_halo] global ids of the halo agents, grouped by owner; inside an owner's
+                                       # group by (first halo set, venue there, id) - see order_halo
     halo_from: np.ndarray              # int64 [R] halo agents received from each peer
     age: np.ndarray                    # [n_ext]
     sex: np.ndarray
@@ -148,6 +149,61 @@ def mode_of(n_edges: int, n_venues: int, world_size: int, people=None) -> str:
                 and (sizes > HALO_MAX_MEAN_DEGREE).any() and (sizes <= HALO_MAX_MEAN_DEGREE).any():
             return "split"
     return "halo"
+
+
+def _lexsort_torch(keys):
+    """``np.lexsort`` for torch tensors: the LAST key is the primary one (successive stable sorts)."""
+    order = torch.arange(keys[0].numel(), device=keys[0].device)
+    for k in keys:
+        order = order[torch.sort(k[order], stable=True)[1]]
+    return order
+
+
+#: "venue" (default): an owner's halo agents are ordered by the halo set and venue that needs them; "id": by agent id
+#: (rounds 1-3) - kept for comparison (tools/rank_share.py)
+HALO_ORDER = os.environ.get("GJ_HALO_ORDER", "venue")
+
+
+def order_halo(lists, bounds, device=None):
+    """The halo agents of one rank in the order of its extended index range, from the per-set lists of (remote attendee,
+    its smallest local venue of the set): grouped by owner (what the all-to-all delivers), and inside an owner's group by
+    (first halo set that needs the agent, its venue there, id).  A halo agent has ~1 halo edge; in id order the halo
+    slices' tiles hold a handful of edges each (a rank's C5 share spent a third of its step scattering them); in this
+    order the agents a venue block needs are neighbours, so a halo slice meets few venue blocks and its tiles are long.
+    Returns (ids, owner) as numpy arrays, or as torch tensors when the lists hold tensors."""
+    on_torch = bool(lists) and isinstance(lists[0][0], torch.Tensor)
+    if not lists:
+        if device is not None:
+            z = torch.zeros(0, dtype=torch.int64, device=device)
+            return z, z.clone()
+        return np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
+    if on_torch:
+        ids = torch.cat([a for a, _ in lists])
+        ven = torch.cat([v for _, v in lists])
+        si = torch.cat([torch.full((a.numel(),), i, dtype=torch.int64, device=a.device) for i, (a, _) in enumerate(lists)])
+        o = _lexsort_torch((si, ids))
+        ids, ven, si = ids[o], ven[o], si[o]
+        first = torch.ones(ids.numel(), dtype=torch.bool, device=ids.device)
+        first[1:] = ids[1:] != ids[:-1]
+        ids, ven, si = ids[first], ven[first], si[first]
+        owner = torch.searchsorted(torch.as_tensor(np.asarray(bounds), device=ids.device), ids, right=True) - 1
+        if HALO_ORDER == "venue":
+            o = _lexsort_torch((ids, ven, si, owner))
+            ids, owner = ids[o], owner[o]
+        return ids, owner
+    ids = np.concatenate([a for a, _ in lists])
+    ven = np.concatenate([v for _, v in lists])
+    si = np.concatenate([np.full(len(a), i, dtype=np.int64) for i, (a, _) in enumerate(lists)])
+    o = np.lexsort((si, ids))
+    ids, ven, si = ids[o], ven[o], si[o]
+    first = np.ones(len(ids), dtype=bool)
+    first[1:] = ids[1:] != ids[:-1]
+    ids, ven, si = ids[first], ven[first], si[first]
+    owner = np.searchsorted(bounds, ids, side="right") - 1
+    if HALO_ORDER == "venue":
+        o = np.lexsort((ids, ven, si, owner))
+        ids, owner = ids[o], owner[o]
+    return ids, owner
 
 
 class RankPartitioner:
@@ -308,7 +364,13 @@ class RankPartitioner:
             ag = agent[keep]
             self.local_sets[r][name] = {"agent_global": ag, "venue": remap[venue[keep]], "people": people[vg]}
             self.venue_global[r][name] = vg if part_venues is None else part_venues[vg]
-            self.halo_lists[r].append(np.unique(ag[(ag < b[r]) | (ag >= b[r + 1])]))
+            rem = (ag < b[r]) | (ag >= b[r + 1])
+            ra, rv = ag[rem], self.local_sets[r][name]["venue"][rem]
+            o = np.lexsort((rv, ra))                               # per remote attendee: its smallest local venue of this part
+            ra, rv = ra[o], rv[o]
+            first = np.ones(len(ra), dtype=bool)
+            first[1:] = ra[1:] != ra[:-1]
+            self.halo_lists[r].append((ra[first], rv[first]))
 
     def _add_part_torch(self, name, agent, venue, people, mode, part_venues) -> None:
         """``_add_part`` with torch ops on the tensors' device; the part's ``people`` go to the host (the graph
@@ -331,10 +393,16 @@ class RankPartitioner:
             ag = agent[keep]
             self.local_sets[r][name] = {"agent_global": ag, "venue": remap[venue[keep]], "people": people[vg].cpu().numpy()}
             self.venue_global[r][name] = (vg if part_venues is None else part_venues[vg]).cpu().numpy()
-            self.halo_lists[r].append(torch.unique(ag[(ag < int(b[r])) | (ag >= int(b[r + 1]))]))
+            rem = (ag < int(b[r])) | (ag >= int(b[r + 1]))
+            ra, rv = ag[rem], self.local_sets[r][name]["venue"][rem]
+            o = _lexsort_torch((rv, ra))
+            ra, rv = ra[o], rv[o]
+            first = torch.ones(ra.numel(), dtype=torch.bool, device=ra.device)
+            first[1:] = ra[1:] != ra[:-1]
+            self.halo_lists[r].append((ra[first], rv[first]))
 
     def finish(self, age, sex, slice_agents: Optional[int] = None) -> Dict[int, "RankWorld"]:
-        if any(isinstance(x, torch.Tensor) for hl in self.halo_lists.values() for x in hl) or any(
+        if any(isinstance(x[0], torch.Tensor) for hl in self.halo_lists.values() for x in hl) or any(
                 isinstance(ls["agent_global"], torch.Tensor) for sets in self.local_sets.values() for ls in sets.values()):
             return self._finish_torch(age, sex, slice_agents)
         age, sex = np.asarray(age), np.asarray(sex)
@@ -342,10 +410,9 @@ class RankPartitioner:
         for r in self.ranks:
             a0, a1 = int(self.bounds[r]), int(self.bounds[r + 1])
             n_local = a1 - a0
-            hl = self.halo_lists[r]
-            halo_global = np.unique(np.concatenate(hl)) if hl else np.zeros(0, dtype=np.int64)
-            owner = np.searchsorted(self.bounds, halo_global, side="right") - 1
-            halo_from = np.bincount(owner, minlength=self.world_size).astype(np.int64)   # sorted ids => grouped by owner
+            halo_global, owner = order_halo(self.halo_lists[r], self.bounds)
+            halo_from = np.bincount(owner, minlength=self.world_size).astype(np.int64)   # grouped by owner
+            sorter = np.argsort(halo_global, kind="stable")
             sa = slice_agents
             if sa is None:
                 # slices sized for the OWNED agents: phase D runs one workgroup per owned slice, and a rank whose halo
@@ -363,7 +430,7 @@ class RankPartitioner:
                 ext = g - a0
                 rem = (g < a0) | (g >= a1)
                 if rem.any():
-                    ext[rem] = n_local_pad + np.searchsorted(halo_global, g[rem])
+                    ext[rem] = n_local_pad + sorter[np.searchsorted(halo_global, g[rem], sorter=sorter)]
                 edge_sets[name] = {"agent": ext, "venue": ls["venue"], "people": ls["people"]}
             ext_global = np.zeros(n_ext, dtype=np.int64)
             ext_global[:n_local] = np.arange(a0, a1)
@@ -387,10 +454,10 @@ def _finish_torch_impl(self, age, sex, slice_agents):
         for ls in self.local_sets[r].values():
             if isinstance(ls["agent_global"], torch.Tensor):
                 dev = ls["agent_global"].device
-        halo_t = torch.unique(torch.cat(hl)) if hl else torch.zeros(0, dtype=torch.int64, device=dev)
+        halo_t, owner_t = order_halo(hl, self.bounds, device=dev)
         halo_global = halo_t.cpu().numpy()
-        owner = np.searchsorted(self.bounds, halo_global, side="right") - 1
-        halo_from = np.bincount(owner, minlength=self.world_size).astype(np.int64)
+        halo_from = np.bincount(owner_t.cpu().numpy(), minlength=self.world_size).astype(np.int64)
+        halo_sorted, sorter_t = torch.sort(halo_t, stable=True)
         sa = slice_agents
         if sa is None:
             _, sa = TL.choose_slices(n_local + len(halo_global) if os.environ.get("GJ_RANK_SLICES", "owned") == "ext"
@@ -406,7 +473,8 @@ def _finish_torch_impl(self, age, sex, slice_agents):
             ext = g - a0
             rem = (g < a0) | (g >= a1)
             if len(halo_global):
-                ext = torch.where(rem, n_local_pad + torch.searchsorted(halo_t, g), ext)
+                ext = torch.where(rem, n_local_pad + sorter_t[torch.searchsorted(halo_sorted, g).clamp_(max=halo_t.numel() - 1)],
+                                  ext)
             elif bool(rem.any()):
                 raise RuntimeError("a remote attendee without a halo list")
             edge_sets[name] = {"agent": ext, "venue": ls["venue"], "people": ls["people"]}

@@ -256,6 +256,51 @@ def test_torch_streamed_share_equals_the_numpy_partition(geography, R):
         assert np.array_equal(share["original_id"], wn["original_id"][a0:a1])
 
 
+def test_halo_agents_are_ordered_by_the_venue_that_needs_them():
+    """The extended index range lists a rank's halo agents owner by owner (what the all-to-all delivers) and, inside an
+    owner's group, by the halo set and venue that needs them: a halo slice then meets few venue blocks - its tiles are
+    long instead of a handful of edges each (id order, rounds 1-3) - and the exchange still delivers the owners' values."""
+    from grad_june_amd import distributed as D
+
+    world = make_world("c5", n_agents=60_000, seed=4)
+    x = np.random.default_rng(3).random(60_000).astype(np.float32)
+    R, tiles = 4, {}
+    for order in ("venue", "id"):
+        D.HALO_ORDER = order
+        try:
+            rws = [build_rank_world(world, r, R, slice_agents=512) for r in range(R)]
+        finally:
+            D.HALO_ORDER = "venue"
+        rw = rws[1]
+        owner = np.searchsorted(rw.bounds, rw.halo_global, side="right") - 1
+        assert (np.diff(owner) >= 0).all() and np.array_equal(np.bincount(owner, minlength=R), rw.halo_from)
+        assert len(np.unique(rw.halo_global)) == rw.n_halo and (owner != 1).all()
+        xs = []
+        for w in rws:
+            xe = np.zeros(w.n_ext, dtype=np.float32)
+            xe[: w.n_local] = x[w.bounds[w.rank]:w.bounds[w.rank + 1]]
+            xs.append(xe)
+        emulate_exchange(rws, xs)
+        assert np.array_equal(xs[1][rw.n_local_pad:], x[rw.halo_global])
+        host = compile_plan(rw.n_local, rw.edge_sets, age=rw.age, sex=rw.sex, n_ext_agents=rw.n_ext, layout="tiled",
+                            slices=(rw.n_slices, rw.slice_agents), sv_max=256, eb_target=1024)
+        first_halo = rw.n_local_pad // rw.slice_agents
+        n = 0
+        for s in host.sets:
+            if rw.modes[s.name] == "halo":
+                J = s.tiled.n_blocks
+                n += int((np.diff(s.tiled.tile_sptr[first_halo * J:]) > 0).sum())
+        tiles[order] = n
+        # every edge of a halo agent is still where the kernels look for it: pass 1 of the halo sets equals the global pass
+        ref = reference_pass(world, x)
+        pad = np.pad(xs[1], (0, host.n_slices * host.slice_agents - rw.n_ext))
+        for s in host.sets:
+            if rw.modes[s.name] == "halo":
+                cum = emulate_pass1(s.tiled, pad, host.slice_agents, beta=1.0)[1]
+                assert np.allclose(cum, ref[s.name.split("~")[0]][0][rw.venue_global[s.name]], rtol=1e-5, atol=1e-7), s.name
+    assert tiles["venue"] < 0.6 * tiles["id"], tiles
+
+
 def test_single_rank_is_all_local():
     world = small_world(2000)
     rw = build_rank_world(world, 0, 1)

@@ -5,7 +5,7 @@
 # Every step writes under gpurun_out/final/; a step that fails or times out stops the script (no further GPU step
 # after a kill).  Under rocprofv3 the program itself follows `--` (no shell, no env wrapper).
 set -euo pipefail
-tag=${1:-r03}
+tag=${1:-r04}
 root=$(pwd)
 out=$root/gpurun_out/final
 rm -rf "$out"

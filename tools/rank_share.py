@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--generator", default="numpy", choices=["numpy", "torch"],
                     help="torch: the world is drawn on the device and the share cut out there (synthetic.iter_world_torch)")
     ap.add_argument("--exchange-rule", default="venue", choices=["venue", "set"])
+    ap.add_argument("--halo-order", default="venue", choices=["venue", "id"],
+                    help="order of a peer's halo agents in the extended index range: by the venue that needs them, or by id")
     a = ap.parse_args()
     import torch
 
@@ -48,6 +50,7 @@ def main():
     from grad_june_amd.synthetic import iter_world, iter_world_torch
 
     D.EXCHANGE_RULE = a.exchange_rule
+    D.HALO_ORDER = a.halo_order
     entry.build()
     dev = torch.device("cuda:0")
     t0 = time.time()
@@ -87,7 +90,7 @@ def main():
     out = {
         "what": f"rank {a.rank} of {a.of}: kernels of one step on its share, collectives not executed",
         "geometry": {"slice_agents": int(rw.slice_agents), "n_slices": int(rw.n_slices), "eb_target": a.eb_target, "sv_max": a.sv_max},
-        "preset": a.preset, "geography": a.geography, "generator": a.generator, "exchange_rule": a.exchange_rule, "n_agents_world": share["n_agents"], "n_owned": int(rw.n_local), "n_halo": int(rw.n_halo),
+        "preset": a.preset, "geography": a.geography, "generator": a.generator, "exchange_rule": a.exchange_rule, "halo_order": a.halo_order, "n_agents_world": share["n_agents"], "n_owned": int(rw.n_local), "n_halo": int(rw.n_halo),
         "modes": rw.modes, "venue_classes": share["classes"],
         "local_set_edges": {k: int(len(v["agent"])) for k, v in rw.edge_sets.items()},
         "halo_all_to_all_bytes_in_per_step": 4 * int(rw.n_halo),
