@@ -243,7 +243,8 @@ def test_transmission_profile_negative_base(G, device):
         ok = ~torch.isnan(ref)
         assert np.allclose(got[ok].numpy(), ref[ok].numpy(), rtol=2e-5, atol=1e-12)
         if now_shift == 0.0:
-            assert (got[shape != 1.56] == 0).all() and torch.isnan(got[shape == 1.56]).all()
+            sh = ip["shape"]
+            assert (got[sh != 1.56] == 0).all() and torch.isnan(got[sh == 1.56]).all()
 
 
 def test_is_infected_sampler_statistics(G, device):
