@@ -286,6 +286,46 @@ __global__ void k_explicit_slots(const int32_t* sptr, const int32_t* tile_jpos, 
   }
 }
 
+// multi chunks (tiling.attach_multi_slots): a row of 64 explicit slots for every chunk its descriptor cannot express
+__global__ void k_multi_flags(const int32_t* desc, int32_t n_chunks, int32_t wide, int32_t* flags) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > n_chunks) return;
+  if (c == n_chunks) {
+    flags[c] = 0;
+    return;
+  }
+  const uint32_t w = (uint32_t)desc[(int64_t)c * (wide ? 8 : 4) + (wide ? 7 : 2)];
+  flags[c] = wide ? (int32_t)((w >> 8) & 1u) : (int32_t)((w >> 16) != 0u);
+}
+// one wave per chunk: lane l resolves slice-major position first_edge + l; the descriptor's j0 field becomes the row
+__global__ void k_multi_fill(const int32_t* chunk_ptr, const int32_t* sptr, const int32_t* tile_jpos, int32_t J, int32_t S,
+                             int32_t n_chunks, int32_t wide, const int32_t* row_of, int32_t* desc, int32_t* multi_slots,
+                             int32_t* counts) {
+  const int lane = threadIdx.x % 64;
+  const int waves = (gridDim.x * blockDim.x) / 64;
+  for (int c = (blockIdx.x * blockDim.x + threadIdx.x) / 64; c < n_chunks; c += waves) {
+    if (row_of[c + 1] == row_of[c]) continue;          // (wave-uniform)
+    const int m = row_of[c];
+    const ChunkGeom g = chunk_geom(c, chunk_ptr, sptr, J, S);
+    const int pos = g.first_edge + lane;
+    int slot = 0;
+    if (pos < g.chunk_end) {
+      const int t = upper_bound(sptr, S * J + 1, pos) - 1;
+      slot = tile_jpos[t] + (pos - sptr[t]);
+    }
+    multi_slots[(int64_t)m * 64 + lane] = slot;
+    if (lane == 0) {
+      if (wide) {
+        if (m >= (1 << 22)) counts[GJ_CC_ERROR] = 4;
+        int32_t* d7 = desc + (int64_t)c * 8 + 7;
+        *d7 = (int32_t)(((uint32_t)*d7 & 0x1FFu) | ((uint32_t)m << 9));
+      } else {
+        desc[(int64_t)c * 4 + 3] = m;
+      }
+    }
+  }
+}
+
 // ---- run form (tiling.split_primary_runs / finish_run_form) ---------------------------------------------------------
 constexpr int32_t kNoVenue = 0x7FFFFFFF;
 
@@ -669,6 +709,33 @@ int gj_compile_explicit_slots(const gj_compile_set* set, const gj_compile_out* o
   const int64_t n_tiles = (int64_t)set->n_slices * set->n_blocks;
   gjc::k_explicit_slots<<<gjc::grid_for(set->n_edges), gjc::kThreads, 0, (hipStream_t)stream>>>(
       out->tile_sptr, out->tile_jpos, n_tiles, set->n_edges, slots);
+  return (int)hipGetLastError();
+}
+
+int gj_compile_multi_slots(const gj_compile_set* set, const gj_compile_out* out, int32_t n_chunks, int32_t wide,
+                           int32_t* desc, int32_t n_multi, int32_t* multi_slots, int32_t* counts, void* workspace,
+                           int64_t workspace_bytes, void* stream) {
+  if (const int rc = gjc::check_set(set)) return rc;
+  if (!out || !out->tile_sptr || !out->tile_jpos || !out->chunk_ptr || !counts) return GJ_E_NULL;
+  if (set->n_blocks < 1 || n_chunks < 0 || n_multi < 0) return GJ_E_RANGE;
+  if (n_chunks == 0 || n_multi == 0) return 0;
+  if (!desc || !multi_slots || !workspace) return GJ_E_NULL;
+  // workspace: flags [n_chunks + 1] | rows [n_chunks + 1] | scan temp
+  const int64_t n1 = (int64_t)n_chunks + 1;
+  size_t temp_bytes = 0;
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, temp_bytes, (const int32_t*)nullptr, (int32_t*)nullptr, (int)n1);
+  const int64_t need = 2 * gjc::align_up(n1 * 4) + gjc::align_up((int64_t)temp_bytes);
+  if (need > workspace_bytes) return GJ_E_RANGE;
+  char* base = static_cast<char*>(workspace);
+  int32_t* flags = reinterpret_cast<int32_t*>(base);
+  int32_t* rows = reinterpret_cast<int32_t*>(base + gjc::align_up(n1 * 4));
+  void* temp = base + 2 * gjc::align_up(n1 * 4);
+  hipStream_t st = (hipStream_t)stream;
+  gjc::k_multi_flags<<<gjc::grid_for(n1), gjc::kThreads, 0, st>>>(desc, n_chunks, wide, flags);
+  if (const int rc = gjc::exclusive_scan(temp, temp_bytes, flags, rows, n1, st)) return rc;
+  gjc::k_multi_fill<<<gjc::grid_for((int64_t)n_chunks * 64), gjc::kThreads, 0, st>>>(
+      out->chunk_ptr, out->tile_sptr, out->tile_jpos, set->n_blocks, set->n_slices, n_chunks, wide, rows, desc, multi_slots,
+      counts);
   return (int)hipGetLastError();
 }
 

@@ -149,6 +149,7 @@ struct TSetA {            // what phases A and D need of one set
                           // 2: no descriptors - chunk_desc is int32 [E], the block-major slot of every slice-major edge
   int32_t direct;         // pass 2 of the set is taken by phase D's direct form (TDirect): no val / a_la reads there
   int32_t presum;         // pass 1 of the set is taken by k_tile_presum: phase A has nothing to scatter
+  const int32_t* multi_slots;   // rows of 64 explicit slots for the chunks a descriptor cannot express, or NULL (walk the tables)
 };
 
 struct TileAArgs {
@@ -248,13 +249,17 @@ __device__ __forceinline__ void batch_slots(const TSetA& T, const int word, int 
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int i = min(seg0 + (c0 + u) * kWave + lane, seg1 - 1);
+      // a chunk that spans more tiles than its descriptor has segments: its lanes' slots are row j0 of multi_slots - one
+      // coalesced load (wave-uniform branch per chunk; without the rows - a plan of rounds 1-3 - the lanes walk the tables)
       if (!WIDE) {
         const int4 d = make_int4(GJ_DW(u, 0), GJ_DW(u, 1), GJ_DW(u, 2), GJ_DW(u, 3));
-        slot[u] = (d.z >> 16) ? chunk_slot_slow(T, d, row, i, lane) : chunk_slot_fast(d, lane);
+        slot[u] = (d.z >> 16) ? (T.multi_slots ? at32(T.multi_slots, d.w * kWave + lane) : chunk_slot_slow(T, d, row, i, lane))
+                              : chunk_slot_fast(d, lane);
       } else {
         const int4 d0 = make_int4(GJ_DW(u, 0), GJ_DW(u, 1), GJ_DW(u, 2), GJ_DW(u, 3));
         const int4 d1 = make_int4(GJ_DW(u, 4), GJ_DW(u, 5), GJ_DW(u, 6), GJ_DW(u, 7));
-        slot[u] = (d1.w & 0x100) ? chunk_slot_walk(T, row, i, (int)((unsigned)d1.w >> 9))
+        const int j0 = (int)((unsigned)d1.w >> 9);
+        slot[u] = (d1.w & 0x100) ? (T.multi_slots ? at32(T.multi_slots, j0 * kWave + lane) : chunk_slot_walk(T, row, i, j0))
                                  : chunk_slot_wide(d0, d1, lane);
       }
     }
@@ -285,6 +290,12 @@ __device__ __forceinline__ void scatter_batches(const TSetA& T, const float* lds
   auto stage2 = [&](int c, int word, const int (&la)[kU]) {
     int slot[kU];
     batch_slots<WIDE, kU>(T, word, row, seg0, seg1, c, lane, slot);
+#ifdef GJ_DIAG_EXTRA_VALU      // diagnostics (tools/ab.py): N no-op VALU instructions per edge - is the launch bound by instruction issue?
+#pragma unroll
+    for (int u = 0; u < kU; ++u)
+#pragma unroll
+      for (int r = 0; r < GJ_DIAG_EXTRA_VALU; ++r) asm volatile("v_add_u32 %0, %0, 0" : "+v"(slot[u]));
+#endif
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
       const int i = seg0 + (c + u) * kWave + lane;
@@ -395,6 +406,12 @@ __device__ __forceinline__ void gather_set(const TSetA& T, fx_t* lds_acc, uint32
       x[u] = edge ? v[u] : 0.0f;
       m = max(m, __float_as_uint(x[u]) & 0x7FFFFFFFu);
     }
+#ifdef GJ_DIAG_EXTRA_VALU
+#pragma unroll
+    for (int u = 0; u < kU; ++u)
+#pragma unroll
+      for (int r = 0; r < GJ_DIAG_EXTRA_VALU; ++r) asm volatile("v_add_f32 %0, %0, 0" : "+v"(x[u]));
+#endif
     if (__builtin_expect(m <= kLimit, 1)) {
 #pragma unroll
       for (int u = 0; u < kU; ++u) atomicAdd(&lds_acc[la[u]], to_fx<kFxAgent>(x[u]));

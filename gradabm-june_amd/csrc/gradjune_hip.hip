@@ -1183,6 +1183,7 @@ static void fill_set_a(const gj_plan* plan, const gj_step_params* p, const Group
     sets[s].raw = p->nets[G.first[g]].mask_kind == GJ_MASK_RAW;
     sets[s].wide = S.desc_wide;          // 0 / 1: descriptor format, 2: explicit slots
     sets[s].direct = S.ell_k != 0;
+    sets[s].multi_slots = S.multi_slots;
   }
 }
 

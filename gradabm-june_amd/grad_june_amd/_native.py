@@ -67,6 +67,7 @@ class TiledSet(C.Structure):
         ("run_max_window", C.c_int32),
         ("run_tiled_edges", C.c_int32),
         ("presum", _vp),
+        ("multi_slots", _vp),
         ("max_venue_edges", C.c_int32),
         ("_pad_mve", C.c_int32),
     ]
@@ -266,6 +267,8 @@ SYMBOLS.update({
     "gj_compile_wide_descriptors": (C.c_int, [C.POINTER(CompileSet), C.POINTER(CompileOut), C.c_int32, _vp, _vp, _vp]),
     "gj_compile_ell_degrees": (C.c_int, [C.POINTER(CompileSet), _vp, _vp, _vp]),
     "gj_compile_explicit_slots": (C.c_int, [C.POINTER(CompileSet), C.POINTER(CompileOut), _vp, _vp]),
+    "gj_compile_multi_slots": (C.c_int, [C.POINTER(CompileSet), C.POINTER(CompileOut), C.c_int32, C.c_int32, _vp,
+                                          C.c_int32, _vp, _vp, _vp, C.c_int64, _vp]),
     "gj_compile_runs_pick": (C.c_int, [C.POINTER(CompileSet), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gj_compile_runs_rest": (C.c_int, [C.POINTER(CompileSet), _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp]),
     "gj_compile_runs_index": (C.c_int, [C.POINTER(CompileSet), _vp, _vp, C.c_int32, C.c_int64, _vp, _vp, _vp, _vp, _vp]),

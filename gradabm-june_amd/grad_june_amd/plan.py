@@ -227,7 +227,7 @@ def save_plan(plan: HostPlan, path) -> None:
         if s.tiled is not None:
             t = s.tiled
             for k in ("blk_v0", "blk_e0", "e_lv", "e_cls", "a_la", "tile_sptr", "tile_jpos", "chunk_ptr", "chunk_desc", "ell",
-                      "slot_idx"):
+                      "slot_idx", "multi_slots"):
                 if getattr(t, k) is not None:
                     a = _host(getattr(t, k))
                     out[p + "tiled/" + k] = a.view(np.uint16) if (k in ("e_lv", "a_la", "ell") and a.dtype == np.int16) else a
@@ -264,6 +264,7 @@ def load_plan(path) -> HostPlan:
                                        v_pcontact=hs.v_pcontact, n_slots=n_slots, chunk_ptr=a[p + "tiled/chunk_ptr"],
                                        chunk_desc=a[p + "tiled/chunk_desc"], desc_wide=bool(wide),
                                        ell=a.get(p + "tiled/ell"), ell_k=ell_k, slot_idx=a.get(p + "tiled/slot_idx"),
+                                       multi_slots=a.get(p + "tiled/multi_slots"),
                                        presum=bool(meta[5]) if len(meta) > 5 else False)
             if p + "tiled/runs/meta" in a:
                 r = p + "tiled/runs/"
@@ -567,6 +568,9 @@ class DevicePlan:
                 if ts.slot_idx is not None and ts.n_edges > 0:      # tiles of a few edges: explicit slots, no descriptors
                     t["chunk_desc"] = up(ts.slot_idx)
                     c.desc_wide = 2
+                elif ts.multi_slots is not None and len(ts.multi_slots):
+                    t["multi_slots"] = up(ts.multi_slots.reshape(-1))
+                    c.multi_slots = t["multi_slots"].data_ptr()
                 c.blk_v0, c.blk_e0 = t["blk_v0"].data_ptr(), t["blk_e0"].data_ptr()
                 c.e_lv, c.a_la = t["e_lv"].data_ptr(), t["a_la"].data_ptr()
                 c.e_cls = N.ptr(t.get("e_cls"))

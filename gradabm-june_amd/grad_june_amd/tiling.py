@@ -105,6 +105,8 @@ class TiledEdgeSet:
     desc_wide: bool = False                  # chunk_desc is int32 [n_chunks, 8], see wide_descriptors()
     slot_idx: Optional[np.ndarray] = None    # int32 [E]: the block-major slot of every slice-major edge - replaces the
                                              # descriptors of a set with tiles of a few edges (EXPLICIT_MIN_SHARE)
+    multi_slots: Optional[np.ndarray] = None  # int32 [n_multi, 64]: the slots of the 64 edges of every chunk its descriptor
+                                              # cannot express ("multi"); the descriptor's j0 field then holds the row
     ell: Optional[np.ndarray] = None         # uint16 [owned agents padded to slices, ell_k]: "direct" pass 2, see build_ell()
     ell_k: int = 0                           # 0: pass 2 runs through phases C + D like pass 1
     runs: Optional["RunForm"] = None         # the set's primary edges in the run form (see split_primary_runs)
@@ -113,7 +115,9 @@ class TiledEdgeSet:
     # A chunk = 64 consecutive slice-major edges.  Its first `split` edges lie in one tile and map to
     # block-major slots slot0, slot0+1, ...; the rest lie in the next non-empty tile and map to slot1,
     # slot1+1, ...  `multi` flags the rare chunk that spans more than two tiles (tiny tiles): its
-    # lanes resolve their slot from the tile tables, starting at block j0.
+    # lanes take their slots from row j0 of `multi_slots` (round 4; before: they walked the tile tables from block j0 -
+    # dependent loads, ~50x a normal chunk: a world with a geography keeps most of a slice's edges in a few long tiles
+    # and scatters the rest - 1 % of the school edges - over every block, and that 1 % doubled phase A).
 
 
 WIDE_SEGMENTS = 6      # tiles a 64-edge chunk may span in the wide descriptor format
@@ -158,10 +162,43 @@ def wide_descriptors(sptr: np.ndarray, jpos_flat: np.ndarray, seg: np.ndarray, c
     return desc.astype(np.uint32).view(np.int32), nseg
 
 
+def multi_flags(chunk_desc, wide: bool) -> np.ndarray:
+    """bool [n_chunks]: the chunks whose descriptor cannot express them (more tiles than it has segments)."""
+    d = np.asarray(chunk_desc.cpu() if hasattr(chunk_desc, "cpu") else chunk_desc).reshape(-1, 8 if wide else 4)
+    return (((d[:, 7].view(np.uint32) >> 8) & 1) if wide else (d[:, 2].view(np.uint32) >> 16)) != 0
+
+
+def attach_multi_slots(chunk_desc: np.ndarray, wide: bool, first_edge: np.ndarray, chunk_end: np.ndarray,
+                       sptr: np.ndarray, jpos_flat: np.ndarray):
+    """The slots of the multi chunks, one row of 64 per chunk in chunk order (lanes past the chunk's end: 0), and the
+    descriptors with the row number in their j0 field.  Returns (chunk_desc, multi_slots or None)."""
+    flags = multi_flags(chunk_desc, wide)
+    rows = np.flatnonzero(flags)
+    if len(rows) == 0:
+        return chunk_desc, None
+    pos = first_edge[rows][:, None] + np.arange(CHUNK, dtype=np.int64)[None, :]
+    ok = pos < chunk_end[rows][:, None]
+    pos = np.where(ok, pos, first_edge[rows][:, None])
+    t_of = np.searchsorted(sptr, pos.reshape(-1), side="right") - 1
+    slots = (jpos_flat[t_of] + (pos.reshape(-1) - sptr[t_of])).reshape(-1, CHUNK)
+    slots = np.where(ok, slots, 0).astype(np.int32)
+    d = chunk_desc.copy()
+    m = np.arange(len(rows), dtype=np.int64)
+    if wide:
+        w7 = d[rows, 7].view(np.uint32).astype(np.int64)
+        d[rows, 7] = ((w7 & 0x1FF) | (m << 9)).astype(np.uint32).view(np.int32)
+        if len(m) >= (1 << 22):
+            raise ValueError("too many multi chunks for the wide descriptor's row field")
+    else:
+        d[rows, 3] = m.astype(np.int32)
+    return d, slots
+
+
 def walk_share(t: "TiledEdgeSet") -> float:
     """Share of a set's 64-edge chunks whose lanes have to walk the tile tables in phases A and D (more tiles in the
-    chunk than its descriptor expresses).  0 for a set with explicit slots; build_tiled keeps it <= EXPLICIT_MIN_SHARE."""
-    if t.slot_idx is not None or t.chunk_desc is None or len(t.chunk_desc) == 0:
+    chunk than its descriptor expresses, and no row of explicit slots for it).  0 for a set with explicit slots or with
+    ``multi_slots`` - i.e. for everything build_tiled / the native compile produce since round 4."""
+    if t.slot_idx is not None or t.multi_slots is not None or t.chunk_desc is None or len(t.chunk_desc) == 0:
         return 0.0
     d = np.asarray(t.chunk_desc.cpu() if hasattr(t.chunk_desc, "cpu") else t.chunk_desc).reshape(-1, 8 if t.desc_wide else 4)
     flag = ((d[:, 7].view(np.uint32) >> 8) & 1) if t.desc_wide else (d[:, 2].view(np.uint32) >> 16)
@@ -171,7 +208,7 @@ def walk_share(t: "TiledEdgeSet") -> float:
 def build_tiled(name: str, agent_index, venue_index, n_venues: int, v_pcontact: np.ndarray,
                 n_slices: int, slice_agents: int, agent_class: Optional[np.ndarray] = None,
                 sv_max: int = SV_MAX, eb_target: int = EB_TARGET, wide: Optional[bool] = None,
-                explicit: Optional[bool] = None, tile_pad: int = 1) -> TiledEdgeSet:
+                explicit: Optional[bool] = None, tile_pad: int = 1, multi_rows: bool = True) -> TiledEdgeSet:
     """``tile_pad`` (experiment, host compile only - DESIGN.md section 8, "the next lever"): every tile's run is padded
     to a multiple of ``tile_pad`` positions in BOTH orders, so that every piece of a 64-edge chunk starts and ends on
     a 64-byte boundary of ``val`` (tile_pad = 16).  Pad positions: local agent 0 in ``a_la``, local venue 0xFFFF in
@@ -267,10 +304,14 @@ def build_tiled(name: str, agent_index, venue_index, n_venues: int, v_pcontact: 
         chunk_desc, nseg = wide_descriptors(sptr, jpos_sj.reshape(-1), seg, chunk_ptr, first_edge, chunk_end, t0, J)
         if explicit is None:
             explicit = bool(len(nseg)) and float((nseg > WIDE_SEGMENTS).mean()) > EXPLICIT_MIN_SHARE
+    multi_slots = None
     if explicit:
         # (every slice-major position, pads included: position p of tile t sits at tile_jpos[t] + (p - sptr[t]))
         t_of = np.searchsorted(sptr, np.arange(E, dtype=np.int64), side="right") - 1
         slot_idx = (jpos_sj.reshape(-1)[t_of] + (np.arange(E, dtype=np.int64) - sptr[t_of])).astype(np.int32)
+    elif multi_rows:
+        chunk_desc, multi_slots = attach_multi_slots(np.ascontiguousarray(chunk_desc), bool(wide), first_edge, chunk_end,
+                                                     sptr, jpos_sj.reshape(-1))
     return TiledEdgeSet(
         name=name, n_venues=n_venues, n_edges=E, n_slices=S, n_blocks=J,
         blk_v0=blk_v0.astype(np.int32), blk_e0=blk_start.astype(np.int32),
@@ -278,7 +319,7 @@ def build_tiled(name: str, agent_index, venue_index, n_venues: int, v_pcontact: 
         tile_sptr=sptr.astype(np.int32), tile_jpos=jpos_sj.reshape(-1).astype(np.int32),
         v_pcontact=np.asarray(v_pcontact, dtype=np.float32), n_slots=n_slots,
         chunk_ptr=chunk_ptr.astype(np.int32), chunk_desc=np.ascontiguousarray(chunk_desc), desc_wide=bool(wide),
-        slot_idx=slot_idx)
+        slot_idx=slot_idx, multi_slots=multi_slots)
 
 
 # ------------------------------------------------------------------------------------------------

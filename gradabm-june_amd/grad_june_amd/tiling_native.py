@@ -72,7 +72,7 @@ class _Session:
 def build_tiled_native(name: str, agent_index, venue_index, n_venues: int, v_pcontact, n_slices: int, slice_agents: int,
                        agent_class=None, sv_max: int = TL.SV_MAX, eb_target: int = TL.EB_TARGET,
                        wide: Optional[bool] = None, device=None, n_ext_agents: Optional[int] = None,
-                       explicit: Optional[bool] = None) -> TL.TiledEdgeSet:
+                       explicit: Optional[bool] = None, multi_rows: bool = True) -> TL.TiledEdgeSet:
     if slice_agents > 65536 or sv_max > 65535:
         raise ValueError("local indices are 16-bit")
     dev = torch.device(device if device is not None else agent_index.device)
@@ -130,18 +130,31 @@ def build_tiled_native(name: str, agent_index, venue_index, n_venues: int, v_pco
                 explicit = n_chunks > 0 and int(c[N.GJ_CC_WIDE_MULTI]) / n_chunks > TL.EXPLICIT_MIN_SHARE
         else:
             chunk_desc = desc[: n_chunks * 4].reshape(n_chunks, 4).clone()      # (drops the upper-bound tail)
+        multi_slots = None
         if explicit and E > 0:
             slot_idx = torch.empty(E, dtype=torch.int32, device=dev)
             N.check(lib.gj_compile_explicit_slots(C.byref(se.set), C.byref(out), N.ptr(slot_idx), st),
                     "gj_compile_explicit_slots")
             torch.cuda.current_stream().synchronize()
+        elif multi_rows and n_chunks > 0:
+            # the chunks the descriptors cannot express get a row of explicit slots each (tiling.attach_multi_slots)
+            n_m = int(c[N.GJ_CC_WIDE_MULTI]) if wide else n_multi
+            if n_m > 0:
+                chunk_desc = chunk_desc.contiguous()
+                multi_slots = torch.empty((n_m, 64), dtype=torch.int32, device=dev)
+                ws2 = torch.empty(2 * (4 * (n_chunks + 1) + 256) + (1 << 20), dtype=torch.uint8, device=dev)
+                N.check(lib.gj_compile_multi_slots(C.byref(se.set), C.byref(out), n_chunks, 1 if wide else 0,
+                                                   N.ptr(chunk_desc), n_m, N.ptr(multi_slots), N.ptr(se.counts), N.ptr(ws2),
+                                                   ws2.numel(), st), "gj_compile_multi_slots")
+                se.read_counts(name)
         se.ws = None
     return TL.TiledEdgeSet(
         name=name, n_venues=n_venues, n_edges=E, n_slices=S, n_blocks=J,
         blk_v0=blk_v0[: J + 1].clone(), blk_e0=blk_e0, e_lv=e_lv[:n_slots].clone(),
         e_cls=None if e_cls is None else e_cls[:n_slots].clone(), a_la=a_la[:E],
         tile_sptr=sptr, tile_jpos=jpos, v_pcontact=v_pc, n_slots=n_slots,
-        chunk_ptr=chunk_ptr, chunk_desc=chunk_desc.contiguous(), desc_wide=bool(wide), slot_idx=slot_idx)
+        chunk_ptr=chunk_ptr, chunk_desc=chunk_desc.contiguous(), desc_wide=bool(wide), slot_idx=slot_idx,
+        multi_slots=multi_slots)
 
 
 class EllBuilder:

@@ -171,6 +171,11 @@ typedef struct gj_tiled_set {
    * network) and write it to presum[workgroup][venue][network]; a second launch adds the tables up and applies
    * beta * p_contact.  Exact (integer sums), so cum is the same bit for bit as through phases A + B.              */
   int64_t* presum;            /* device [presum_wgs][n_venues * cum_stride] workspace or NULL                         */
+  const int32_t* multi_slots; /* device [n_multi * 64] or NULL: the block-major slots of the 64 edges of every chunk that spans
+                                 more tiles than its descriptor has segments ("multi"); the descriptor's j0 field holds the
+                                 chunk's row.  NULL: such a chunk's lanes walk tile_sptr / tile_jpos from block j0
+                                 (rounds 1-3: ~50x the cost of a chunk - 1 % of them doubled phase A on a world with a
+                                 geography).  ABI 6                                                                     */
   int32_t max_venue_edges;    /* edges of the set's LARGEST venue (run-form primaries included).  Bounds the terms of one
                                  venue sum: the window of a term is min(16384, 2^26 / next_pow2(max_venue_edges)), so that
                                  no sum can leave its 64 bits.  0 = not stated: 16384, no such guarantee (ABI 6)        */
@@ -540,6 +545,15 @@ int gj_compile_ell(const gj_compile_set* set, int32_t ell_k, int64_t rows, const
 /* (optional, after gj_compile_tiles) the explicit-slot form of a set with tiles of a few edges: slots[i] (int32 [E]) = the
  * block-major slot of slice-major edge i; gj_tiled_set.desc_wide = 2 and chunk_desc = slots.                       */
 int gj_compile_explicit_slots(const gj_compile_set* set, const gj_compile_out* out, int32_t* slots, void* stream);
+/* (after gj_compile_tiles / gj_compile_wide_descriptors, for a set NOT in the explicit-slot form) the chunks a descriptor
+ * cannot express - counts[GJ_CC_MULTI] of the 4-word form, counts[GJ_CC_WIDE_MULTI] of the 8-word form = `n_multi` - get
+ * a row of 64 explicit slots each, in chunk order (gj_tiled_set.multi_slots, int32 [n_multi * 64], caller-owned; lanes
+ * past a chunk's end: 0), and their descriptors the row number in the j0 field.  `desc` = the descriptors in use
+ * ([n_chunks * 4] or, `wide` != 0, [n_chunks * 8]); workspace >= 2 * (n_chunks + 1) * 4 bytes + 64 KiB.
+ * Specification: tiling.attach_multi_slots.  (ABI 6; before, such a chunk's lanes walked the tile tables.)              */
+int gj_compile_multi_slots(const gj_compile_set* set, const gj_compile_out* out, int32_t n_chunks, int32_t wide,
+                           int32_t* desc, int32_t n_multi, int32_t* multi_slots, int32_t* counts, void* workspace,
+                           int64_t workspace_bytes, void* stream);
 
 /* ---- run form of the set that orders the agents (gj_tiled_set.run_*; specification: tiling.split_primary_runs /
  * finish_run_form).  Three steps around the compile of the set's remaining edges:

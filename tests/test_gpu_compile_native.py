@@ -39,6 +39,9 @@ def assert_same_tiled(got, ref, what=""):
     assert (got.slot_idx is None) == (ref.slot_idx is None), what
     if ref.slot_idx is not None:
         assert np.array_equal(_host(got.slot_idx), ref.slot_idx), (what, "slot_idx")
+    assert (got.multi_slots is None) == (ref.multi_slots is None), (what, "multi_slots")
+    if ref.multi_slots is not None:
+        assert np.array_equal(_host(got.multi_slots), ref.multi_slots), (what, "multi_slots")
 
 
 CASES = [  # A, V, E, sa, svmax, eb, wide, dup

@@ -415,7 +415,7 @@ def test_device_compiled_plan_is_identical(device):
     assert np.array_equal(dev.work, host.work)
     for a, b in zip(dev.sets, host.sets):
         assert a.tiled.e_lv.device.type == "cuda"
-        for k in ("blk_v0", "blk_e0", "e_cls", "tile_sptr", "tile_jpos", "chunk_ptr", "chunk_desc"):
+        for k in ("blk_v0", "blk_e0", "e_cls", "tile_sptr", "tile_jpos", "chunk_ptr", "chunk_desc", "multi_slots"):
             x, y = getattr(a.tiled, k), getattr(b.tiled, k)
             assert (x is None) == (y is None) and (x is None or np.array_equal(_host(x), y)), (a.name, k)
         for k in ("e_lv", "a_la"):

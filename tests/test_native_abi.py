@@ -51,7 +51,7 @@ def test_struct_sizes_match_the_header_layout():
     assert ctypes.sizeof(N.AgentState) == 80
     assert ctypes.sizeof(N.StepIO) == 40
     assert ctypes.sizeof(N.Plan) == 16 + 16 + 72 * N.GJ_MAX_SETS + 5 * 8 + 8 + 8
-    assert ctypes.sizeof(N.TiledSet) == 16 + 11 * 8 + 5 * 8 + 8 + 8 + 8      # (+ max_venue_edges and its pad, ABI 6)
+    assert ctypes.sizeof(N.TiledSet) == 16 + 11 * 8 + 5 * 8 + 8 + 8 + 8 + 8  # (+ multi_slots, max_venue_edges and its pad: ABI 6)
     assert ctypes.sizeof(N.Tiled) == 16 + 8 + 8 + 8 + ctypes.sizeof(N.TiledSet) * N.GJ_MAX_SETS
 
 

@@ -46,7 +46,10 @@ def test_layout_and_emulation(A, V, E, sa, svmax, eb, wide):
                 d = [int(x) for x in t.chunk_desc[c]]
                 starts = [0] + [(d[6] >> (8 * k)) & 0xFF for k in range(4)] + [d[7] & 0xFF]
                 multi, j0 = (d[7] >> 8) & 1, (d[7] & 0xFFFFFFFF) >> 9
-                assert t.tile_sptr[sl * J + j0] <= i0 < t.tile_sptr[sl * J + j0 + 1]
+                if multi and t.slot_idx is None:   # the j0 field of a chunk the descriptor cannot express: its row of explicit slots
+                    assert np.array_equal(t.multi_slots[j0][:n], slot_ref[i0:i0 + n]) and (t.multi_slots[j0][n:] == 0).all()
+                elif not multi or t.slot_idx is not None:
+                    assert t.tile_sptr[sl * J + j0] <= i0 < t.tile_sptr[sl * J + j0 + 1]
                 assert starts == sorted(starts) and all(0 < st <= 64 for st in starts[1:])
                 lane = np.arange(n)
                 seg_of = sum((lane >= st).astype(int) for st in starts[1:])
@@ -62,12 +65,16 @@ def test_layout_and_emulation(A, V, E, sa, svmax, eb, wide):
                 continue
             slot0, slot1, sm, j0 = (int(x) for x in t.chunk_desc[c])
             split, multi = sm & 0xFFFF, sm >> 16
-            assert t.tile_sptr[sl * J + j0] <= i0 < t.tile_sptr[sl * J + j0 + 1] and 1 <= split <= n
+            assert 1 <= split <= n
             assert np.array_equal(slot_ref[i0:i0 + split], slot0 + np.arange(split))
             if multi:
                 n_multi += 1
+                assert np.array_equal(t.multi_slots[j0][:n], slot_ref[i0:i0 + n]) and (t.multi_slots[j0][n:] == 0).all()
             else:
+                assert t.tile_sptr[sl * J + j0] <= i0 < t.tile_sptr[sl * J + j0 + 1]
                 assert np.array_equal(slot_ref[i0 + split:i0 + n], slot1 + np.arange(n - split))
+    if t.slot_idx is None:         # (a set in the explicit-slot form carries every edge's slot instead)
+        assert (t.multi_slots is None and n_multi == 0) or len(t.multi_slots) == n_multi     # one row per such chunk, chunk order
     # every tile is contiguous in both orders and holds the same multiset of edges
     lens = np.diff(t.tile_sptr).reshape(S, J)
     assert lens.sum() == E
@@ -340,8 +347,13 @@ def test_no_compiled_set_walks_the_tile_tables(sv_max, eb):
     A, V, E, sa = 6000, 5000, 20000, 64
     agent, venue = rng.integers(0, A, E), (rng.zipf(1.5, E) % V)
     t = build_tiled("x", agent, venue, V, np.ones(V, np.float32), -(-A // sa), sa, sv_max=sv_max, eb_target=eb)
-    assert TL.walk_share(t) <= TL.EXPLICIT_MIN_SHARE
-    if t.slot_idx is None:         # descriptors kept: then they do express (nearly) every chunk
+    # round 4: NO chunk walks - what a descriptor cannot express has a row of explicit slots (multi_slots)
+    assert TL.walk_share(t) == 0.0
+    if t.slot_idx is None:
         forced = build_tiled("x", agent, venue, V, np.ones(V, np.float32), -(-A // sa), sa, sv_max=sv_max, eb_target=eb,
                              explicit=False)
-        assert TL.walk_share(forced) <= TL.EXPLICIT_MIN_SHARE
+        assert TL.walk_share(forced) == 0.0
+        # the descriptors themselves (round 3's fence) still express all but EXPLICIT_MIN_SHARE of the chunks
+        bare = build_tiled("x", agent, venue, V, np.ones(V, np.float32), -(-A // sa), sa, sv_max=sv_max, eb_target=eb,
+                           multi_rows=False)
+        assert bare.multi_slots is None and TL.walk_share(bare) <= TL.EXPLICIT_MIN_SHARE

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--of", type=int, default=8, help="ranks of the run")
     ap.add_argument("--rank", type=int, default=0)
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--eb-target", type=int, default=None)
     ap.add_argument("--sv-max", type=int, default=None)
@@ -75,7 +76,8 @@ def main():
                             rank_world=rw, total_edges=share["total_edges"], device_compile=True,
                             plan_kw={k: v for k, v in (("eb_target", a.eb_target), ("sv_max", a.sv_max)) if v})
     t_setup = time.time() - t0
-    for _ in range(3):
+    inf0 = float(hp.state["is_infected"].clamp(max=1).mean())
+    for _ in range(a.warmup):
         hp.step()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -96,6 +98,7 @@ def main():
         "halo_all_to_all_bytes_in_per_step": 4 * int(rw.n_halo),
         "partial_sum_all_reduce_bytes_per_step": 4 * int(hp.flat_cum.numel()) if hp.flat_cum is not None else 0,
         "kernel_ms_per_step": ms, "kernel_ms": hp.kernel_ms(),
+        "infected_fraction": {"start": inf0, "end": float(hp.state["is_infected"].clamp(max=1).mean())},
         "setup_s": {"stream_and_partition": t_part, "total": t_setup},
         "host_peak_rss_mb": resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0,
     }
