@@ -245,21 +245,43 @@ __device__ __forceinline__ void batch_slots(const TSetA& T, const int word, int 
                                   make_int4(GJ_DW(u, 4), GJ_DW(u, 5), GJ_DW(u, 6), GJ_DW(u, 7)), lane);
       }
     }
+  } else if (T.multi_slots) {
+    // A batch that holds a chunk its descriptor cannot express (more tiles than segments): that chunk's lanes take
+    // their slots from row j0 of multi_slots.  Branch-free: EVERY chunk of the batch issues the load (row 0 where it is
+    // not needed) before the first select, so the batch's loads are in flight together - under a per-chunk branch hipcc
+    // waits for each one with vmcnt(0), which also drains the software pipeline's loads of the next batch.
+    int ms[U];
+    bool mu[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int w = WIDE ? GJ_DW(u, 7) : GJ_DW(u, 2);
+      mu[u] = WIDE ? ((w & 0x100) != 0) : ((w >> 16) != 0);
+      const int j0 = WIDE ? (int)((unsigned)w >> 9) : GJ_DW(u, 3);
+      ms[u] = at32(T.multi_slots, (mu[u] ? j0 : 0) * kWave + lane);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int f;
+      if (!WIDE) {
+        f = chunk_slot_fast(make_int4(GJ_DW(u, 0), GJ_DW(u, 1), GJ_DW(u, 2), 0), lane);
+      } else {
+        f = chunk_slot_wide(make_int4(GJ_DW(u, 0), GJ_DW(u, 1), GJ_DW(u, 2), GJ_DW(u, 3)),
+                            make_int4(GJ_DW(u, 4), GJ_DW(u, 5), GJ_DW(u, 6), GJ_DW(u, 7)), lane);
+      }
+      slot[u] = mu[u] ? ms[u] : f;
+    }
   } else {
+    // a plan without the rows (rounds 1-3): the lanes of such a chunk walk the tile tables
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int i = min(seg0 + (c0 + u) * kWave + lane, seg1 - 1);
-      // a chunk that spans more tiles than its descriptor has segments: its lanes' slots are row j0 of multi_slots - one
-      // coalesced load (wave-uniform branch per chunk; without the rows - a plan of rounds 1-3 - the lanes walk the tables)
       if (!WIDE) {
         const int4 d = make_int4(GJ_DW(u, 0), GJ_DW(u, 1), GJ_DW(u, 2), GJ_DW(u, 3));
-        slot[u] = (d.z >> 16) ? (T.multi_slots ? at32(T.multi_slots, d.w * kWave + lane) : chunk_slot_slow(T, d, row, i, lane))
-                              : chunk_slot_fast(d, lane);
+        slot[u] = (d.z >> 16) ? chunk_slot_slow(T, d, row, i, lane) : chunk_slot_fast(d, lane);
       } else {
         const int4 d0 = make_int4(GJ_DW(u, 0), GJ_DW(u, 1), GJ_DW(u, 2), GJ_DW(u, 3));
         const int4 d1 = make_int4(GJ_DW(u, 4), GJ_DW(u, 5), GJ_DW(u, 6), GJ_DW(u, 7));
-        const int j0 = (int)((unsigned)d1.w >> 9);
-        slot[u] = (d1.w & 0x100) ? (T.multi_slots ? at32(T.multi_slots, j0 * kWave + lane) : chunk_slot_walk(T, row, i, j0))
+        slot[u] = (d1.w & 0x100) ? chunk_slot_walk(T, row, i, (int)((unsigned)d1.w >> 9))
                                  : chunk_slot_wide(d0, d1, lane);
       }
     }
