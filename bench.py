@@ -91,6 +91,9 @@ def parse():
     ap.add_argument("--backward", action="store_true",
                     help="row f3: time forward and backward of a T-step differentiable run (the eight log_beta as "
                          "nn.Parameter, loss = cases of the last step) instead of the forward-only hot path")
+    ap.add_argument("--wide-min-share", type=float, default=None,
+                    help="experiment: share of a set's chunks spanning more than two tiles above which it gets the 8-word "
+                         "descriptors (tiling.WIDE_MIN_SHARE, default 0.01); below it such chunks take a row of explicit slots")
     ap.add_argument("--tile-pad", type=int, default=1,
                     help="experiment (with --host-compile): pad every tile to a multiple of this many edges in both orders")
     ap.add_argument("--backward-recompute", action="store_true",
@@ -615,6 +618,10 @@ def main():
         if rank == 0:
             print(f"[bench {time.time() - t0:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
+    if args.wide_min_share is not None:
+        from grad_june_amd import tiling as _TL
+
+        _TL.WIDE_MIN_SHARE = float(args.wide_min_share)
     reorder = args.reorder if args.reorder != "auto" else "household"
     device_compile = not args.host_compile
     share = rw = None
