@@ -470,8 +470,10 @@ def auto_parts(n_agents: int) -> int:
     """One GPU: agent partitions stepped in turn (distributed.PartitionedHotPath).  Round 2 switched to partitions of
     16 M agents above 48 M, unmeasured; the round-3 sweeps (profiles/r03_c3_40m_parts*.json, r03_c5_100m_parts*.json)
     say a single partition is the fastest at every size tried - C3 at 40 M agents 2.62 / 2.78 / 2.96 / 3.00 ms for
-    1 / 2 / 3 / 4 partitions, C5 at 100 M agents 12.6 ms against 18.4 ms for 7 - so partitions are only what --parts
-    asks for (they remain the one-GPU rehearsal of the multi-GPU partitioning)."""
+    1 / 2 / 3 / 4 partitions in that sweep (2.38 ms with the round's final kernels, r03_c3_40m_parts1.json), C5 at 100 M
+    agents 8.4 ms (r03_c5_100m_parts1.json; 12.6 ms is the same world with descriptors only, _parts1_descriptors.json)
+    against 18.4 ms for 7 - so partitions are only what --parts asks for (they remain the one-GPU rehearsal of the
+    multi-GPU partitioning)."""
     return 1
 
 

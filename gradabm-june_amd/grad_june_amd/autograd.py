@@ -19,8 +19,9 @@ the two products of the forward's sparse passes that the adjoint needs, the per-
 factor (``gj_step_io.agent_sums``, one float per agent) and the per-venue sums ``cum`` (a clone, a few MB): 4 floats
 per agent and step, 160 MB per step of a 10 M-agent world out of 288 GB.  With ``GJ_BACKWARD_RECOMPUTE=1`` (or
 ``autograd.KEEP_FORWARD_SUMS = False``) a step keeps the pre-state only and its backward recomputes the two passes
-first (round 2's form: 3 floats per agent and step, a backward of 2.7x the forward instead of 1.8x).  Both give the
-same gradients bit for bit - the kept sums ARE what the recomputation produces (tests/test_gpu_autograd_kept.py).
+first (round 2's form: 3 floats per agent and step; C3 at 10 M agents: a backward of 1.42 ms = 2.5x the forward instead
+of 0.91 ms = 1.6x, profiles/r04_c3_10m_backward*.json).  Both give the same gradients bit for bit - the kept sums ARE
+what the recomputation produces (tests/test_gradients.py::test_kept_forward_sums_equal_the_recomputation).
 """
 from __future__ import annotations
 
