@@ -121,7 +121,8 @@ class TiledEdgeSet:
 
 
 WIDE_SEGMENTS = 6      # tiles a 64-edge chunk may span in the wide descriptor format
-WIDE_MIN_SHARE = 0.01  # a set whose chunks span > 2 tiles more often than this gets wide descriptors
+WIDE_MIN_SHARE = 0.05  # a set whose chunks span > 2 tiles more often than this gets wide descriptors (round 4: 0.01 until such
+                       # chunks had rows of explicit slots; clustered C3: 513 -> 508 us per step, profiles/r04_ab_wide_threshold_clustered.txt)
 EXPLICIT_MIN_SHARE = 0.02   # a set whose chunks span > 6 tiles (every lane walks the tile tables: a 5x cliff in phases A
                             # and D) more often than this carries the slot of every edge explicitly instead (slot_idx)
 

@@ -489,7 +489,7 @@ int gj_unpack_f32(int64_t n, const int32_t* index, const float* in, float* dst, 
 #define GJ_CC_BLOCKS 0       /* J: venue blocks                                                        */
 #define GJ_CC_SLOTS 1        /* length of the block-major arrays (every block padded to 8 slots)       */
 #define GJ_CC_CHUNKS 2       /* 64-edge chunks of the slice-major order                                */
-#define GJ_CC_MULTI 3        /* chunks that span more than two tiles (share > 1 %: use wide descriptors) */
+#define GJ_CC_MULTI 3        /* chunks that span more than two tiles (share > 5 %: use wide descriptors; else rows, gj_compile_multi_slots) */
 #define GJ_CC_OWNED_EDGES 4  /* edges whose agent is owned (< n_agents)                                */
 #define GJ_CC_MAX_DEGREE 5   /* largest number of edges of one owned agent                             */
 #define GJ_CC_ERROR 7
