@@ -91,6 +91,7 @@ def test_argument_errors_do_not_need_a_gpu(lib):
     assert lib.gj_pack_f32(0, None, None, None, None) == 0
     # graph compile: argument checks come before any device work
     assert lib.gj_compile_capacity(None, None, None, None) == -1
+    assert lib.gj_compile_multi_slots(None, None, 0, 0, None, 0, None, None, None, 0, None) == -1
     cs = N.CompileSet(None, None, None, 0, 0, 0, 0, 1, 64, 16, 16, 0)
     cap = [ctypes.c_int64(0) for _ in range(3)]
     assert lib.gj_compile_capacity(ctypes.byref(cs), *[ctypes.byref(c) for c in cap]) == 0
