@@ -376,6 +376,58 @@ def test_non_finite_transmissions_propagate(device, layout, poison):
     assert bool((torch.isnan(r) | ((r - ref_clean["not_infected_probs"][rest]).abs() <= 1e-5)).all())
 
 
+SAT_LAYOUTS = [LAYOUTS[i] for i in (0, 1, 2, 6, 7, 10)]
+SAT_IDS = [LAYOUT_IDS[i] for i in (0, 1, 2, 6, 7, 10)]
+
+
+@pytest.mark.parametrize("layout", SAT_LAYOUTS, ids=SAT_IDS)
+def test_saturation_on_the_reference_world_with_leisure_and_quarantine(device, layout):
+    """The reference's own 769-agent world - eleven networks, leisure tables (class weights of 0 for some ages), an active
+    quarantine policy in the recorded step - with a huge finite infectiousness (3e30) on three infected agents: every
+    co-attendee's probability equals the ORACLE's on the same state (no NaN anywhere): exp(-100) where the reference's
+    finite sums are clamped, the clean value where a zero factor (susceptibility 0, a quarantined agent's mask, a leisure
+    weight of 0) removes the term - which is why a saturated sum reads back a finite 1e30 and not an infinity."""
+    import gj_oracle as O
+    from grad_june_amd.engine import AgentBuffers
+
+    npz = L.load_npz("june769_hot.npz")
+    world, tables = L.world_from(npz), L.tables_from(npz)
+    A = world["n_agents"]
+    step = next(i for i in range(int(npz["n_steps"])) if int(npz[f"step{i}/has_quarantine"])
+                and not np.isnan(npz[f"step{i}/q_thresholds"]).all())
+    rec = L.step_record(npz, f"step{step}/")
+    sc = L.step_scalars(rec)
+    assert sc["quarantine_thresholds"] is not None and {"pub", "household"} <= set(sc["active"])
+    pre = L.pre_state(rec)
+    dirty = {k: v.clone() for k, v in pre.items()}
+    who = torch.nonzero(pre["is_infected"] > 0).reshape(-1)[:3]
+    assert len(who) == 3
+    dirty["max_infectiousness"][who] = 3e30
+    noise = torch.from_numpy(rec["exp_noise"])
+    ref = O.hot_path_step(world, dirty, exp_noise=noise, leisure_tables=tables, **sc)
+    clean = O.hot_path_step(world, pre, exp_noise=noise, leisure_tables=tables, **sc)
+    assert not bool(torch.isnan(ref["not_infected_probs"]).any())
+    hit = ref["not_infected_probs"] != clean["not_infected_probs"]
+    assert int(hit.sum()) >= 10 and bool((ref["not_infected_probs"][hit] <= 1e-30).any())
+    eng = engine_for(world, tables, device, layout)
+    st = L.device_state(dirty, device)
+    has_q = True
+    p = eng.params(now=sc["now"], delta_time=sc["delta_time"], day_type=sc["day_type"], active=sc["active"],
+                   betas=sc["betas"], has_quarantine=has_q, q_threshold=L.q_threshold(sc["quarantine_thresholds"]))
+    bufs = AgentBuffers(eng.plan, max_infectiousness=st["max_infectiousness"], shape=st["shape"], rate=st["rate"],
+                        shift=st["shift"], infection_time=st["infection_time"], is_infected=st["is_infected"],
+                        susceptibility=st["susceptibility"], transmission=st["transmission"],
+                        current_stage=st["current_stage"])
+    probs, new = torch.empty(A, device=device), torch.empty(A, device=device)
+    eng.step(bufs, p, eng.io(not_infected_probs=probs, new_infected=new, exp_noise=noise.to(device).contiguous()))
+    torch.cuda.synchronize()
+    got = probs.cpu()
+    assert not bool(torch.isnan(got).any())
+    assert np.abs(got.numpy() - ref["not_infected_probs"].numpy()).max() <= 1e-5
+    assert torch.equal(new.cpu() > 0.5, ref["new_infected"] > 0.5)
+    assert torch.equal(st["is_infected"].cpu(), ref["is_infected"])
+
+
 @pytest.mark.parametrize("term, saturates", [(1000.0, False), (10000.0, True)])
 def test_large_venue_sums_saturate_and_never_wrap(device, term, saturates):
     """20 000 attendees with a transmission of 1 000 / 10 000 each in ONE venue: 2e7 is summed exactly; 2e8 is beyond
