@@ -26,6 +26,8 @@ sys.path.insert(0, os.path.join(ROOT, "gradabm-june_amd"))
 import numpy as np
 import torch
 
+from grad_june_amd.synthetic import DEFAULT_AGENTS  # noqa: E402
+
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -34,7 +36,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--preset", default="c3", choices=["c2", "c3", "c5"])
+    ap.add_argument("--preset", default="c3", choices=["c2", "c3", "c5", "june"],
+                    help="c2 / c3 / c5: BASELINE.json configs[1] / [2] / [4] (c3 = the headline workload); june: a world with "
+                         "the membership structure of the reference's own graphs and its default eleven networks "
+                         "(synthetic.JUNE_WORLD; numpy generator, always on a map)")
     ap.add_argument("--agents", type=int, default=None)
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--geography", default="random", choices=["random", "clustered"],
@@ -303,7 +308,7 @@ def cached_world(args, progress, make_world):
         if args.generator == "torch":
             from grad_june_amd.synthetic import make_world_torch
 
-            n = args.agents or {"c2": 1_000_000, "c3": 10_000_000, "c5": 100_000_000}[args.preset]
+            n = args.agents or DEFAULT_AGENTS[args.preset]
             w = make_world_torch(args.preset, n, args.seed, torch.device("cuda", torch.cuda.current_device()),
                                  infected_fraction=args.infected, geography=args.geography)
             for es in w["edge_sets"].values():      # the partitioner and the locality order work on host arrays
@@ -569,7 +574,7 @@ def capture_validated(runner, dev, backend, dist):
 def main():
     args = parse()
     if args.generator == "auto":
-        n_default = {"c2": 1_000_000, "c3": 10_000_000, "c5": 100_000_000}[args.preset]
+        n_default = DEFAULT_AGENTS[args.preset]
         args.generator = "torch" if (args.agents or n_default) > 40_000_000 else "numpy"
     if args.only_headline:
         args.no_cpu_baseline, args.high_prevalence = True, 0.0
@@ -634,7 +639,7 @@ def main():
         from grad_june_amd.synthetic import iter_world, iter_world_torch
 
         if args.generator == "torch":
-            n = args.agents or {"c2": 1_000_000, "c3": 10_000_000, "c5": 100_000_000}[args.preset]
+            n = args.agents or DEFAULT_AGENTS[args.preset]
             pieces = iter_world_torch(args.preset, n, args.seed, dev, infected_fraction=args.infected,
                                       geography=args.geography, progress=progress)
         else:

@@ -401,6 +401,62 @@ class RankPartitioner:
             first[1:] = ra[1:] != ra[:-1]
             self.halo_lists[r].append((ra[first], rv[first]))
 
+    def _finish_torch(self, age, sex, slice_agents):
+        """``RankPartitioner.finish`` for parts cut out on a device: the extended indices are computed there, the edge lists
+        stay there; the halo list, age and sex of the extended range come to the host (small)."""
+        out = {}
+        for r in self.ranks:
+            a0, a1 = int(self.bounds[r]), int(self.bounds[r + 1])
+            n_local = a1 - a0
+            hl = self.halo_lists[r]
+            dev = None
+            for ls in self.local_sets[r].values():
+                if isinstance(ls["agent_global"], torch.Tensor):
+                    dev = ls["agent_global"].device
+            halo_t, owner_t = order_halo(hl, self.bounds, device=dev)
+            halo_global = halo_t.cpu().numpy()
+            halo_from = np.bincount(owner_t.cpu().numpy(), minlength=self.world_size).astype(np.int64)
+            halo_sorted, sorter_t = torch.sort(halo_t, stable=True)
+            sa = slice_agents
+            if sa is None:
+                _, sa = TL.choose_slices(n_local + len(halo_global) if os.environ.get("GJ_RANK_SLICES", "owned") == "ext"
+                                         else n_local)
+            n_local_pad = -(-n_local // sa) * sa if len(halo_global) else n_local
+            n_ext = n_local_pad + len(halo_global)
+            n_slices = max(1, -(-n_ext // sa))
+            edge_sets = {}
+            for name, ls in self.local_sets[r].items():
+                g = ls.pop("agent_global")
+                if not isinstance(g, torch.Tensor):
+                    g = torch.as_tensor(g, device=dev)
+                ext = g - a0
+                rem = (g < a0) | (g >= a1)
+                if len(halo_global):
+                    ext = torch.where(rem, n_local_pad + sorter_t[torch.searchsorted(halo_sorted, g).clamp_(max=halo_t.numel() - 1)],
+                                      ext)
+                elif bool(rem.any()):
+                    raise RuntimeError("a remote attendee without a halo list")
+                edge_sets[name] = {"agent": ext, "venue": ls["venue"], "people": ls["people"]}
+
+            def ext_attr(v):
+                if isinstance(v, torch.Tensor):
+                    o = torch.full((n_ext,), int(v[0]), dtype=v.dtype, device=v.device)   # (padding rows: agent 0's, as finish())
+                    o[:n_local] = v[a0:a1]
+                    if len(halo_global):
+                        o[n_local_pad:] = v[halo_t.to(v.device)]
+                    return o.cpu().numpy()
+                v = np.asarray(v)
+                o = np.full(n_ext, v[0], dtype=v.dtype)
+                o[:n_local] = v[a0:a1]
+                o[n_local_pad:] = v[halo_global]
+                return o
+
+            out[r] = RankWorld(r, self.world_size, self.bounds, n_local, sa, n_local_pad, n_ext, n_slices, halo_global,
+                               halo_from, ext_attr(age), ext_attr(sex), edge_sets, dict(self.modes),
+                               dict(self.venue_global[r]))
+        self.local_sets = self.halo_lists = self.venue_global = None      # consumed
+        return out
+
     def finish(self, age, sex, slice_agents: Optional[int] = None) -> Dict[int, "RankWorld"]:
         if any(isinstance(x[0], torch.Tensor) for hl in self.halo_lists.values() for x in hl) or any(
                 isinstance(ls["agent_global"], torch.Tensor) for sets in self.local_sets.values() for ls in sets.values()):
@@ -442,64 +498,6 @@ class RankPartitioner:
         return out
 
 
-def _finish_torch_impl(self, age, sex, slice_agents):
-    """``RankPartitioner.finish`` for parts cut out on a device: the extended indices are computed there, the edge lists
-    stay there; the halo list, age and sex of the extended range come to the host (small)."""
-    out = {}
-    for r in self.ranks:
-        a0, a1 = int(self.bounds[r]), int(self.bounds[r + 1])
-        n_local = a1 - a0
-        hl = self.halo_lists[r]
-        dev = None
-        for ls in self.local_sets[r].values():
-            if isinstance(ls["agent_global"], torch.Tensor):
-                dev = ls["agent_global"].device
-        halo_t, owner_t = order_halo(hl, self.bounds, device=dev)
-        halo_global = halo_t.cpu().numpy()
-        halo_from = np.bincount(owner_t.cpu().numpy(), minlength=self.world_size).astype(np.int64)
-        halo_sorted, sorter_t = torch.sort(halo_t, stable=True)
-        sa = slice_agents
-        if sa is None:
-            _, sa = TL.choose_slices(n_local + len(halo_global) if os.environ.get("GJ_RANK_SLICES", "owned") == "ext"
-                                     else n_local)
-        n_local_pad = -(-n_local // sa) * sa if len(halo_global) else n_local
-        n_ext = n_local_pad + len(halo_global)
-        n_slices = max(1, -(-n_ext // sa))
-        edge_sets = {}
-        for name, ls in self.local_sets[r].items():
-            g = ls.pop("agent_global")
-            if not isinstance(g, torch.Tensor):
-                g = torch.as_tensor(g, device=dev)
-            ext = g - a0
-            rem = (g < a0) | (g >= a1)
-            if len(halo_global):
-                ext = torch.where(rem, n_local_pad + sorter_t[torch.searchsorted(halo_sorted, g).clamp_(max=halo_t.numel() - 1)],
-                                  ext)
-            elif bool(rem.any()):
-                raise RuntimeError("a remote attendee without a halo list")
-            edge_sets[name] = {"agent": ext, "venue": ls["venue"], "people": ls["people"]}
-
-        def ext_attr(v):
-            if isinstance(v, torch.Tensor):
-                o = torch.full((n_ext,), int(v[0]), dtype=v.dtype, device=v.device)   # (padding rows: agent 0's, as finish())
-                o[:n_local] = v[a0:a1]
-                if len(halo_global):
-                    o[n_local_pad:] = v[halo_t.to(v.device)]
-                return o.cpu().numpy()
-            v = np.asarray(v)
-            o = np.full(n_ext, v[0], dtype=v.dtype)
-            o[:n_local] = v[a0:a1]
-            o[n_local_pad:] = v[halo_global]
-            return o
-
-        out[r] = RankWorld(r, self.world_size, self.bounds, n_local, sa, n_local_pad, n_ext, n_slices, halo_global,
-                           halo_from, ext_attr(age), ext_attr(sex), edge_sets, dict(self.modes),
-                           dict(self.venue_global[r]))
-    self.local_sets = self.halo_lists = self.venue_global = None      # consumed
-    return out
-
-
-RankPartitioner._finish_torch = _finish_torch_impl
 
 
 def build_rank_worlds(world: dict, world_size: int, ranks: Optional[Sequence[int]] = None,

@@ -11,6 +11,11 @@ Presets (BASELINE.json configs):
   "c3"  10 M agents, household, care_home, company, school, university + pub/grocery/gym on one
         shared leisure set; every edge set 15 M edges (90 M set-edges, 120 M network-edges)
   "c5"  power-law venue degrees (Zipf alpha=2 truncated to [1, 50 000])
+  "june"  a world with the MEMBERSHIP STRUCTURE of the reference's own graphs (june_world_loader: population/group_ids
+        holds at most one household, one primary activity - school, company, university or care home - per person;
+        leisure attaches everybody of the k nearest super areas to each super-area venue, leisure_loader.py:38-73) and
+        the reference's default eleven networks (configs/default.yaml:12-43), six of them on the one leisure set.
+        Always on a map (``geography`` is "clustered" whatever is asked): see ``JUNE_WORLD``.
 All presets scale with ``n_agents`` (edges per agent are kept).
 
 ``geography="random"`` (default; SURVEY 8d's specification): agents are dealt to venue slots uniformly at random - no
@@ -46,7 +51,22 @@ PRESETS = {
     },
 }
 
+#: the "june" preset: who attends what (by age, as JUNE's activity assignment does; the shares are stated, not fitted),
+#: venue sizes, and k of the leisure loader
+JUNE_WORLD = {
+    "household": ("poisson1", 1.4),                                       # every person lives in exactly one household
+    "school": (5, 18, 1.0, ("lognormal", 500.0, 0.5)),                    # ages [5, 18): everybody
+    "university": (18, 25, 0.3, ("lognormal", 2000.0, 0.5)),              # ages [18, 25): 30 %
+    "company": (18, 65, 0.7, ("lognormal", 20.0, 1.0)),                   # ages [18, 65): 70 % of those not at university
+    "care_home": (75, 100, 0.1, ("lognormal", 50.0, 0.5)),                # ages >= 75: 10 %
+    "k_leisure": 3,                                                       # GraphLoader(k_leisure): the k nearest super areas
+}
+
+DEFAULT_AGENTS = {"c2": 1_000_000, "c3": 10_000_000, "c5": 100_000_000, "june": 10_000_000}
+
 NETWORKS = {
+    "june": ["school", "university", "company", "care_home", "pub", "gym", "grocery", "visit", "care_visit", "cinema",
+             "household"],
     "c2": ["school", "company", "household"],
     "c3": ["school", "university", "company", "care_home", "pub", "gym", "grocery", "household"],
     "c5": ["school", "university", "company", "care_home", "pub", "gym", "grocery", "household"],
@@ -166,18 +186,27 @@ def _venue_sizes(rng, dist, n_edges: int) -> np.ndarray:
     return sizes[sizes > 0]
 
 
-def _edge_set(rng, n_agents: int, n_edges: int, dist, geo=None, mix=None) -> dict:
+def _edge_set(rng, n_agents: int, n_edges: int, dist, geo=None, mix=None, members=None) -> dict:
     """``geo`` (a ``super_area_map``) + ``mix`` (the set's entry of GEOGRAPHY): the clustered form - memberships are
-    dealt to the venue slots in the order of where they look for a venue, the slots lie along the curve."""
-    sizes = _venue_sizes(rng, dist, n_edges)
+    dealt to the venue slots in the order of where they look for a venue, the slots lie along the curve.
+    ``members``: the agent of every membership (the "june" preset: one per person who attends); default: every agent
+    floor(E / A) memberships, a random subset one more."""
+    if members is not None:
+        n_edges = len(members)
+    sizes = _venue_sizes(rng, dist, n_edges) if n_edges else np.zeros(0, dtype=np.int64)
     V = len(sizes)
     venue = np.repeat(np.arange(V, dtype=np.int64), sizes)
-    # every agent gets floor(E/A) memberships, a random subset one more
-    base, extra = divmod(n_edges, n_agents)
-    parts = [np.tile(np.arange(n_agents, dtype=np.int64), base)] if base else []
-    if extra:
-        parts.append(rng.choice(n_agents, extra, replace=False).astype(np.int64))
-    agent = np.concatenate(parts)
+    if members is not None:
+        agent = np.asarray(members, dtype=np.int64).copy()
+    else:
+        # every agent gets floor(E/A) memberships, a random subset one more
+        base, extra = divmod(n_edges, n_agents)
+        parts = [np.tile(np.arange(n_agents, dtype=np.int64), base)] if base else []
+        if extra:
+            parts.append(rng.choice(n_agents, extra, replace=False).astype(np.int64))
+        agent = np.concatenate(parts)
+    if n_edges == 0:
+        return {"agent": agent, "venue": venue, "people": np.zeros(max(V, 1), dtype=np.int64)}
     if geo is None:
         rng.shuffle(agent)
     else:
@@ -205,9 +234,12 @@ def iter_world(preset: str = "c3", n_agents: Optional[int] = None, seed: int = 1
         ("set", name, {"agent", "venue", "people"})     once per edge set
         ("state", {per-agent arrays})
     A consumer that keeps only its share of every set (distributed.RankPartitioner) never holds the whole COO."""
+    if preset == "june":
+        yield from _iter_june_world(10_000_000 if n_agents is None else n_agents, seed, infected_fraction, progress)
+        return
     spec = PRESETS[preset]
     if n_agents is None:
-        n_agents = {"c2": 1_000_000, "c3": 10_000_000, "c5": 100_000_000}[preset]
+        n_agents = DEFAULT_AGENTS[preset]
     if geography not in ("random", "clustered"):
         raise ValueError(f"geography {geography!r}: 'random' or 'clustered'")
     rng = np.random.default_rng(seed)
@@ -224,6 +256,68 @@ def iter_world(preset: str = "c3", n_agents: Optional[int] = None, seed: int = 1
             progress(f"generated edge set {name}: {len(es['agent'])} edges")
         yield ("set", name, es)
         del es
+    inf = (rng.random(A) < infected_fraction).astype(np.float32)
+    yield ("state", {
+        "max_infectiousness": rng.lognormal(0.0, 0.5, A).astype(np.float32),
+        "shape": rng.normal(1.56, 0.08, A).astype(np.float32),
+        "rate": rng.normal(0.53, 0.03, A).astype(np.float32),
+        "shift": rng.normal(-2.12, 0.1, A).astype(np.float32),
+        "is_infected": inf,
+        "susceptibility": (1.0 - inf).astype(np.float32),
+        "infection_time": (-10.0 * rng.random(A)).astype(np.float32) * inf,
+        "current_stage": np.where(inf > 0, rng.integers(2, 6, A), 1).astype(np.float32),
+    })
+
+
+def _iter_june_world(n_agents: int, seed: int, infected_fraction: float, progress=None):
+    """The "june" preset piece by piece (see ``JUNE_WORLD``)."""
+    rng = np.random.default_rng(seed)
+    A = int(n_agents)
+    geo = super_area_map(A)
+    age = rng.integers(0, 100, A, dtype=np.int64)
+    sex = rng.integers(0, 2, A, dtype=np.int64)
+    yield ("header", {"preset": "june", "n_agents": A, "age": age, "sex": sex, "networks": list(NETWORKS["june"]),
+                      "n_sets": 6, "geography": "clustered"})
+    everyone = np.arange(A, dtype=np.int64)
+    es = _edge_set(rng, A, A, JUNE_WORLD["household"], geo, None, members=everyone)
+    yield ("set", "household", es)
+    taken = np.zeros(A, dtype=bool)                    # one primary activity per person (population/group_ids)
+    for name in ("care_home", "school", "university", "company"):
+        lo, hi, share, dist = JUNE_WORLD[name]
+        who = (age >= lo) & (age < hi) & ~taken
+        if share < 1.0:
+            who &= rng.random(A) < share
+        taken |= who
+        es = _edge_set(rng, A, 0, dist, geo, GEOGRAPHY[name], members=everyone[who])
+        if progress:
+            progress(f"generated edge set {name}: {len(es['agent'])} edges")
+        yield ("set", name, es)
+        del es
+    # leisure_loader.py:38-73: venue = super area, attended by everybody who lives in one of its k nearest super areas
+    # (itself first); k nearest = itself and the first k - 1 surrounding cells that exist
+    k, sa, n_sa = JUNE_WORLD["k_leisure"], geo["sa_agents"], geo["n_sa"]
+    near = np.concatenate([np.arange(n_sa)[:, None], geo["nb"][:, :k - 1]], axis=1)            # [n_sa, k] (-1: none)
+    home = everyone // sa
+    agents, venues = [], []
+    for c in range(k):
+        src = near[:, c]                               # venue v is attended by the residents of super area near[v, c]
+        ok = src >= 0
+        v_of_src = np.flatnonzero(ok)
+        # residents of super area s attend every venue v with near[v, c] == s
+        order = np.argsort(src[ok], kind="stable")
+        s_sorted, v_sorted = src[ok][order], v_of_src[order]
+        first = np.searchsorted(s_sorted, home, side="left")
+        last = np.searchsorted(s_sorted, home, side="right")
+        cnt = last - first
+        a_rep = np.repeat(everyone, cnt)
+        offs = np.arange(len(a_rep)) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+        agents.append(a_rep)
+        venues.append(v_sorted[np.repeat(first, cnt) + offs])
+    agent, venue = np.concatenate(agents), np.concatenate(venues)
+    perm = rng.permutation(len(agent))
+    agent, venue = agent[perm], venue[perm]
+    yield ("set", "leisure", {"agent": agent, "venue": venue, "people": np.bincount(venue, minlength=n_sa).astype(np.int64)})
+    del agent, venue
     inf = (rng.random(A) < infected_fraction).astype(np.float32)
     yield ("state", {
         "max_infectiousness": rng.lognormal(0.0, 0.5, A).astype(np.float32),
@@ -303,6 +397,8 @@ def iter_world_torch(preset: str, n_agents: int, seed: int, device, infected_fra
 
     if geography not in ("random", "clustered"):
         raise ValueError(f"geography {geography!r}: 'random' or 'clustered'")
+    if preset not in PRESETS:
+        raise ValueError(f"preset {preset!r} is drawn by the numpy generator only (iter_world)")
     dev = torch.device(device)
     g = torch.Generator(device=dev)
     g.manual_seed(seed)

@@ -41,9 +41,11 @@ def test_more_ranks_than_gpus_is_refused_before_anything_starts():
 
 
 @pytest.mark.gpu
-def test_bench_starts_its_own_ranks(device):
+@pytest.mark.parametrize("geography", ["random", "clustered"])
+def test_bench_starts_its_own_ranks(device, geography):
+    """(both kinds of world: SURVEY 8d's uniformly random one and the one with a geography, synthetic.GEOGRAPHY)"""
     r = _run("--gpus", "2", "--backend", "gloo", "--agents", "400000", "--steps", "5", "--warmup", "2",
-             "--repeats", "2")
+             "--repeats", "2", "--geography", geography)
     assert r.returncode == 0, r.stderr[-4000:]
     j = _one_json_line(r.stdout)
     assert j["n_gpus"] == 2 and j["steps"] == 5 and j["warmup"] == 2 and j["scaling"] == "strong"
@@ -53,9 +55,13 @@ def test_bench_starts_its_own_ranks(device):
     assert j["host_us_per_step"] > 0 and j["exposed_collective_ms_per_step"] >= 0
     assert {"halo_all_to_all", "partial_all_reduce"} <= set(j["kernel_ms"])
     assert j["exchange"]["halo_agents_rank0"] > 0 and j["exchange"]["partial_sum_floats"] > 0
+    assert j["config"]["geography"] == geography and j["exchange"]["venue_classes"]["household"]["venues"] > 100_000
+    if geography == "clustered":         # households of neighbours: all but the ones on the one rank boundary are local
+        hh = j["exchange"]["venue_classes"]["household"]
+        assert hh["local"] >= hh["venues"] - 5 and j["exchange"]["halo_agents_rank0"] < 60_000
     # the two ranks together computed what one GPU computes: same seed, same world, Philox keyed by global agent id
     r1 = _run("--gpus", "1", "--agents", "400000", "--steps", "5", "--warmup", "2", "--repeats", "2",
-              "--no-cpu-baseline", "--tune", "off")
+              "--no-cpu-baseline", "--tune", "off", "--geography", geography)
     assert r1.returncode == 0, r1.stderr[-4000:]
     j1 = _one_json_line(r1.stdout)
     # both runs make warm-up + repeats x steps (+ the sequential bracketed pass of N > 1) steps: compare equal step counts

@@ -25,7 +25,9 @@ from grad_june_amd.synthetic import edge_set_of, make_world
 pytestmark = pytest.mark.gpu
 
 # c5 = power-law venue degrees (Zipf alpha 2, venues up to 50 000 attendees)
-CASES = [("c2", None), ("c3", None), ("c5", 1_000_000)]
+# june = the membership structure of the reference's own graphs, its default eleven networks (six on the leisure set,
+# care_visit with its asymmetric age > 75 weight), every person in exactly one household (the run form takes the whole set)
+CASES = [("c2", None), ("c3", None), ("c5", 1_000_000), ("june", 2_000_000)]
 
 _WORLDS = {}
 
@@ -63,6 +65,8 @@ def fp64_device_reference(world, r, betas, device):
         sums = torch.zeros(len(es["people"]), dtype=torch.float64, device=device).index_add_(0, venue, xs)
         cum[name] = float(np.float32(betas[name])) * pc * sums
         per_agent = torch.zeros(A, dtype=torch.float64, device=device).index_add_(0, agent, cum[name][venue])
+        if w is not None and name == "care_visit":          # leisure_network.py:107-120: susceptibility also x (age > 75)
+            w = w * ((cls % 100) > 75).double()
         acc += per_agent if w is None else w * per_agent
     return cum, susc * acc
 

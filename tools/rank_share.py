@@ -48,7 +48,7 @@ def main():
     import bench as B
     from grad_june_amd import distributed as D
     from grad_june_amd.distributed import DistributedHotPath, stream_rank_share
-    from grad_june_amd.synthetic import iter_world, iter_world_torch
+    from grad_june_amd.synthetic import DEFAULT_AGENTS, iter_world, iter_world_torch
 
     D.EXCHANGE_RULE = a.exchange_rule
     D.HALO_ORDER = a.halo_order
@@ -60,7 +60,7 @@ def main():
         print(f"[rank_share {time.time() - t0:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
     if a.generator == "torch":
-        n = a.agents or {"c2": 1_000_000, "c3": 10_000_000, "c5": 100_000_000}[a.preset]
+        n = a.agents or DEFAULT_AGENTS[a.preset]
         pieces = iter_world_torch(a.preset, n, a.seed, dev, infected_fraction=0.01, geography=a.geography, progress=progress)
     else:
         pieces = iter_world(a.preset, n_agents=a.agents, seed=a.seed, infected_fraction=0.01, progress=progress,
