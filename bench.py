@@ -96,6 +96,8 @@ def parse():
     ap.add_argument("--backward", action="store_true",
                     help="row f3: time forward and backward of a T-step differentiable run (the eight log_beta as "
                          "nn.Parameter, loss = cases of the last step) instead of the forward-only hot path")
+    ap.add_argument("--multi-net-block-div", type=int, default=None,
+                    help="experiment: edges per venue block of the sets that carry several networks = eb_target / this")
     ap.add_argument("--wide-min-share", type=float, default=None,
                     help="experiment: share of a set's chunks spanning more than two tiles above which it gets the 8-word "
                          "descriptors (tiling.WIDE_MIN_SHARE, default 0.01); below it such chunks take a row of explicit slots")
@@ -625,6 +627,8 @@ def main():
         if rank == 0:
             print(f"[bench {time.time() - t0:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
+    if args.multi_net_block_div:
+        os.environ["GJ_MULTI_NET_BLOCK_DIV"] = str(args.multi_net_block_div)
     if args.wide_min_share is not None:
         from grad_june_amd import tiling as _TL
 

@@ -293,7 +293,7 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
                  sv_max: int = TL.SV_MAX, eb_target: Optional[int] = None, slices=None, tile_pad: int = 1,
                  nets_per_set: Optional[Dict[str, int]] = None, progress=None,
                  desc_wide: Optional[bool] = None, device=None, direct=None, runs=None, presum=None,
-                 desc_explicit: Optional[bool] = None) -> HostPlan:
+                 desc_explicit: Optional[bool] = None, multi_net_block_div: Optional[int] = None) -> HostPlan:
     """edge_sets: {name: {"agent": i64[E], "venue": i64[E], "people": [V]}} (insertion order = set ids).
 
     layout: "csr" (deterministic CSR kernels), "tiled" (LDS-tiled fast path) or "both".
@@ -316,6 +316,9 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
     atomics it takes out of the venue launch (115 M per step) cost the same there, and its own launch pays a memory
     round trip per batch (one workgroup per CU: the tables fill the LDS).  A second attempt in the same round (batches
     software-pipelined, a parallel table reduction) brought it to 8 % slower: still opt-in.
+    multi_net_block_div: the edges per venue block of a set that carries several networks (the leisure sets) are
+    ``eb_target`` divided by this (None: GJ_MULTI_NET_BLOCK_DIV or 1): a venue-block workgroup sums every slot once per
+    network, so such a block is nets times as heavy as its edge count says.
     tile_pad: experiment of the numpy compile (tiling.build_tiled): tiles padded to a multiple of this many positions in
     both orders (16 = whole 64-byte sectors of the workspace); measured -1 % on C3, not adopted, not in the device compile.
     """
@@ -329,6 +332,8 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
     S, SA = slices if slices is not None else TL.choose_slices(n_ext)
     if eb_target is None:
         eb_target = TL.choose_block_edges(S)
+    if multi_net_block_div is None:
+        multi_net_block_div = int(os.environ.get("GJ_MULTI_NET_BLOCK_DIV", "1"))
     if want_tiled and n_ext != n_agents and (-(-n_agents // SA)) * SA > n_ext:
         raise ValueError("halo agents must start on a slice boundary (pad the owned range to a multiple of SA)")
     sets, all_blocks, all_long, work = [], [], [], []
@@ -354,17 +359,18 @@ def compile_plan(n_agents: int, edge_sets: Dict[str, dict], age=None, sex=None,
                 rf, es_t = _split_runs(name, es, n_agents, hs.n_venues, SA, device, forced_run)
             if device is not None and tile_pad > 1:
                 raise NotImplementedError("tile_pad is an experiment of the numpy compile (compile_plan without device=)")
+            eb_set = eb_target if k <= 1 else max(8192, eb_target // max(1, multi_net_block_div))
             if device is not None:
                 from .tiling_native import build_tiled_native
 
                 hs.tiled = build_tiled_native(name, es_t["agent"], es_t["venue"], hs.n_venues, hs.v_pcontact, S, SA,
                                               agent_class=use_cls, sv_max=max(16, sv_max // max(1, k)),
-                                              eb_target=eb_target, wide=desc_wide, device=device, n_ext_agents=n_ext,
+                                              eb_target=eb_set, wide=desc_wide, device=device, n_ext_agents=n_ext,
                                               explicit=desc_explicit)
             else:
                 hs.tiled = TL.build_tiled(name, es_t["agent"], es_t["venue"], hs.n_venues, hs.v_pcontact, S, SA,
                                           agent_class=use_cls, sv_max=max(16, sv_max // max(1, k)),
-                                          eb_target=eb_target, wide=desc_wide, explicit=desc_explicit,
+                                          eb_target=eb_set, wide=desc_wide, explicit=desc_explicit,
                                           tile_pad=tile_pad)
             t = hs.tiled
             if rf is not None:
