@@ -709,6 +709,15 @@ class DistributedHotPath:
         plan_kw = dict(plan_kw or {})
         if os.environ.get("GJ_RANK_SLICES", "owned") != "ext":     # venue blocks for the owned slices' tiles (see finish())
             plan_kw.setdefault("eb_target", TL.choose_block_edges(max(1, -(-rw.n_local // rw.slice_agents))))
+        # A rank's share has few venue blocks (C3 / 8: ~200 for 256 CUs), and a block of a set that carries several
+        # networks sums every slot once per network: such sets get blocks of a sixth of the edges while the share has
+        # fewer than two blocks per CU (measured, tools/rank_share.py: C3 / 8 clustered 0.129 -> 0.111 ms, random 0.122 ->
+        # 0.118, the june preset / 8 0.160 -> 0.121; on a whole GPU smaller blocks LOSE: profiles/r04_ab_multi_net_block_div_*)
+        local_edges = sum(int(es["agent"].numel() if hasattr(es["agent"], "numel") else len(es["agent"]))
+                          for es in rw.edge_sets.values())
+        eb_rank = plan_kw.get("eb_target") or TL.choose_block_edges(max(1, -(-rw.n_ext // rw.slice_agents)))
+        if "GJ_MULTI_NET_BLOCK_DIV" not in os.environ and local_edges < 512 * eb_rank:
+            plan_kw.setdefault("multi_net_block_div", 6)
         leisure = tuple(s for s in rw.edge_sets if s.split(SPLIT_SUFFIX)[0] == "leisure")
         host = compile_plan(rw.n_local, rw.edge_sets, age=rw.age, sex=rw.sex, n_ext_agents=rw.n_ext,
                             layout="tiled", slices=(rw.n_slices, rw.slice_agents), progress=progress,

@@ -30,4 +30,6 @@ run c3_10m_clustered_rank_share_of_2          --of 2 --geography clustered --gen
 run c5_100m_random_rank_share_of_8            --preset c5 --of 8 --generator torch
 run c5_100m_random_rank_share_of_8_halo_by_id --preset c5 --of 8 --generator torch --halo-order id
 run c5_100m_clustered_rank_share_of_8         --preset c5 --of 8 --generator torch --geography clustered
+# the june preset (the reference's membership structure, eleven networks) / 8
+run june_10m_rank_share_of_8                  --preset june --of 8
 echo "== done" | tee -a "$out/log.txt"
