@@ -201,7 +201,10 @@ class SingleGpuHotPath:
 GEOMETRY_CANDIDATES = ({}, {"eb_target": 131072, "sv_max": 16384}, {"eb_target": 65536, "sv_max": 16384},
                        {"eb_target": 131072, "sv_max": 16384, "slice_agents": 2048},
                        {"eb_target": 32768, "sv_max": 16384, "slice_agents": 2048},
-                       {"eb_target": 131072, "sv_max": 16384, "direct": False})
+                       {"eb_target": 131072, "sv_max": 16384, "direct": False},
+                       # (round 4) more, smaller venue blocks: a world of this size has ~1 block per CU otherwise
+                       {"eb_target": 32768, "sv_max": 16384}, {"eb_target": 32768, "sv_max": 8192},
+                       {"eb_target": 16384, "sv_max": 4096})
 
 
 def tune_geometry(world: dict, specs, betas, device, candidates=GEOMETRY_CANDIDATES, progress=None, **kw):
