@@ -49,7 +49,8 @@ def _runs_option():
     if RUNS in ("off", "0", ""):
         return False
     return tuple(x for x in (RUNS if isinstance(RUNS, str) else ",".join(RUNS)).split(",") if x)
-TUNE_CANDIDATES = ({}, {"eb_target": 131072, "sv_max": 16384}, {"eb_target": 65536, "sv_max": 16384})
+TUNE_CANDIDATES = ({}, {"eb_target": 131072, "sv_max": 16384}, {"eb_target": 65536, "sv_max": 16384},
+                   {"eb_target": 32768, "sv_max": 16384})      # (round 4: a 1 M-agent world has ~1 venue block per CU otherwise)
 TUNE_MIN_EDGES, TUNE_MAX_EDGES = 200_000, 40_000_000
 N_MAX_TUNE_NETS = 16
 

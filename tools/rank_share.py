@@ -76,6 +76,10 @@ def main():
                             rank_world=rw, total_edges=share["total_edges"], device_compile=True,
                             plan_kw={k: v for k, v in (("eb_target", a.eb_target), ("sv_max", a.sv_max)) if v})
     t_setup = time.time() - t0
+    stamps = None
+    if os.environ.get("GJ_DIAG_STAMPS"):       # a library built with -DGJ_DIAG_STAMPS (tools/ab.py --build-only stamps:GJ_DIAG_STAMPS=1):
+        stamps = torch.zeros(rw.n_local, dtype=torch.float32, device=dev)      # phase D writes cycle stamps per workgroup
+        hp.io = hp.engine.io(new_infected=hp.new_infected, trans_susc=stamps)
     inf0 = float(hp.state["is_infected"].clamp(max=1).mean())
     for _ in range(a.warmup):
         hp.step()
@@ -102,6 +106,14 @@ def main():
         "setup_s": {"stream_and_partition": t_part, "total": t_setup},
         "host_peak_rss_mb": resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0,
     }
+    if stamps is not None:
+        import numpy as np
+
+        sa = int(rw.slice_agents)
+        st = stamps[: (rw.n_local // sa) * sa].view(-1, sa)[:, :16].cpu().numpy()
+        out["phase_d_stamps_mean_cycles"] = [float(x) for x in np.round(st.mean(0))]
+        out["phase_d_stamps_legend"] = ("slot 1 after the tiled gather, 2 sums in registers, 8+2t / 9+2t direct item t begins / "
+                                        "ends, 3 after the direct sets, 4 ts in LDS, 6 after the epilogue loop, 5 end")
     print(json.dumps(out))
 
 
