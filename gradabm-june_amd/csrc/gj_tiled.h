@@ -769,14 +769,44 @@ __global__ __launch_bounds__(kTileThreads, GJ_VENUE_WAVES_PER_SIMD) void k_tile_
       }
     };
 #endif
+#ifndef GJ_WAVE_RUNS
+#define GJ_WAVE_RUNS 1
+#endif
+    // 512 consecutive slots of ONE venue (a wave's 64 groups): the slots' fixed-point terms are added up per lane, then
+    // across the wave (integer adds: the same sum, bit for bit), and ONE lane adds the total - instead of 512 LDS
+    // atomics per network of which 448 go to scratch sums and 64 to one address.  What makes the case common: venues far
+    // larger than a tile's width - the leisure venues of a JUNE world (every resident of the k nearest super areas:
+    // 15 000 attendees, six networks per slot), the giant venues of BASELINE config 5, schools on a world with a geography.
+    auto wave_sum = [&](const float (&xl)[8], int target) -> bool {      // false: a term outside the window - generic path
+      uint32_t m = 0u;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) m = max(m, __float_as_uint(xl[q]) & 0x7FFFFFFFu);
+      if (__builtin_amdgcn_ballot_w64(m > T.term_limit) != 0ull) return false;
+      fx_t s = 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s += to_fx<kFxVenue>(xl[q]);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, kWave);
+      if ((tid & (kWave - 1)) == 0) atomicAdd(&sums[target], s);
+      return true;
+    };
     auto add_group = [&](const uint4 raw, const float4 xa, const float4 xb, const uint2 craw) {
       const Slots8 L{{raw.x, raw.y, raw.z, raw.w}};
       const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
       int lv[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) lv[q] = L.lv(q);
+      bool one_venue = false;
+#if GJ_WAVE_RUNS
+      {
+        // (raw.x == raw.y == raw.z == raw.w and both halves of a word equal: all eight local venues are the same)
+        const bool mine = (raw.x == raw.y) && (raw.y == raw.z) && (raw.z == raw.w) && ((raw.x >> 16) == (raw.x & 0xFFFFu)) &&
+                          (lv[0] != 0xFFFF) && (lv[0] == __builtin_amdgcn_readfirstlane(lv[0]));
+        one_venue = __builtin_amdgcn_ballot_w64(mine) == ~0ull;         // every lane of the wave, all of them active
+      }
+#endif
       if (!T.leisure) {
-        run_sums(lv, x, 0);
+        if (!(one_venue && wave_sum(x, lv[0]))) run_sums(lv, x, 0);
       } else {
         const uint32_t cw[2] = {craw.x, craw.y};
         for (int k = 0; k < nk; ++k) {
@@ -784,7 +814,7 @@ __global__ __launch_bounds__(kTileThreads, GJ_VENUE_WAVES_PER_SIMD) void k_tile_
           float xl[8];
 #pragma unroll
           for (int q = 0; q < 8; ++q) xl[q] = tk[(cw[q >> 2] >> ((q & 3) * 8)) & 0xFF] * x[q];
-          run_sums(lv, xl, k * nv);
+          if (!(one_venue && wave_sum(xl, k * nv + lv[0]))) run_sums(lv, xl, k * nv);
         }
       }
     };
