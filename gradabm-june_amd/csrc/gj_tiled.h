@@ -74,6 +74,7 @@ __device__ __forceinline__ float from_fx(fx_t v) {
 // the add's own block, behind an s_waitcnt of its own - a batch of eight loads then costs eight round trips, not one.
 constexpr float kSaturated = 1.0e30f;
 __device__ __forceinline__ void fx_flag(uint32_t* flags, int words, int i, float x) {
+  // (only ever called with |x| beyond the window or x not a number: a zero would raise both flags)
   const uint32_t bit = 1u << (i & 31);
   if (!(x < 0.0f)) atomicOr(&flags[i >> 5], bit);             // positive, +inf or NaN
   if (!(x > 0.0f)) atomicOr(&flags[words + (i >> 5)], bit);   // negative, -inf or NaN
