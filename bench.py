@@ -120,7 +120,7 @@ def parse():
                     help="second, short timed region on the same world re-seeded at this infected fraction (0 = skip): "
                          "k_transmission skips uninfected agents' parameter lines and phase D rewrites state only where it "
                          "changes, so the headline state (1 %% infected, SURVEY 8d) is the cheap end")
-    ap.add_argument("--work-order", default=None, choices=["heavy", "light", "mixed", "set"],
+    ap.add_argument("--work-order", default=None, choices=["heavy", "light", "mixed", "set", "stagger", "stagger40", "stagger64", "stagger100", "stagger128"],
                     help="experiments: order of the venue launch's (set, block) work list (default: heaviest first)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--only-headline", action="store_true",

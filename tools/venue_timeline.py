@@ -34,6 +34,7 @@ def main():
 
     class Args:
         preset, agents, seed, infected, edge_mult, world_cache, generator = "c3", None, 1234, 0.01, 1.0, a.world_cache, "numpy"
+        geography = "random"
 
     world = reorder_agents(B.cached_world(Args, lambda m: print(m, file=sys.stderr), make_world), by="household")
     dev = torch.device("cuda:0")
