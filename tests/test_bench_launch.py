@@ -119,3 +119,22 @@ def test_c5_ranks_draw_and_cut_their_share_on_the_device(device):
     j1 = _one_json_line(r1.stdout)
     a, b = j["state_checksum"]["infected_after_first_region"], j1["state_checksum"]["infected_after_first_region"]
     assert b > 200_000 and abs(a - b) <= max(5.0, 1e-4 * b), (a, b)
+
+
+@pytest.mark.gpu
+def test_the_reference_shaped_world_across_two_ranks(device):
+    """``--preset june``: the membership structure of the reference's own graphs with its default ELEVEN networks (six on
+    the one leisure set; the library holds 16 networks, so not every set that has both venue classes can be cut in two -
+    the partitioner says which run whole) on two gloo ranks against one GPU: the same number of infected."""
+    common = ("--preset", "june", "--agents", "400000", "--steps", "6", "--warmup", "2", "--repeats", "1", "--infected", "0.05")
+    r = _run("--gpus", "2", "--backend", "gloo", *common)
+    assert r.returncode == 0, r.stderr[-4000:]
+    j = _one_json_line(r.stdout)
+    assert j["n_gpus"] == 2 and "11 infection networks" in j["config"]["workload"]
+    hh = j["exchange"]["venue_classes"]["household"]
+    assert hh["local"] >= hh["venues"] - 5                         # every person in one household of neighbours
+    r1 = _run("--gpus", "1", *common, "--only-headline", "--tune", "off")
+    assert r1.returncode == 0, r1.stderr[-4000:]
+    j1 = _one_json_line(r1.stdout)
+    a, b = j["state_checksum"]["infected_after_first_region"], j1["state_checksum"]["infected_after_first_region"]
+    assert b > 20_000 and abs(a - b) <= max(3.0, 1e-4 * b), (a, b)
