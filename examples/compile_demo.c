@@ -43,7 +43,7 @@ int main(void) {
   hipStream_t stream;
   CHECK_HIP(hipStreamCreate(&stream));
 
-  gj_compile_set cs = {d_agent, d_venue, NULL, E, A, A, V, S, SA, 1024 /* venues per block */, 16384 /* edges per block */, 0};
+  gj_compile_set cs = {d_agent, d_venue, NULL, E, A, A, V, S, SA, 1024 /* venues per block */, 2048 /* edges per block: tiles of ~40 edges, so that some 64-edge chunks span more than two tiles */, 0};
   int64_t blk_cap = 0, slots_cap = 0, chunks_cap = 0, ws_bytes = 0;
   CHECK_GJ(gj_compile_capacity(&cs, &blk_cap, NULL, NULL));
   CHECK_GJ(gj_compile_workspace_bytes(&cs, &ws_bytes));
@@ -108,6 +108,45 @@ int main(void) {
   int64_t max_deg = 0;
   for (int64_t e = 0; e < E; ++e) adeg[agent[e]]--;
   for (int64_t a = 0; a < A; ++a) CHECK(adeg[a] == 0);
+
+  /* the chunks a 4-word descriptor cannot express (they span more than two tiles) get a row of 64 explicit slots each
+   * (gj_tiled_set.multi_slots, ABI 6); every row is checked against the tile tables here */
+  const int32_t n_multi = c[GJ_CC_MULTI];
+  if (n_multi > 0) {
+    int32_t* multi_slots = (int32_t*)dmalloc((size_t)n_multi * 64 * 4);
+    const int64_t ws2_bytes = 2 * (4 * ((int64_t)n_chunks + 1) + 256) + (1 << 20);
+    void* ws2 = dmalloc((size_t)ws2_bytes);
+    CHECK(multi_slots && ws2);
+    CHECK_GJ(gj_compile_multi_slots(&cs, &out, n_chunks, 0, out.chunk_desc, n_multi, multi_slots, counts, ws2, ws2_bytes, stream));
+    CHECK_HIP(hipStreamSynchronize(stream));
+    int32_t* h_desc = (int32_t*)malloc((size_t)n_chunks * 16);
+    int32_t* h_rows = (int32_t*)malloc((size_t)n_multi * 64 * 4);
+    int32_t* h_jpos = (int32_t*)malloc((int64_t)S * J * 4);
+    int32_t* h_cptr = (int32_t*)malloc((S + 1) * 4);
+    CHECK_HIP(hipMemcpy(h_desc, out.chunk_desc, (size_t)n_chunks * 16, hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(h_rows, multi_slots, (size_t)n_multi * 64 * 4, hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(h_jpos, out.tile_jpos, (int64_t)S * J * 4, hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(h_cptr, out.chunk_ptr, (S + 1) * 4, hipMemcpyDeviceToHost));
+    int32_t seen = 0;
+    for (int32_t s = 0; s < S; ++s)
+      for (int32_t ch = h_cptr[s]; ch < h_cptr[s + 1]; ++ch) {
+        if (((uint32_t)h_desc[4 * ch + 2] >> 16) == 0) continue;
+        const int32_t row = h_desc[4 * ch + 3];                 /* the j0 field of such a chunk: its row */
+        CHECK(row == seen);                                    /* rows are in chunk order */
+        ++seen;
+        const int64_t first = h_sptr[(int64_t)s * J] + 64 * (int64_t)(ch - h_cptr[s]), seg_end = h_sptr[(int64_t)(s + 1) * J];
+        int64_t t = (int64_t)s * J;
+        for (int lane = 0; lane < 64; ++lane) {
+          const int64_t pos = first + lane;
+          if (pos >= seg_end) { CHECK(h_rows[64 * row + lane] == 0); continue; }
+          while (h_sptr[t + 1] <= pos) ++t;                    /* the tile that holds the position */
+          CHECK(h_rows[64 * row + lane] == h_jpos[t] + (int32_t)(pos - h_sptr[t]));
+        }
+      }
+    CHECK(seen == n_multi);
+    printf("multi chunks: %d rows of explicit slots, every slot = tile_jpos + offset\n", n_multi);
+    free(h_desc); free(h_rows); free(h_jpos); free(h_cptr);
+  }
 
   /* the ELL rows of the direct form of pass 2 */
   int32_t* degree = (int32_t*)dmalloc((A + 1) * 4);
