@@ -575,6 +575,8 @@ def capture_validated(runner, dev, backend, dist):
 
 def main():
     args = parse()
+    if args.preset == "june":
+        args.geography = "clustered"          # (the preset is always drawn on a map; the JSON says so)
     if args.generator == "auto":
         n_default = DEFAULT_AGENTS[args.preset]
         args.generator = "torch" if (args.agents or n_default) > 40_000_000 else "numpy"
