@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--sv-max", type=int, default=None)
     ap.add_argument("--slice-agents", type=int, default=None, help="agents per slice (default: sized for the owned agents)")
     ap.add_argument("--geography", default="random", choices=["random", "clustered"])
+    ap.add_argument("--graph", type=int, default=1, help="also replay the step from a hipGraph (0: eager launches only)")
     ap.add_argument("--generator", default="numpy", choices=["numpy", "torch"],
                     help="torch: the world is drawn on the device and the share cut out there (synthetic.iter_world_torch)")
     ap.add_argument("--exchange-rule", default="venue", choices=["venue", "set"])
@@ -93,6 +94,19 @@ def main():
     for _ in range(max(4, a.steps // 4)):
         hp.step(timed=True)
     torch.cuda.synchronize()
+    graph_ms = None
+    if a.graph:                                 # the same launches replayed from a hipGraph (DistributedHotPath.capture):
+        hp.capture()                            # what the production loop does; takes the host's launch cost out of the figure
+        for _ in range(a.warmup):
+            hp.step()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(a.steps):
+            hp.step()
+        e1.record()
+        torch.cuda.synchronize()
+        graph_ms = e0.elapsed_time(e1) / a.steps
     out = {
         "what": f"rank {a.rank} of {a.of}: kernels of one step on its share, collectives not executed",
         "geometry": {"slice_agents": int(rw.slice_agents), "n_slices": int(rw.n_slices), "eb_target": a.eb_target, "sv_max": a.sv_max},
@@ -101,7 +115,7 @@ def main():
         "local_set_edges": {k: int(len(v["agent"])) for k, v in rw.edge_sets.items()},
         "halo_all_to_all_bytes_in_per_step": 4 * int(rw.n_halo),
         "partial_sum_all_reduce_bytes_per_step": 4 * int(hp.flat_cum.numel()) if hp.flat_cum is not None else 0,
-        "kernel_ms_per_step": ms, "kernel_ms": hp.kernel_ms(),
+        "kernel_ms_per_step": ms, "graph_replay_ms_per_step": graph_ms, "kernel_ms": hp.kernel_ms(),
         "infected_fraction": {"start": inf0, "end": float(hp.state["is_infected"].clamp(max=1).mean())},
         "setup_s": {"stream_and_partition": t_part, "total": t_setup},
         "host_peak_rss_mb": resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0,

@@ -31,7 +31,7 @@ def main():
     from grad_june_amd.synthetic import make_world, reorder_agents
 
     class Args:
-        preset, agents, seed, infected, edge_mult, world_cache, generator = "c3", None, 1234, 0.01, 1.0, a.world_cache, "numpy"
+        preset, agents, seed, infected, edge_mult, world_cache, generator, geography = "c3", None, 1234, 0.01, 1.0, a.world_cache, "numpy", "random"
 
     world = reorder_agents(B.cached_world(Args, lambda m: print(m, file=sys.stderr), make_world), by="household")
     dev = torch.device("cuda:0")
@@ -52,6 +52,27 @@ def main():
         e.step_phase(r.bufs, p_all, r.io, 3)
         r.t += 1
 
+    streams = [torch.cuda.Stream(device=dev) for _ in groups[1:]]
+    cache = {}
+
+    def forked_step():
+        """The groups side by side: group 0 on the current stream, the others on streams of their own (fork after the
+        transmission launch, join in front of phase D) - one group's tail under another's ramp."""
+        e = r.engine
+        main = torch.cuda.current_stream(dev)
+        p_all = params(r.networks)
+        e.step_phase(r.bufs, p_all, r.io, 0)
+        ps = [params([n for n in r.networks if n in g]) for g in groups]
+        for st, p in zip(streams, ps[1:]):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                e.step_phase(r.bufs, p, r.io, 8)
+        e.step_phase(r.bufs, ps[0], r.io, 8)
+        for st in streams:
+            main.wait_stream(st)
+        e.step_phase(r.bufs, p_all, r.io, 3)
+        r.t += 1
+
     def timed(fn, n):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -65,8 +86,9 @@ def main():
     snap = {k: v.clone() for k, v in r.state.items()}
     t_snap = r.t
     out = {}
-    for name, fn in (("fused gj_step", r.step), ("two groups", split_step), ("fused gj_step again", r.step),
-                     ("two groups again", split_step)):
+    for name, fn in (("fused gj_step", r.step), ("groups in sequence", split_step), ("groups side by side", forked_step),
+                     ("fused gj_step again", r.step), ("groups in sequence again", split_step),
+                     ("groups side by side again", forked_step)):
         for k, v in snap.items():
             r.state[k].copy_(v)
         r.t = t_snap
