@@ -89,7 +89,9 @@ def parse():
                     help="N > 1: capture the production step (kernels + RCCL collectives) in a hipGraph after the warm-up "
                          "and replay it per timed step (13.5 us of host time per step instead of ~100).  auto (default): "
                          "capture, replay ONE step against an eager step from the same state and keep the graph only if "
-                         "every rank's state agrees bit for bit - otherwise the eager step is timed and the JSON says why")
+                         "every rank's state agrees bit for bit - otherwise the eager step is timed and the JSON says why; then "
+                         "time 20 replays against 20 eager steps from one state and keep the faster form (the JSON "
+                         "carries both figures).  on: the validated graph without that trial")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the K-step timed region is run this many times back to back; `value` is the FIRST region, the "
                          "others give min / median / max (one 11 ms region per run is a noisy round-over-round figure)")
@@ -573,6 +575,53 @@ def capture_validated(runner, dev, backend, dist):
     return True, reason
 
 
+def faster_of_graph_and_eager(runner, dev, dist, n_steps: int = 20):
+    """``--graph auto``, after the captured step was validated: time ``n_steps`` replays and ``n_steps`` eager production
+    steps from the same state (barrier + synchronize around each, MAX over ranks - every rank sees the same two
+    numbers) and keep the faster form.  On one GPU a replayed rank-sized step measured 8 % SLOWER than the eager launches
+    (profiles/r04_*rank_share*: the graph's clock node and its node-to-node gaps), while eager steps need the host to
+    issue ~8 launches + 2-3 collectives per 0.12 ms step - which of the two wins depends on the host, so it is
+    measured where it runs.  The state, the timestep and the device clock are restored: the timed region starts where
+    it would have started.  Returns (graph in use, note)."""
+    keys = [k for k in ("is_infected", "susceptibility", "infection_time", "transmission", "q_transmission")
+            if runner.state.get(k) is not None]
+    saved = {k: runner.state[k].clone() for k in keys}
+    t_saved = runner.t
+
+    def restore():
+        for k in keys:
+            runner.state[k].copy_(saved[k])
+        runner.t = t_saved
+        runner.sync_clock()
+
+    def timed() -> float:
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            runner.step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return 1e3 * float(el.item()) / n_steps
+
+    runner.step()                       # (one replay outside the clock: the first replay after a capture pays the upload)
+    restore()
+    g = timed()
+    restore()
+    token = runner.suspend_graph()
+    runner.step()
+    restore()
+    e = timed()
+    restore()
+    note = f"{n_steps} steps each from one state: replay {g:.4f} ms, eager {e:.4f} ms per step"
+    if g <= e:
+        runner.resume_graph(token)
+        return True, note + " - replaying"
+    return False, note + " - eager launches"
+
+
 def main():
     args = parse()
     if args.preset == "june":
@@ -752,6 +801,9 @@ def main():
     sync()
     if want_graph:          # the last warm-up step is the eager step the first replay is compared with
         graph_on, graph_reason = capture_validated(runner, dev, args.backend, dist)
+        if graph_on and args.graph == "auto":
+            graph_on, note = faster_of_graph_and_eager(runner, dev, dist)
+            graph_reason += "; " + note
         sync()
     elif distributed:
         graph_reason = "--graph off" if args.graph == "off" else "no warm-up step to validate a captured step against"

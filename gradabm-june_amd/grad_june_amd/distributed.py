@@ -873,6 +873,26 @@ class DistributedHotPath:
         self._clock_ptr = None
         self._params_cache.clear()
 
+    def suspend_graph(self):
+        """Eager production steps for a while, the captured graph kept: returns the token ``resume_graph`` takes."""
+        token = self.graph
+        self.drop_graph()
+        return token
+
+    def resume_graph(self, token) -> None:
+        """Replay the graph ``suspend_graph`` put aside again, from the runner's current timestep."""
+        if token is None:
+            return
+        self.graph = token
+        self._clock_ptr = self.clock.ptr
+        self._params_cache.clear()
+        self.sync_clock()
+
+    def sync_clock(self) -> None:
+        """After ``self.t`` was set by hand (a state restored): the device clock the graph's first node advances."""
+        if self.graph is not None:
+            self.clock.set((1.0 + self.t) - self._delta_now, self.t - 1)
+
     def run_step(self, bufs, io, params_of, timed: bool = False):
         """The multi-rank launch sequence for one step.  ``params_of(None)`` gives the launch parameters of every
         active network, ``params_of(edge set names)`` those of the networks on these sets (the phase entry points

@@ -79,11 +79,18 @@ def test_rccl_step_is_captured_and_validated_by_default(device):
     """One rank under the nccl backend: the production step (asynchronous collectives) is captured after the warm-up,
     ONE replay is compared with the eager step from the same state, and the timed region replays the graph."""
     r = _run("--gpus", "1", "--force-distributed", "--agents", "400000", "--steps", "6", "--warmup", "3",
-             "--repeats", "2")
+             "--repeats", "2", "--graph", "on")
     assert r.returncode == 0, r.stderr[-4000:]
     j = _one_json_line(r.stdout)
     assert j["rccl_ranks"] == 1 and j["backend"] == "nccl"
     assert j["graph"] is True, j["graph_reason"]
+    # the default (--graph auto) also times replays against eager steps from one state and keeps the faster form; the
+    # state is restored, so the run ends where the others end
+    r0 = _run("--gpus", "1", "--force-distributed", "--agents", "400000", "--steps", "6", "--warmup", "3", "--repeats", "2")
+    assert r0.returncode == 0, r0.stderr[-4000:]
+    j0 = _one_json_line(r0.stdout)
+    assert "steps each from one state" in j0["graph_reason"] and ("replaying" in j0["graph_reason"]) == j0["graph"]
+    assert j0["state_checksum"] == j["state_checksum"]
     # the same run with the eager production step ends in the same state
     r2 = _run("--gpus", "1", "--force-distributed", "--agents", "400000", "--steps", "6", "--warmup", "3",
               "--repeats", "2", "--graph", "off")
