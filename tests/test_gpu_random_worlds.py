@@ -1,0 +1,177 @@
+"""GPU parity on RANDOM small worlds: the fused production step (through the C ABI, tiled and CSR layouts, random tile
+geometries) against the CPU oracle on the same seeded inputs and the same injected noise.
+
+The golden fixtures pin the reference's values on the reference's own worlds; this file covers what those worlds do not
+have - edge sets without edges, venues nobody attends, `people` that differs from the degree (p_contact is computed from
+`people`, base.py:63-70), duplicated (agent, venue) pairs, one venue holding a third of a set, agents without any edge,
+every subset of the eleven networks, both day types, quarantine on and off - in combinations nobody wrote down.
+
+Tolerances as in test_gpu_golden_parity.py: transmissions rtol 2e-5, probabilities atol 1e-5, decisions identical except
+where the oracle's Gumbel margin is below 1e-3, post-state equal wherever the decisions are."""
+import numpy as np
+import pytest
+import torch
+
+import gj_testlib as L
+
+pytestmark = pytest.mark.gpu
+
+SIZES = (37, 64, 200, 1000, 3000, 6000)
+
+
+def random_world(rng):
+    A = int(rng.choice(SIZES)) + int(rng.integers(0, 30))
+    names = [s for s in L.EDGE_SETS if rng.random() < 0.7] or ["household"]
+    sets = {}
+    for s in names:
+        V = int(rng.integers(1, max(2, A // int(rng.choice([1, 3, 20, 200])))))
+        E = 0 if rng.random() < 0.1 else int(rng.integers(1, 4 * A))
+        venue = rng.integers(0, V, E)
+        if E and rng.random() < 0.3:
+            venue[: E // 3] = int(rng.integers(0, V))             # one venue with a third of the set
+        agent = rng.integers(0, max(1, int(A * rng.choice([1.0, 0.5]))), E)    # 0.5: half the agents without an edge here
+        people = np.bincount(venue, minlength=V)
+        if rng.random() < 0.5:                                    # `people` is data of its own, not the degree
+            people = people + rng.integers(0, 3, V)
+        sets[s] = {"agent": torch.from_numpy(agent.astype(np.int64)), "venue": torch.from_numpy(venue.astype(np.int64)),
+                   "people": torch.from_numpy(people.astype(np.int64))}
+    return {"n_agents": A, "age": torch.from_numpy(rng.integers(0, 100, A).astype(np.int64)),
+            "sex": torch.from_numpy(rng.integers(0, 2, A).astype(np.int64)), "edge_sets": sets}
+
+
+def random_state(rng, A, now):
+    inf = (rng.random(A) < rng.choice([0.0, 0.02, 0.3, 0.9])).astype(np.float32)
+    inf[rng.random(A) < 0.01] = 2.0                               # `is_infected` is additive (model.py:103-110)
+    f32 = lambda x: torch.from_numpy(np.asarray(x, dtype=np.float32))
+    return {"max_infectiousness": f32(rng.lognormal(0.0, 0.5, A)), "shape": f32(rng.normal(1.56, 0.08, A)),
+            "rate": f32(rng.normal(0.53, 0.03, A)), "shift": f32(rng.normal(-2.12, 0.1, A)),
+            "infection_time": f32((now - 15.0 * rng.random(A)) * (inf > 0)), "is_infected": f32(inf),
+            "susceptibility": f32(np.where(inf > 0, 0.0, rng.choice([1.0, 0.4], A))),
+            "current_stage": f32(rng.integers(1, 7, A))}
+
+
+def random_layout(rng, A):
+    if rng.random() < 0.2:
+        return "csr", {}
+    kw = {}
+    if rng.random() < 0.7:
+        kw["sv_max"] = int(rng.choice([16, 64, 256]))
+        kw["eb_target"] = int(rng.choice([64, 512, 4096]))
+    if rng.random() < 0.7:
+        sa = int(rng.choice([64, 128, 512]))
+        kw["slices"] = (-(-A // sa), sa)
+    r = rng.random()
+    if r < 0.25:
+        kw["direct"] = False
+    if rng.random() < 0.3:
+        kw["desc_wide"] = bool(rng.random() < 0.5)
+    elif rng.random() < 0.2:
+        kw["desc_explicit"] = True
+    if rng.random() < 0.2:
+        kw["split_epilogue"] = True
+    return "tiled", kw
+
+
+@pytest.mark.parametrize("seed", range(150))
+def test_random_world_against_the_oracle(device, seed):
+    import gj_oracle as O
+    from grad_june_amd.engine import AgentBuffers
+
+    rng = np.random.default_rng(1000 + seed)
+    world = random_world(rng)
+    A = world["n_agents"]
+    now, dt, day_type = float(rng.choice([1.0, 7.5, 30.0])), float(rng.choice([1.0, 0.5, 1.0 / 3.0])), int(rng.integers(0, 2))
+    tables = {n: torch.from_numpy(rng.random((2, 2, 100)).astype(np.float32)) for n in L.LEISURE + ("care_visit",)
+              if rng.random() < 0.8}
+    specs = L.network_specs(world, tables)
+    if not specs:
+        pytest.skip("the draw has no network on any of its sets")
+    active = [s.name for s in specs if rng.random() < 0.8] or [specs[0].name]
+    hot = rng.random() < 0.3                                      # a third of the draws: an epidemic that takes off
+    betas = {n: float(rng.uniform(3.0, 40.0) if hot else rng.uniform(0.1, 3.0)) for n in active}
+    thr = None if rng.random() < 0.5 else [float(rng.choice([2.0, 3.0, 4.0]))]
+    state = random_state(rng, A, now)
+    noise = O.draw_exp_noise(A, generator=torch.Generator().manual_seed(seed))
+    ref = O.hot_path_step(world, {k: v.clone() for k, v in state.items()}, now=now, delta_time=dt, day_type=day_type,
+                          active=active, betas=betas, leisure_tables=tables, quarantine_thresholds=thr, exp_noise=noise)
+
+    layout, kw = random_layout(rng, A)
+    engine = L.make_engine(world, tables, device, layout=layout, **kw)
+    st = L.device_state(state, device)
+    bufs = AgentBuffers(engine.plan, max_infectiousness=st["max_infectiousness"], shape=st["shape"], rate=st["rate"],
+                        shift=st["shift"], infection_time=st["infection_time"], is_infected=st["is_infected"],
+                        susceptibility=st["susceptibility"], transmission=st["transmission"],
+                        current_stage=st["current_stage"])
+    p = engine.params(now=now, delta_time=dt, day_type=day_type, active=active, betas=betas, has_quarantine=thr is not None,
+                      q_threshold=L.q_threshold(thr))
+    probs, new = torch.empty(A, device=device), torch.empty(A, device=device)
+    engine.step(bufs, p, engine.io(not_infected_probs=probs, new_infected=new, exp_noise=noise.to(device).contiguous()))
+    torch.cuda.synchronize()
+    what = f"seed {seed}: {A} agents, sets {list(world['edge_sets'])}, active {active}, q {thr}, {layout} {kw}"
+    assert np.allclose(st["transmission"].cpu().numpy(), ref["transmission"].numpy(), rtol=2e-5, atol=1e-9), what
+    pr = ref["not_infected_probs"].numpy()
+    assert np.abs(probs.cpu().numpy() - pr).max() <= 1e-5, what
+    dec, dref = new.cpu().numpy() > 0.5, ref["new_infected"].numpy() > 0.5
+    bad = dec != dref
+    if bad.any():
+        t = torch.from_numpy(pr)
+        margin = (((1 - t).log() - noise[1].log()) / 0.1 - (t.log() - noise[0].log()) / 0.1).abs().numpy()
+        assert (margin[bad] < 1e-3).all(), what
+    ok = ~bad
+    for k in ("susceptibility", "is_infected", "infection_time"):
+        assert np.allclose(st[k].cpu().numpy()[ok], ref[k].numpy()[ok], rtol=1e-6, atol=1e-6), (what, k)
+
+
+# ---- the same kind of world cut into partitions (= the ranks of the multi-GPU path, collectives stood in on the device) ----
+JUNE_NETWORKS = ["school", "university", "company", "care_home", "pub", "gym", "grocery", "visit", "care_visit", "cinema",
+                 "household"]
+
+
+def random_bench_world(rng):
+    """A random world in the form bench.py / distributed.py take (numpy arrays, a `networks` list, a `state`)."""
+    from grad_june_amd.synthetic import edge_set_of
+
+    w = random_world(rng)
+    A = w["n_agents"]
+    sets = {k: {kk: vv.numpy() for kk, vv in v.items()} for k, v in w["edge_sets"].items()}
+    nets = [n for n in JUNE_NETWORKS if edge_set_of(n) in sets and rng.random() < 0.8] or \
+           [n for n in JUNE_NETWORKS if edge_set_of(n) in sets][:1]
+    st = random_state(rng, A, 1.0)
+    return {"preset": "random", "n_agents": A, "age": w["age"].numpy(), "sex": w["sex"].numpy(), "networks": nets,
+            "edge_sets": sets, "state": {k: v.numpy() for k, v in st.items()}}
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_world_partitions_equal_the_unpartitioned_run(device, seed, monkeypatch):
+    """2-8 partitions of a random world (per-venue exchange classes; in half of the draws with the split thresholds
+    lowered so that small sets are cut into a halo half and a partial-sum half too) against the single partition: the
+    same state after three steps.  Halo and local venues are bit-equal across partitions, partial-sum venues agree to
+    fp32 rounding of the partitions' terms - a decision can flip only within that of its Philox threshold."""
+    import bench as B
+    from grad_june_amd import distributed as D
+    from grad_june_amd.benchrun import SingleGpuHotPath
+
+    rng = np.random.default_rng(5000 + seed)
+    world = random_bench_world(rng)
+    if rng.random() < 0.5:
+        monkeypatch.setattr(D, "MIN_SPLIT_HALO_FLOATS", 8)
+        monkeypatch.setattr(D, "MIN_SPLIT_HALO_SHARE", 0.01)
+        monkeypatch.setattr(D, "MIN_SPLIT_VENUE_SHARE", 0.01)
+    if rng.random() < 0.25:
+        monkeypatch.setattr(D, "EXCHANGE_RULE", "set")
+    R = int(rng.choice([2, 3, 5, 8]))
+    specs = B.network_specs(world)
+    betas = {n: float(rng.uniform(0.5, 20.0)) for n in world["networks"]}
+    single = SingleGpuHotPath(world, specs, betas, device, seed=seed, layout="tiled")
+    parted = D.PartitionedHotPath(world, specs, betas, device, parts=R, seed=seed)
+    for _ in range(3):
+        single.step()
+        parted.step()
+    torch.cuda.synchronize()
+    what = f"seed {seed}: {world['n_agents']} agents, {R} partitions, modes {parted.ranks[0].rw.modes}"
+    ps = parted.state
+    differ = int((ps["is_infected"] != single.state["is_infected"]).sum())
+    assert differ <= 2, (what, differ)
+    if differ == 0:
+        for k in ("susceptibility", "infection_time"):
+            assert torch.equal(ps[k], single.state[k]), (what, k)
