@@ -175,3 +175,97 @@ def test_random_world_partitions_equal_the_unpartitioned_run(device, seed, monke
     if differ == 0:
         for k in ("susceptibility", "infection_time"):
             assert torch.equal(ps[k], single.state[k]), (what, k)
+
+
+# ---- gradients (row f3) on random worlds: the HIP backward against autograd through the oracle -------------------------
+def _hetero(G, world, state, device):
+    d = G.HeteroData()
+    A = world["n_agents"]
+    ag = d["agent"]
+    ag.id = torch.arange(A)
+    ag.age, ag.sex = world["age"], world["sex"]
+    for s, es in world["edge_sets"].items():
+        d[s].id = torch.arange(len(es["people"]))
+        d[s].people = es["people"]
+        d["agent", "attends_" + s, s].edge_index = torch.vstack((es["agent"], es["venue"]))
+    d = d.to(device)
+    st = {k: v.to(device) for k, v in state.items()}
+    ag.infection_parameters = {k: st[k] for k in ("max_infectiousness", "shape", "rate", "shift")}
+    for k in ("is_infected", "susceptibility", "infection_time"):
+        ag[k] = st[k].clone()
+    ag.transmission = torch.zeros(A, device=device)
+    ag.symptoms = {"current_stage": st["current_stage"].clone(), "next_stage": st["current_stage"].clone(),
+                   "time_to_next_stage": torch.full((A,), 1e9, device=device)}
+    return d
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_random_world_gradients_against_oracle_autograd(device, seed):
+    """d (cases after the last step, and summed over the steps) / d log_beta of every network through three chained
+    timesteps of `GradJune.hot_path` in grad mode (hand-written HIP adjoints) against torch autograd through the oracle
+    on the same injected noise - on worlds with empty sets, unattended venues, `is_infected` = 2, any subset of the
+    networks and a quarantine policy in half of the draws.  The oracle's autograd is pinned to the reference's recorded
+    gradients within 2e-4 (tests/test_gradients.py); the bound here is 1e-3 of the largest gradient of the draw (+ 1e-6)."""
+    import gj_oracle as O
+    import grad_june_amd as G
+    from grad_june_amd.defaults import default_parameters
+    from grad_june_amd.synthetic import edge_set_of
+
+    rng = np.random.default_rng(9000 + seed)
+    world = random_world(rng)
+    A = world["n_agents"]
+    names = [n for n in JUNE_NETWORKS if edge_set_of(n) in world["edge_sets"] and rng.random() < 0.8]
+    if not names:
+        pytest.skip("the draw has no network on any of its sets")
+    params = default_parameters(str(device))
+    params["networks"] = {n: {"log_beta": float(rng.uniform(-0.3, 1.2))} for n in names}
+    params["policies"] = {"interaction": {}}
+    thr = None
+    if rng.random() < 0.5:
+        thr = float(rng.choice([3.0, 4.0]))
+        params["policies"]["quarantine"] = {
+            "quarantine": {1: {"start_date": "2022-01-01", "end_date": "2022-12-31", "stage_threshold": thr}}}
+    model = G.GradJune.from_parameters(params)
+    acts = (tuple(names),)
+    timer = G.Timer(initial_day="2022-02-01", total_days=10, weekday_step_duration=(24,), weekend_step_duration=(24,),
+                    weekday_activities=acts, weekend_activities=acts)
+    state = random_state(rng, A, 0.0)
+    data = _hetero(G, world, state, device)
+    for n in names:
+        net = model.infection_networks.networks[n]
+        net.log_beta = torch.nn.Parameter(net.log_beta.detach().clone())
+    tables = {n: model.infection_networks.networks[n].leisure_probabilities.detach().cpu()
+              for n in names if edge_set_of(n) == "leisure"}
+    mult = {n: torch.ones((), requires_grad=True) for n in names}
+    st = {k: v.clone() for k, v in state.items()}
+    hip_series, ref_series = [], []
+    for i in range(3):
+        next(timer)
+        noise = O.draw_exp_noise(A, generator=torch.Generator().manual_seed(100 * seed + i))
+        betas = {n: float(model.infection_networks[n].beta_value(model.policies, timer)) for n in names}
+        model.hot_path(data, timer, exp_noise=noise)
+        hip_series.append(data["agent"].is_infected.sum())
+        out = O.hot_path_step(world, st, now=timer.now, delta_time=timer.duration,
+                              day_type=0 if timer.day_type == "weekday" else 1, active=names,
+                              betas={n: torch.tensor(np.float32(betas[n])) * mult[n] for n in names},
+                              leisure_tables=tables, quarantine_thresholds=None if thr is None else [thr], exp_noise=noise)
+        for k in ("susceptibility", "is_infected", "infection_time"):
+            st[k] = out[k]
+        ref_series.append(out["is_infected"].sum())
+        if not np.array_equal(data["agent"].is_infected.detach().cpu().numpy(), out["is_infected"].detach().numpy()):
+            pytest.skip(f"step {i}: a decision at a Gumbel tie differs - the two graphs are not the same function")
+    ps = [model.infection_networks.networks[n].log_beta for n in names]
+    for tag, hip, ref in (("last", hip_series[-1], ref_series[-1]),
+                          ("series", torch.stack(hip_series).sum(), torch.stack(ref_series).sum())):
+        if not hip.requires_grad:                        # nobody infectious meets anybody susceptible: no graph
+            assert not ref.requires_grad or all(g is None or float(g) == 0.0 for g in torch.autograd.grad(
+                ref, list(mult.values()), retain_graph=True, allow_unused=True)), tag
+            continue
+        got = [0.0 if g is None else float(g) for g in torch.autograd.grad(hip, ps, retain_graph=True, allow_unused=True)]
+        want = [0.0 if g is None else float(g) * np.log(10.0)
+                for g in torch.autograd.grad(ref, [mult[n] for n in names], retain_graph=True, allow_unused=True)]
+        scale = max(1e-6, max(abs(w) for w in want))
+        for n, a, b in zip(names, got, want):
+            # (+ 1e-6 absolute: a draw whose gradients are all ~1e-6 lives on agents at the probability floor, where
+            # 1 - p itself carries a relative fp32 error of several per cent in either implementation)
+            assert abs(a - b) <= 1e-3 * scale + 1e-6, (seed, tag, n, a, b, scale)
