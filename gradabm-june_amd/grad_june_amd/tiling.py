@@ -306,11 +306,11 @@ def build_tiled(name: str, agent_index, venue_index, n_venues: int, v_pcontact: 
         if explicit is None:
             explicit = bool(len(nseg)) and float((nseg > WIDE_SEGMENTS).mean()) > EXPLICIT_MIN_SHARE
     multi_slots = None
-    if explicit:
+    if explicit and E > 0:          # (a set without edges carries no slots, in either compile)
         # (every slice-major position, pads included: position p of tile t sits at tile_jpos[t] + (p - sptr[t]))
         t_of = np.searchsorted(sptr, np.arange(E, dtype=np.int64), side="right") - 1
         slot_idx = (jpos_sj.reshape(-1)[t_of] + (np.arange(E, dtype=np.int64) - sptr[t_of])).astype(np.int32)
-    elif multi_rows:
+    elif multi_rows and not explicit:
         chunk_desc, multi_slots = attach_multi_slots(np.ascontiguousarray(chunk_desc), bool(wide), first_edge, chunk_end,
                                                      sptr, jpos_sj.reshape(-1))
     return TiledEdgeSet(

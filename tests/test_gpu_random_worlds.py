@@ -269,3 +269,30 @@ def test_random_world_gradients_against_oracle_autograd(device, seed):
             # (+ 1e-6 absolute: a draw whose gradients are all ~1e-6 lives on agents at the probability floor, where
             # 1 - p itself carries a relative fp32 error of several per cent in either implementation)
             assert abs(a - b) <= 1e-3 * scale + 1e-6, (seed, tag, n, a, b, scale)
+
+
+# ---- the graph compile (row f4) on random worlds: the library's kernels against the numpy specification ----------------
+@pytest.mark.parametrize("seed", range(60))
+def test_random_world_device_compile_equals_the_numpy_compile(device, seed):
+    """`compile_plan(device=...)` (csrc/gj_compile.hip behind the C ABI) against `compile_plan` with numpy on the same random
+    world and the same random geometry: the work list and every array of every set bit for bit - tiles, descriptors (narrow,
+    wide, explicit slots, multi-slot rows), ELL rows - incl. sets without edges and venues without attendees."""
+    from grad_june_amd.plan import _host, compile_plan
+    from test_gpu_compile_native import assert_same_tiled
+
+    rng = np.random.default_rng(7000 + seed)
+    world = random_bench_world(rng)
+    A = world["n_agents"]
+    _, kw = random_layout(rng, A)
+    kw.pop("split_epilogue", None)
+    host = compile_plan(A, world["edge_sets"], age=world["age"], sex=world["sex"], layout="tiled", **kw)
+    dev = compile_plan(A, {k: {kk: torch.from_numpy(vv) for kk, vv in v.items()} for k, v in world["edge_sets"].items()},
+                       age=world["age"], sex=world["sex"], layout="tiled", device=device, **kw)
+    what = f"seed {seed}: {A} agents, {kw}"
+    assert np.array_equal(dev.work, host.work) and dev.n_slices == host.n_slices, what
+    for a, b in zip(dev.sets, host.sets):
+        assert (a.name, a.n_venues, a.n_edges) == (b.name, b.n_venues, b.n_edges), what
+        assert_same_tiled(a.tiled, b.tiled, what + " " + a.name)
+        assert a.tiled.ell_k == b.tiled.ell_k, (what, a.name)
+        if b.tiled.ell is not None:
+            assert np.array_equal(_host(a.tiled.ell).view(np.uint16), b.tiled.ell), (what, a.name)
