@@ -92,6 +92,8 @@ def parse():
                          "every rank's state agrees bit for bit - otherwise the eager step is timed and the JSON says why; then "
                          "time 20 replays against 20 eager steps from one state and keep the faster form (the JSON "
                          "carries both figures).  on: the validated graph without that trial")
+    ap.add_argument("--prewarm-ms", type=float, default=100.0,
+                    help="one GPU: milliseconds of stateless passes at the end of the set-up (0: none), see main()")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the K-step timed region is run this many times back to back; `value` is the FIRST region, the "
                          "others give min / median / max (one 11 ms region per run is a noisy round-over-round figure)")
@@ -794,6 +796,20 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # The timed region is 10 ms of GPU work after half a minute of host-side world generation: the first ~20 ms after
+    # such a pause run ~2 % slower than what follows (five back-to-back regions of one cold run: 0.501, 0.502, 0.492,
+    # 0.492, 0.489 ms per step - the GPU's clocks ramping).  The set-up therefore ends with >= 100 ms of STATELESS
+    # passes (transmission + both sparse passes + probabilities, no decision: the geometry tuner's measurement loop;
+    # the epidemic state, the timestep and the Philox counter stay where they are), then the W warm-up steps follow.
+    prewarm = None
+    if not distributed and hasattr(runner, "time_stateless") and args.prewarm_ms > 0:
+        t0, n_pass = time.perf_counter(), 0
+        while 1e3 * (time.perf_counter() - t0) < args.prewarm_ms:
+            runner.time_stateless(steps=20, repeats=1)
+            n_pass += 22
+        prewarm = {"ms": 1e3 * (time.perf_counter() - t0), "stateless_passes": n_pass,
+                   "what": "set-up: stateless passes of the hot path before the warm-up steps, so that the timed region "
+                           "does not sit on the GPU's clock ramp after the host-side world generation"}
     graph_on, graph_reason = False, "single GPU: the step is one gj_step call"
     want_graph = distributed and hasattr(runner, "capture") and args.graph != "off" and args.warmup > 0
     for _ in range(args.warmup - (1 if want_graph else 0)):
@@ -1005,6 +1021,8 @@ def main():
     out.update(extra)
     if sustained:
         out["sustained"] = sustained
+    if prewarm is not None:
+        out["prewarm"] = prewarm
     if full:
         out["full_step"] = full
     if high:
