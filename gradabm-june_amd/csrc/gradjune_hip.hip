@@ -170,8 +170,8 @@ __global__ __launch_bounds__(kThreads) void k_transmission(
       const float4 c = load_nt(reinterpret_cast<const float4*>(rt) + i);
       const float4 d = load_nt(reinterpret_cast<const float4*>(sh) + i);
       const float4 e = load_nt(reinterpret_cast<const float4*>(t_inf) + i);
-      // The profile (lgammaf ~420, powf ~200, two expf: ~690 instructions) is evaluated by a wave for all 64 lanes
-      // whenever one of them needs it.  Each lane therefore takes ITS infected agents one after the other: a wave makes
+      // The profile (~100 instructions since round 3, ~690 with libm - see inv_gamma) is evaluated by a wave for all 64
+      // lanes whenever one of them needs it.  Each lane therefore takes ITS infected agents one after the other: a wave makes
       // as many evaluations as its busiest lane has infected agents (at 1 % prevalence ~1 instead of ~2 with one
       // evaluation per component, at 30 % 3.4 of 4): 67 -> 62 us on C3.  (Measured, not adopted: exp(-lgamma(shape)),
       // 60 % of those instructions and a per-agent constant, cached in a sixth parameter array - 6 us SLOWER: with
