@@ -296,3 +296,62 @@ def test_random_world_device_compile_equals_the_numpy_compile(device, seed):
         assert a.tiled.ell_k == b.tiled.ell_k, (what, a.name)
         if b.tiled.ell is not None:
             assert np.array_equal(_host(a.tiled.ell).view(np.uint16), b.tiled.ell), (what, a.name)
+
+
+# ---- medium-sized benchmark worlds in random geometries against the oracle ----------------------------------------------
+MEDIUM = [("c3", "random", 60_000), ("c3", "clustered", 150_000), ("c5", "random", 120_000), ("c5", "clustered", 300_000),
+          ("june", "clustered", 100_000), ("june", "clustered", 250_000), ("c2", "random", 200_000), ("c2", "clustered", 80_000)]
+
+
+@pytest.mark.parametrize("preset,geography,n_agents", MEDIUM)
+@pytest.mark.parametrize("variant", [0, 1])
+def test_medium_world_in_a_random_geometry_against_the_oracle(device, preset, geography, n_agents, variant):
+    """The benchmark presets (random and clustered geographies; power-law venues; the eleven networks of the `june`
+    preset) at 60 k - 300 k agents - large enough for wide descriptors, rows of explicit slots, wave-wide venue runs, the
+    run form of the households and several slices of up to 19 840 agents - in a random tile geometry, one fused step
+    against the oracle on injected noise, with a quarantine policy in every second case."""
+    import bench as B
+    import gj_oracle as O
+    from grad_june_amd.benchrun import SingleGpuHotPath
+    from grad_june_amd.synthetic import make_world, reorder_agents
+
+    import zlib
+
+    rng = np.random.default_rng(zlib.crc32(f"{preset} {geography} {n_agents} {variant}".encode()))
+    world = make_world(preset, n_agents=n_agents, seed=int(rng.integers(1 << 30)), infected_fraction=0.05, geography=geography)
+    if variant:
+        world = reorder_agents(world, by="household")
+    specs = B.network_specs(world)
+    betas = {n: 4.0 * v for n, v in B.betas_of(world).items()}
+    kw = {}
+    if rng.random() < 0.6:
+        kw["sv_max"], kw["eb_target"] = int(rng.choice([256, 2048, 16384])), int(rng.choice([2048, 32768, 131072]))
+    if rng.random() < 0.6:
+        sa = int(rng.choice([1024, 4928, 19840]))
+        kw["slices"] = (-(-n_agents // sa), sa)
+    if rng.random() < 0.3:
+        kw["direct"] = False
+    thr = 4.0 if variant else None
+    A = world["n_agents"]
+    noise = O.draw_exp_noise(A, generator=torch.Generator().manual_seed(n_agents + variant))
+    w = {"n_agents": A, "age": torch.from_numpy(world["age"]), "sex": torch.from_numpy(world["sex"]),
+         "edge_sets": {k: {kk: torch.from_numpy(vv) for kk, vv in v.items()} for k, v in world["edge_sets"].items()}}
+    st = {k: torch.from_numpy(v.copy()) for k, v in world["state"].items()}
+    tables = {s.name: torch.from_numpy(s.table) for s in specs if s.table is not None}
+    ref = O.hot_path_step(w, st, now=1.0, delta_time=1.0, day_type=0, active=world["networks"], betas=betas,
+                          leisure_tables=tables, quarantine_thresholds=None if thr is None else [thr], exp_noise=noise)
+    r = SingleGpuHotPath(world, specs, betas, device, seed=0, layout="tiled", exp_noise=noise.to(device),
+                         quarantine_threshold=thr, **kw)
+    r.step()
+    torch.cuda.synchronize()
+    what = f"{preset} {geography} {n_agents} variant {variant}: {kw}"
+    pr = ref["not_infected_probs"].numpy()
+    assert np.abs(r.probs.cpu().numpy() - pr).max() <= 1e-5, what
+    dec, dref = r.new_infected.cpu().numpy() > 0.5, ref["new_infected"].numpy() > 0.5
+    bad = dec != dref
+    if bad.any():
+        t = torch.from_numpy(pr)
+        margin = (((1 - t).log() - noise[1].log()) / 0.1 - (t.log() - noise[0].log()) / 0.1).abs().numpy()
+        assert (margin[bad] < 1e-3).all() and bad.sum() <= 3, what
+    assert dref.sum() > 0.002 * A, (what, int(dref.sum()))
+    assert np.allclose(r.state["transmission"].cpu().numpy(), ref["transmission"].numpy(), rtol=2e-5, atol=1e-9), what
