@@ -2,7 +2,7 @@ import sys, os
 ROOT=os.environ.get("GRAFT_REPO_ROOT","/root/repo")
 for p in ("gradabm-june_amd","oracle","tests"): sys.path.insert(0, os.path.join(ROOT,p))
 sys.path.insert(0, ROOT)
-import numpy as np, torch
+import torch
 import grad_june_amd as G
 from test_gradients import load_case, step_info, _model_and_timer, _hetero
 dev=torch.device("cuda:0")

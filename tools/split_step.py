@@ -53,7 +53,6 @@ def main():
         r.t += 1
 
     streams = [torch.cuda.Stream(device=dev) for _ in groups[1:]]
-    cache = {}
 
     def forked_step():
         """The groups side by side: group 0 on the current stream, the others on streams of their own (fork after the
