@@ -626,6 +626,10 @@ def faster_of_graph_and_eager(runner, dev, dist, n_steps: int = 20):
 
 def main():
     args = parse()
+    if os.environ.get("GJ_DUMP_STACKS_AFTER"):      # diagnostics: every rank prints its Python stack after that many seconds
+        import faulthandler
+
+        faulthandler.dump_traceback_later(float(os.environ["GJ_DUMP_STACKS_AFTER"]), exit=False)
     if args.preset == "june":
         args.geography = "clustered"          # (the preset is always drawn on a map; the JSON says so)
     if args.generator == "auto":

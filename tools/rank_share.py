@@ -119,6 +119,7 @@ def main():
         "infected_fraction": {"start": inf0, "end": float(hp.state["is_infected"].clamp(max=1).mean())},
         "setup_s": {"stream_and_partition": t_part, "total": t_setup},
         "host_peak_rss_mb": resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0,
+        "hbm_peak_gb": {"allocated": torch.cuda.max_memory_allocated() / 1e9, "reserved": torch.cuda.max_memory_reserved() / 1e9},
     }
     if stamps is not None:
         import numpy as np
